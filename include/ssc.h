@@ -1,0 +1,332 @@
+/*
+ * ssc.h - C ABI of libssc_hip.so: the MI355X (gfx950) Style-SeqCVAE hot path.
+ *
+ * The reference (visinf/style-seqcvae) has NO native boundary on this path: its hot path is stock
+ * PyTorch ops behind the Python module API var_updown.models.UpDownCaptioner /
+ * var_updown.modules.UpDownCell.  This header is the boundary the build creates
+ * underneath that API; each entry point cites the reference code it replaces (paths relative to
+ * /root/reference).
+ *
+ * Conventions
+ *  - plain C: raw device pointers, ints, floats; no torch / C++ types.
+ *  - all tensors fp32 row-major unless noted; token ids int64; `ld*` = leading dimension in floats.
+ *  - every buffer is caller-allocated device memory (e.g. torch tensor .data_ptr()), kept alive by
+ *    the caller until `stream` is synchronised.  The library allocates nothing, keeps no global
+ *    mutable state, is re-entrant per stream and safe under hipGraph capture.
+ *  - `stream` is a hipStream_t passed as void* (0 = default stream).
+ *  - return value: 0 on success, negative SSC_E* otherwise; never throws.
+ */
+#ifndef SSC_H
+#define SSC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSC_OK 0
+#define SSC_EINVAL (-1)   /* bad shape / argument */
+#define SSC_EALIGN (-2)   /* pointer or leading dimension violates an alignment requirement */
+#define SSC_EHIP (-3)     /* a HIP runtime call failed (see ssc_last_hip_error) */
+#define SSC_EWORKSPACE (-4) /* workspace too small */
+
+#define SSC_MAX_SEG 6
+
+int ssc_version(void);              /* ABI version (this header: 1) */
+int ssc_last_hip_error(void);       /* last hipError_t observed by this thread */
+const char* ssc_arch(void);         /* "gfx950" */
+
+/* ------------------------------------------------------------------------------------------------
+ * GEMM: C[M,N] (+)= sum_s op(A_s)[M,K_s] * op(B_s)[K_s,N] (+ bias[N])     exact-fp32 MFMA
+ * (v_mfma_f32_32x32x2_f32).  Replaces aten::mm / aten::addmm under nn.LSTMCell, nn.Linear
+ * (var_updown/var_updown/modules/updown_cell.py:146,192,196-197,227;
+ *  updown-baseline/updown/modules/attention.py:69,125; var_updown/.../updown_captioner.py:444-445)
+ * and their autograd backward.  K is segmented so that torch.cat inputs (updown_cell.py:143,178,211)
+ * are never materialised: segment s multiplies a column block of the weight with its own source.
+ *   a_kc=1: A_s is (M,K_s) row-major (lda>=K_s)   a_kc=0: A_s is (K_s,M) row-major (A given transposed)
+ *   b_kc=1: B_s is (N,K_s) row-major (weights as stored, out x in)   b_kc=0: B_s is (K_s,N) row-major
+ * splits>1 splits the K loop over `splits` workgroups per tile; partial slabs go to `workspace`
+ * (>= splits*M*N floats) and are reduced (deterministically) by a second kernel.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  const float* A; const float* B;
+  int lda, ldb, K;
+} ssc_gemm_seg;
+
+typedef struct {
+  ssc_gemm_seg seg[SSC_MAX_SEG];
+  int nseg;
+  int M, N;
+  int a_kc, b_kc;
+  float* C; int ldc;
+  const float* bias;   /* optional (N) */
+  int accumulate;      /* 1: C += result */
+  int splits;          /* >=1; 0 = choose automatically */
+  float* workspace; size_t workspace_floats;
+} ssc_gemm_desc;
+
+int ssc_gemm(const ssc_gemm_desc* d, void* stream);
+int ssc_gemm_auto_splits(int M, int N, int ksteps); /* the split count ssc_gemm picks for splits=0 */
+
+/* ------------------------------------------------------------------------------------------------
+ * Per-sequence precompute
+ * ---------------------------------------------------------------------------------------------- */
+/* region mask + masked mean: UpDownCell._average_image_features (updown_cell.py:233-270) +
+ * allennlp masked_mean.  feats (B,R,F) -> mask (B,R) float {0,1}, avg (B,F). */
+int ssc_feat_prep(const float* feats, int B, int R, int F, float* mask, float* avg, void* stream);
+
+/* boundary tokens + loss weights: allennlp add_sentence_boundary_token_ids as called at
+ * updown_captioner.py:265-278.  caps (B,L) int64 -> tokens_tm (L+2,B) int64 time-major,
+ * w_tm (T=L+1,B) float = [tokens[b,t+1] != pad], nvalid (B) float = sum_t w. */
+int ssc_prep_tokens(const int64_t* caps, int B, int L, int pad, int boundary, int64_t* tokens_tm, float* w_tm,
+                    float* nvalid, void* stream);
+
+/* nn.Embedding forward (updown_captioner.py:430): out[i,:] = table[ids[i],:]  (n rows, E cols). */
+int ssc_embed_gather(const float* table, int ldt, const int64_t* ids, int n, int E, float* out, int ldo, void* stream);
+/* nn.Embedding backward: dtable[ids[i],:] += d[i,:] for ids[i] != pad (padding_idx row gets no grad). */
+int ssc_embed_scatter_add(float* dtable, int ldt, const int64_t* ids, int n, int E, const float* d, int ldd, int pad,
+                          void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * LSTM cell epilogue: torch.nn.LSTMCell pointwise part (gate order i,f,g,o), fused with the split-K
+ * slab reduction, the hoisted time-invariant gate terms, both biases and the rank-1 sentiment
+ * column (updown_cell.py:146-148,192-194,227-229).
+ *   pre[b,n] = sum_{s<nslab} slabs[s][b,n] + add0[b,n] + add1[row1(b),n] + b_ih[n] + b_hh[n]
+ *              + sent[b]*wcol[n*ldwcol]
+ *   gates_out (B,4H) = activated (i,f,g,o);  c_out = f*c_prev + i*g;  h_out = o*tanh(c_out)
+ * add1 is indexed by b / rows_per_add1 (decode: per-image hoisted term).  Any optional pointer may be 0.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  int B, H;
+  const float* slabs; int nslab; size_t slab_stride; /* each slab (B,4H), ld 4H */
+  const float* add0; int ld_add0;
+  const float* add1; int ld_add1; int rows_per_add1;
+  const float* b_ih; const float* b_hh;
+  const float* sent; const float* wcol; int ldwcol;
+  const float* c_prev; int ld_cprev;
+  float* gates_out;            /* (B,4H) activated, ld 4H; may be 0 */
+  float* c_out; int ld_cout;
+  float* h_out; int ld_hout;
+} ssc_lstm_fwd_desc;
+int ssc_lstm_fwd(const ssc_lstm_fwd_desc* d, void* stream);
+
+/* LSTMCell pointwise backward (SURVEY Appendix A.4 "LSTM^-1"):
+ *   dh (B,H) (+ dh2 optional second addend), dc_in (B,H), gates (activated), c_prev, c_new
+ *   -> dG (B,4H) pre-activation grads, dc_prev (B,H).  If dgsum != 0: dgsum += dG. */
+typedef struct {
+  int B, H;
+  const float* dh; int ld_dh;
+  const float* dh2; int ld_dh2;
+  const float* dc_in; int ld_dcin;
+  const float* gates;
+  const float* c_prev; int ld_cprev;
+  const float* c_new; int ld_cnew;
+  float* dG;                   /* (B,4H) ld 4H */
+  float* dc_prev; int ld_dcprev;
+  float* dgsum;                /* optional (B,4H) running sum over time */
+} ssc_lstm_bwd_desc;
+int ssc_lstm_bwd(const ssc_lstm_bwd_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Bottom-up top-down attention step: BottomUpTopDownAttention.forward after the q projection
+ * (attention.py:78-95) + allennlp masked_softmax + the weighted sum (updown_cell.py:156-158).
+ *   logit[g,r] = wa . tanh(q[g] + pv[img(g),r]);  alpha = masked_softmax(logit, mask[img(g)])
+ *   att[g,:]  = sum_r alpha[g,r] feats[img(g),r,:]          img(g) = g / rows_per_image
+ * ---------------------------------------------------------------------------------------------- */
+int ssc_attn_logits(const float* q, int ldq, const float* pv, const float* wa, int G, int R, int A, int rows_per_image,
+                    float* logits, void* stream);
+/* logits: scratch (G,R); alpha (G,R); R <= 256 */
+int ssc_attn_fwd(const float* q, int ldq, const float* pv, const float* wa, const float* mask, const float* feats,
+                 int G, int R, int A, int F, int rows_per_image, float* logits, float* alpha, float* att, int ldatt,
+                 void* stream);
+
+/* Attention backward: datt (G,F) -> dq (G,A), dpv_acc (G,R,A) += dpre,
+ * dwa_acc (G,A) += sum_r dl_r u_r (caller sums over G at the end).  Training only (rows_per_image=1). */
+int ssc_attn_bwd(const float* datt, int lddatt, const float* q, int ldq, const float* pv, const float* wa,
+                 const float* alpha, const float* feats, int G, int R, int A, int F, float* dq, int lddq,
+                 float* dpv_acc, float* dwa_acc, float* scratch_dalpha, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Latent head epilogue: fc_mean / fc_log_var bias add, reparameterised sample and closed-form KL
+ * (updown_cell.py:196-208, updown_captioner.py:295-303).
+ *   mulv (B,2Z) raw [h_e Wmu^T | h_e Wlv^T] (ld ldmulv);  mu = mulv[:, :Z]+bmu;  lv = mulv[:, Z:]+blv
+ *   z = eps*exp(lv/2)+mu;  kld_t[b] per formula (mode 0: vs N(0,1); mode 1: vs N(prior_mean, prior_var+1e-5))
+ *   kld_acc[b] += w[b]*kld_t[b].   prior_mean per row = pm_scale*sent[b] (or 0), prior_var scalar.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  int B, Z;
+  const float* mulv; int ldmulv; int nslab; size_t slab_stride;
+  const float* bmu; const float* blv;
+  const float* eps; int ldeps;
+  int kld_mode;                 /* 0: SENTIMENT_VAE==0 ; 1: otherwise */
+  const float* sent; float pm_scale; float prior_var;
+  const float* w;               /* (B) step weights w_bt */
+  float* mu; float* lv; float* z; int ldz; /* mu, lv, z: (B, ldz) */
+  float* kld_acc;               /* (B) */
+} ssc_latent_fwd_desc;
+int ssc_latent_fwd(const ssc_latent_fwd_desc* d, void* stream);
+
+/* eval-mode sample: z = eps*sqrt(prior_var) + prior_mean (updown_cell.py:200-208). */
+int ssc_latent_prior_sample(const float* eps, int ldeps, const float* sent, float pm_scale, float prior_var, int G, int Z,
+                            float* z, int ldz, void* stream);
+
+/* latent backward (Appendix A.4): dz -> dmulv (B,2Z) = [dmu | dlv];  k[b] = gk[b]*w[b]. */
+typedef struct {
+  int B, Z;
+  const float* dz; int lddz;
+  const float* eps; int ldeps;
+  const float* mu; const float* lv; int ldz;
+  int kld_mode; const float* sent; float pm_scale; float prior_var;
+  const float* w; const float* gk; /* (B) step weights, (B) upstream grad of kld_b */
+  float* dmulv; int lddmulv;
+} ssc_latent_bwd_desc;
+int ssc_latent_bwd(const ssc_latent_bwd_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Vocabulary cross-entropy: allennlp sequence_cross_entropy_with_logits(average=None) times the
+ * target length (updown_captioner.py:457-466).  logits (T*B, V) time-major rows (row = t*B+b).
+ *   fwd: nll[row] = lse - logits[row,target];  loss[b] = n_b * sum_t w*nll / (n_b + 1e-13)
+ *        `lse` must hold 2*T*B floats: [lse | w*nll]
+ *   bwd (in place): logits[row,:] <- (softmax - onehot) * gl[b] * w[row] * n_b/(n_b+1e-13)
+ * ---------------------------------------------------------------------------------------------- */
+int ssc_ce_fwd(const float* logits, int ldl, const int64_t* targets, const float* w, const float* nvalid, int T, int B,
+               int V, float* lse, float* loss, void* stream);
+int ssc_ce_bwd(float* logits, int ldl, const int64_t* targets, const float* w, const float* nvalid, const float* lse,
+               const float* gl, int T, int B, int V, void* stream);
+/* row-wise log_softmax (updown_captioner.py:450, nn.LogSoftmax(dim=1)); in place allowed. */
+int ssc_log_softmax(const float* logits, int ldl, int rows, int V, float* out, int ldo, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Small reductions / elementwise
+ * ---------------------------------------------------------------------------------------------- */
+/* out[n] (+)= sum_rows wrow[row]*X[row,n]  (bias grads: wrow=0 -> weights 1; sentiment column grads) */
+int ssc_colsum(const float* X, int ldx, int rows, int N, const float* wrow, float* out, int out_stride, int accumulate,
+               void* stream);
+/* y = tanh(x + bias) (tied output projection, updown_captioner.py:115-117) and its backward dy*(1-y^2) */
+int ssc_bias_tanh(float* x, int ldx, int rows, int N, const float* bias, void* stream);
+int ssc_tanh_bwd(float* dy, int lddy, const float* y, int ldy, int rows, int N, void* stream);
+int ssc_fill(float* p, size_t n, float v, void* stream);
+
+/* clip_grad_norm_ + SGD(momentum, weight_decay) (var_updown/scripts/train.py:126-131,173-175) on flat buffers.
+ *   ssc_sq_norm: partial sums of g^2 -> out (1 float, accumulated deterministically via 2 passes; scratch>=1024 floats)
+ *   ssc_sgd_step: g' = g*gscale*min(1, max_norm/(sqrt(*sqnorm)*gscale+1e-6)); d = g' + wd*p;
+ *                 buf = first ? d : mom*buf + d;  p -= lr*buf.     gscale folds the 1/world_size of DP. */
+int ssc_sq_norm(const float* g, size_t n, float* scratch, float* out, void* stream);
+int ssc_sgd_step(float* p, const float* g, float* buf, size_t n, const float* sqnorm, float gscale, float max_norm,
+                 float lr, float momentum, float weight_decay, int first, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Model / sequence level: the T-step teacher-forced training forward and its BPTT
+ * (UpDownCaptioner.forward training branch, updown_captioner.py:228-323; _decode_step :371-455;
+ *  UpDownCell.forward updown_cell.py:86-231; backward = what autograd derives, Appendix A.4).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  int V, E, H, A, F, Z;
+  int S;            /* sentiment columns on the language LSTMs: 0 or 1 (updown_cell.py:47-81) */
+  int tied;         /* 1: frozen tied embedding + Linear/Tanh projection (updown_captioner.py:112-119) */
+  int kld_mode;     /* 0: SENTIMENT_VAE==0 formula; 1: otherwise (updown_captioner.py:298-303) */
+  float pm_scale;   /* prior_mean = pm_scale * sentiment (0 for SENTIMENT_VAE 0 / SIMPLE_VAE) */
+  float prior_var;  /* PRIOR_STD^2 */
+  int pad, boundary;
+} ssc_model_cfg;
+
+/* Parameter (or gradient) table: device pointers + leading dimensions of 2-D weights. */
+typedef struct {
+  float* emb; int ld_emb;                         /* _embedding_layer.weight (V,E) */
+  float* att_w_ih; int ld_att_w_ih;               /* (4H, E+F+2H) */
+  float* att_w_hh; int ld_att_w_hh;               /* (4H, H) */
+  float* att_b_ih; float* att_b_hh;               /* (4H) */
+  float* wq; int ld_wq;                           /* (A,H) */
+  float* wv; int ld_wv;                           /* (A,F) */
+  float* wa;                                      /* (A) */
+  float* enc_w_ih; int ld_enc_w_ih;               /* (4H, F+2H+S) */
+  float* enc_w_hh; int ld_enc_w_hh;
+  float* enc_b_ih; float* enc_b_hh;
+  float* dec_w_ih; int ld_dec_w_ih;               /* (4H, F+2H+S+Z) */
+  float* dec_w_hh; int ld_dec_w_hh;
+  float* dec_b_ih; float* dec_b_hh;
+  float* fc_mean_w; int ld_fc_mean_w;             /* (Z,H) */
+  float* fc_mean_b;
+  float* fc_lv_w; int ld_fc_lv_w;
+  float* fc_lv_b;
+  float* out_w; int ld_out_w;                     /* untied: _output_layer.weight (V,H); tied: unused */
+  float* out_b;                                   /* untied: (V) */
+  float* proj_w; int ld_proj_w;                   /* tied: _output_projection.0.weight (E,H) */
+  float* proj_b;                                  /* tied: (E) */
+} ssc_params;
+
+typedef struct {
+  int B, R, L;                 /* minibatch rows, regions, caption length (T = L+1 steps) */
+  const float* feats;          /* (B,R,F) */
+  const int64_t* caps;         /* (B,L) 0-padded, no boundary tokens */
+  const float* sentiment;      /* (B) (ignored when cfg.S==0 and pm_scale==0) */
+  const float* eps;            /* (T,B,Z) standard normal noise, ld Z */
+} ssc_batch;
+
+size_t ssc_train_workspace_bytes(const ssc_model_cfg* cfg, int B, int R, int L);
+
+/* forward: fills loss (B), kld (B); keeps activations in `workspace` for ssc_train_bwd. */
+int ssc_train_fwd(const ssc_model_cfg* cfg, const ssc_params* p, const ssc_batch* batch, void* workspace,
+                  size_t workspace_bytes, float* loss, float* kld, void* stream);
+
+/* backward: gl (B), gk (B) = upstream grads of loss_b, kld_b.  Gradients are WRITTEN (not
+ * accumulated) into `g` (same layout as p); a null pointer in `g` skips that parameter's gradient
+ * (frozen decoder LSTM, train.py:156-161; frozen tied embedding).  */
+int ssc_train_bwd(const ssc_model_cfg* cfg, const ssc_params* p, const ssc_batch* batch, void* workspace,
+                  size_t workspace_bytes, const float* gl, const float* gk, const ssc_params* g, void* stream);
+
+/* read-back of saved per-step activations for tests: which = 0:h1 1:c1 2:h_enc 3:c_enc 4:h_dec 5:c_dec
+ * (each (T+1,B,H), index 0 = initial zeros), 6: alpha (T,B,R), 7: mu (T,B,Zp), 8: lv (T,B,Zp), 9: logits (T*B,V),
+ * 10: tokens (L+2,B) int64, 11: att (T,B,F).  Returns pointer into the workspace (and its ld) or 0. */
+void* ssc_train_workspace_view(const ssc_model_cfg* cfg, int B, int R, int L, void* workspace, int which, int* ld);
+
+/* ------------------------------------------------------------------------------------------------
+ * Eval-mode decode step (UpDownCaptioner._decode_step with training=False, updown_captioner.py:371-455;
+ * UpDownCell.forward training=False branch, updown_cell.py:200-229).  G rows, batch-major:
+ * row g belongs to image g / rows_per_image; per-image terms (mask, avg, pv, hoisted gate term)
+ * come from ssc_decode_prepare and are computed once per image instead of per step.
+ * ---------------------------------------------------------------------------------------------- */
+size_t ssc_decode_image_bytes(const ssc_model_cfg* cfg, int nimg, int R);
+int ssc_decode_prepare(const ssc_model_cfg* cfg, const ssc_params* p, const float* feats, int nimg, int R, void* imgbuf,
+                       size_t imgbuf_bytes, void* stream);
+
+typedef struct {
+  int G, R, rows_per_image;
+  const float* feats;        /* (nimg,R,F) */
+  const void* imgbuf;        /* from ssc_decode_prepare */
+  const int64_t* tokens;     /* (G) previous predictions */
+  const float* sentiment;    /* (G) per-row sentiment */
+  const float* eps;          /* (G,Z) ld Z */
+  /* states in (G,H) each, ld H; h_encoder / c_encoder are carried untouched by the caller */
+  const float* h1; const float* c1; const float* hd; const float* cd;
+  float* h1_out; float* c1_out; float* hd_out; float* cd_out;
+  float* alpha;              /* (G,R) */
+  float* log_probs;          /* (G,V) ld V */
+} ssc_decode_step_desc;
+size_t ssc_decode_step_workspace_bytes(const ssc_model_cfg* cfg, int G, int R);
+int ssc_decode_step(const ssc_model_cfg* cfg, const ssc_params* p, const ssc_decode_step_desc* d, void* workspace,
+                    size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Constrained beam search bookkeeping on device (updown-baseline/updown/modules/cbs.py:59-277).
+ *   ssc_beam_first : first step (:127-145): per (b, state s) top-`beam` of log_probs[b,:] masked by fsm[b,0,s,:]
+ *   ssc_beam_step  : one later step (:170-234): ended beams forced to end_index, per target state i the
+ *                    masked (-1e20) top-`per_node` per row, + running log-prob, top-`beam` over S*beam*per_node;
+ *                    backpointer = idx / per_node (floor).  Ties resolve to the lowest index.
+ *   ssc_gather_rows: state re-ordering by backpointer (:236-250).
+ * fsm (B,S,S,V) uint8.  Row order (batch, fsm_state, beam).
+ * ---------------------------------------------------------------------------------------------- */
+int ssc_beam_first(const float* log_probs, int ldlp, const uint8_t* fsm, int B, int S, int V, int beam,
+                   int64_t* pred, float* lp_out, void* stream);
+int ssc_beam_step(const float* log_probs, int ldlp, const uint8_t* fsm, const int64_t* last_pred, const float* last_lp,
+                  int B, int S, int V, int beam, int per_node, int end_index, int64_t* pred, float* lp_out,
+                  int64_t* backptr, float* scratch_val, int64_t* scratch_idx, void* stream);
+int ssc_gather_rows(const float* src, int ld, const int64_t* backptr, int B, int rows_per_batch, int W, float* dst,
+                    void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSC_H */

@@ -1,0 +1,220 @@
+// Bottom-up top-down attention step for gfx950: additive attention logits, allennlp-style masked
+// softmax over R regions and the weighted sum of region features, plus the backward.
+// Reference: updown-baseline/updown/modules/attention.py:69-95 (logits + masked_softmax),
+// var_updown/var_updown/modules/updown_cell.py:151-158 (weighted sum).  The reference's
+// q.repeat (attention.py:78-80) is never materialised.
+//
+// HBM-bound (AI ~ 0.55 flop/B): per step it must read pv (G,R,A) and feats (G,R,F) once.
+//   logits : one 64-lane wave per (row, region) - 16 B/lane reads of pv, shuffle reduction of the
+//            A-dot; grid = G*R waves (2304 at B=64,R=36) fills the 256 CUs.
+//   apply  : one wave per (row, 256-float feature chunk): the wave re-derives the row's softmax with
+//            shuffles (R <= a few hundred, negligible) and streams its feature columns once with
+//            R independent 1 KiB loads in flight; grid = G * F/256 waves.
+#include "ssc_common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void attn_logits_kernel(const float* __restrict__ q, int ldq,
+                                                          const float* __restrict__ pv, const float* __restrict__ wa,
+                                                          int G, int R, int A, int rows_per_image,
+                                                          float* __restrict__ logits) {
+  int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+  int lane = threadIdx.x & 63;
+  if (wid >= G * R) return;
+  int g = wid / R, r = wid - g * R;
+  int img = g / rows_per_image;
+  const float* qp = q + (size_t)g * ldq;
+  const float* pp = pv + ((size_t)img * R + r) * A;
+  float s = 0.f;
+  if (((A & 3) == 0) && ((ldq & 3) == 0) && ssc_aligned16_dev(qp) && ssc_aligned16_dev(pp) && ssc_aligned16_dev(wa)) {
+    for (int a = lane * 4; a < A; a += 256) {
+      float4 qv = *reinterpret_cast<const float4*>(qp + a);
+      float4 p4 = *reinterpret_cast<const float4*>(pp + a);
+      float4 w4 = *reinterpret_cast<const float4*>(wa + a);
+      s += w4.x * tanhf(qv.x + p4.x) + w4.y * tanhf(qv.y + p4.y) + w4.z * tanhf(qv.z + p4.z) + w4.w * tanhf(qv.w + p4.w);
+    }
+  } else {
+    for (int a = lane; a < A; a += 64) s += wa[a] * tanhf(qp[a] + pp[a]);
+  }
+  s = ssc_wave_sum(s);
+  if (lane == 0) logits[wid] = s;
+}
+
+// masked softmax of one row held across the wave's lanes (R strided by 64), allennlp semantics:
+// x = l*m ; p = softmax(x)*m ; alpha = p / (sum p + 1e-13)
+template <int MAXR_PER_LANE>
+__device__ __forceinline__ void wave_masked_softmax(const float* __restrict__ l, const float* __restrict__ m, int R, int lane,
+                                                    float (&alpha)[MAXR_PER_LANE]) {
+  float x[MAXR_PER_LANE], mk[MAXR_PER_LANE];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < MAXR_PER_LANE; ++i) {
+    int r = lane + 64 * i;
+    if (r < R) {
+      mk[i] = m[r];
+      x[i] = l[r] * mk[i];
+      mx = fmaxf(mx, x[i]);
+    } else {
+      mk[i] = 0.f;
+      x[i] = -INFINITY;
+    }
+  }
+  mx = ssc_wave_max(mx);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXR_PER_LANE; ++i) {
+    x[i] = (lane + 64 * i < R) ? expf(x[i] - mx) : 0.f;
+    s += x[i];
+  }
+  s = ssc_wave_sum(s);
+  float ps = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXR_PER_LANE; ++i) {
+    x[i] = x[i] / s * mk[i];
+    ps += x[i];
+  }
+  ps = ssc_wave_sum(ps);
+#pragma unroll
+  for (int i = 0; i < MAXR_PER_LANE; ++i) alpha[i] = x[i] / (ps + 1e-13f);
+}
+
+constexpr int MAXR_LANE = 4;  // R <= 256
+
+__global__ __launch_bounds__(64) void attn_apply_kernel(const float* __restrict__ logits, const float* __restrict__ mask,
+                                                        const float* __restrict__ feats, int G, int R, int F,
+                                                        int rows_per_image, float* __restrict__ alpha_out,
+                                                        float* __restrict__ att, int ldatt) {
+  __shared__ float sa[64 * MAXR_LANE];
+  int g = blockIdx.y, chunk = blockIdx.x;
+  int lane = threadIdx.x;
+  int img = g / rows_per_image;
+  float al[MAXR_LANE];
+  wave_masked_softmax<MAXR_LANE>(logits + (size_t)g * R, mask + (size_t)img * R, R, lane, al);
+#pragma unroll
+  for (int i = 0; i < MAXR_LANE; ++i) {
+    int r = lane + 64 * i;
+    if (r < R) {
+      sa[r] = al[i];
+      if (chunk == 0) alpha_out[(size_t)g * R + r] = al[i];
+    }
+  }
+  __syncthreads();
+  const float* fp = feats + (size_t)img * R * F;
+  int f = chunk * 256 + lane * 4;
+  if (((F & 3) == 0) && ssc_aligned16_dev(fp) && ((ldatt & 3) == 0) && ssc_aligned16_dev(att)) {
+    if (f < F) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int r = 0; r < R; ++r) {
+        float a = sa[r];
+        float4 v = *reinterpret_cast<const float4*>(fp + (size_t)r * F + f);
+        acc.x += a * v.x; acc.y += a * v.y; acc.z += a * v.z; acc.w += a * v.w;
+      }
+      *reinterpret_cast<float4*>(att + (size_t)g * ldatt + f) = acc;
+    }
+  } else {
+    for (int k = 0; k < 4; ++k) {
+      int ff = chunk * 256 + k * 64 + lane;
+      if (ff < F) {
+        float acc = 0.f;
+        for (int r = 0; r < R; ++r) acc += sa[r] * fp[(size_t)r * F + ff];
+        att[(size_t)g * ldatt + ff] = acc;
+      }
+    }
+  }
+}
+
+// ---- backward ---------------------------------------------------------------------------------
+// dalpha[g,r] = datt[g,:] . feats[g,r,:]
+__global__ __launch_bounds__(256) void attn_dalpha_kernel(const float* __restrict__ datt, int lddatt,
+                                                          const float* __restrict__ feats, int G, int R, int F,
+                                                          float* __restrict__ dalpha) {
+  int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+  int lane = threadIdx.x & 63;
+  if (wid >= G * R) return;
+  int g = wid / R;
+  const float* dp = datt + (size_t)g * lddatt;
+  const float* fp = feats + (size_t)wid * F;
+  float s = 0.f;
+  if (((F & 3) == 0) && ((lddatt & 3) == 0) && ssc_aligned16_dev(dp) && ssc_aligned16_dev(fp)) {
+    for (int f = lane * 4; f < F; f += 256) {
+      float4 a = *reinterpret_cast<const float4*>(dp + f);
+      float4 b = *reinterpret_cast<const float4*>(fp + f);
+      s += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+    }
+  } else {
+    for (int f = lane; f < F; f += 64) s += dp[f] * fp[f];
+  }
+  s = ssc_wave_sum(s);
+  if (lane == 0) dalpha[wid] = s;
+}
+
+// dl = alpha * (dalpha - sum alpha*dalpha)   (masked rows have alpha == 0; the 1e-13 term is inert in fp32,
+// see DESIGN.md "attention backward").  Then per (g, a): u = tanh(q+pv); dpre = dl*wa*(1-u^2).
+__global__ __launch_bounds__(64) void attn_bwd_apply_kernel(const float* __restrict__ q, int ldq,
+                                                            const float* __restrict__ pv, const float* __restrict__ wa,
+                                                            const float* __restrict__ alpha,
+                                                            const float* __restrict__ dalpha, int G, int R, int A,
+                                                            float* __restrict__ dq, int lddq, float* __restrict__ dpv_acc,
+                                                            float* __restrict__ dwa_acc) {
+  __shared__ float sdl[64 * MAXR_LANE];
+  int g = blockIdx.y, chunk = blockIdx.x, lane = threadIdx.x;
+  float c = 0.f;
+  for (int r = lane; r < R; r += 64) c += alpha[(size_t)g * R + r] * dalpha[(size_t)g * R + r];
+  c = ssc_wave_sum(c);
+  for (int r = lane; r < R; r += 64) sdl[r] = alpha[(size_t)g * R + r] * (dalpha[(size_t)g * R + r] - c);
+  __syncthreads();
+  for (int k = 0; k < 4; ++k) {
+    int a = chunk * 256 + k * 64 + lane;
+    if (a >= A) continue;
+    float qa = q[(size_t)g * ldq + a], w = wa[a];
+    float dqa = 0.f, dw = 0.f;
+    for (int r = 0; r < R; ++r) {
+      size_t off = ((size_t)g * R + r) * A + a;
+      float u = tanhf(qa + pv[off]);
+      float dl = sdl[r];
+      float dpre = dl * w * (1.f - u * u);
+      dpv_acc[off] += dpre;
+      dqa += dpre;
+      dw += dl * u;
+    }
+    dq[(size_t)g * lddq + a] = dqa;
+    dwa_acc[(size_t)g * A + a] += dw;
+  }
+}
+
+}  // namespace
+
+extern "C" int ssc_attn_logits(const float* q, int ldq, const float* pv, const float* wa, int G, int R, int A,
+                               int rows_per_image, float* logits, void* stream) {
+  if (!q || !pv || !wa || !logits || G <= 0 || R <= 0 || A <= 0 || rows_per_image <= 0 || ldq < A) return SSC_EINVAL;
+  hipLaunchKernelGGL(attn_logits_kernel, dim3(ssc_cdiv(G * R, 4)), dim3(256), 0, (hipStream_t)stream, q, ldq, pv, wa, G, R,
+                     A, rows_per_image, logits);
+  SSC_CHECK_LAUNCH();
+  return SSC_OK;
+}
+
+extern "C" int ssc_attn_fwd(const float* q, int ldq, const float* pv, const float* wa, const float* mask,
+                            const float* feats, int G, int R, int A, int F, int rows_per_image, float* logits,
+                            float* alpha, float* att, int ldatt, void* stream) {
+  if (!mask || !feats || !alpha || !att || !logits || F <= 0 || ldatt < F) return SSC_EINVAL;
+  if (R > 64 * MAXR_LANE) return SSC_EINVAL;
+  SSC_TRY(ssc_attn_logits(q, ldq, pv, wa, G, R, A, rows_per_image, logits, stream));
+  hipLaunchKernelGGL(attn_apply_kernel, dim3(ssc_cdiv(F, 256), G), dim3(64), 0, (hipStream_t)stream, logits, mask, feats,
+                     G, R, F, rows_per_image, alpha, att, ldatt);
+  SSC_CHECK_LAUNCH();
+  return SSC_OK;
+}
+
+extern "C" int ssc_attn_bwd(const float* datt, int lddatt, const float* q, int ldq, const float* pv, const float* wa,
+                            const float* alpha, const float* feats, int G, int R, int A, int F, float* dq, int lddq,
+                            float* dpv_acc, float* dwa_acc, float* scratch_dalpha, void* stream) {
+  if (!datt || !q || !pv || !wa || !alpha || !feats || !dq || !dpv_acc || !dwa_acc || !scratch_dalpha) return SSC_EINVAL;
+  if (G <= 0 || R <= 0 || A <= 0 || F <= 0 || R > 64 * MAXR_LANE || lddatt < F || ldq < A || lddq < A) return SSC_EINVAL;
+  hipLaunchKernelGGL(attn_dalpha_kernel, dim3(ssc_cdiv(G * R, 4)), dim3(256), 0, (hipStream_t)stream, datt, lddatt, feats,
+                     G, R, F, scratch_dalpha);
+  SSC_CHECK_LAUNCH();
+  hipLaunchKernelGGL(attn_bwd_apply_kernel, dim3(ssc_cdiv(A, 256), G), dim3(64), 0, (hipStream_t)stream, q, ldq, pv, wa,
+                     alpha, scratch_dalpha, G, R, A, dq, lddq, dpv_acc, dwa_acc);
+  SSC_CHECK_LAUNCH();
+  return SSC_OK;
+}

@@ -1,0 +1,368 @@
+// Eval-mode decode step and constrained-beam-search bookkeeping for gfx950.
+// Reference: UpDownCaptioner._decode_step with training=False
+// (var_updown/var_updown/models/updown_captioner.py:371-455), UpDownCell.forward eval branch
+// (var_updown/var_updown/modules/updown_cell.py:200-229), ConstrainedBeamSearch.search
+// (updown-baseline/updown/modules/cbs.py:59-277).
+//
+// Differences in mechanism, not in result: the reference re-materialises
+// feats.repeat(...) for every beam row on every step, so both of its lru-caches miss and avg / pv are
+// recomputed per step; here per-image terms are computed once (ssc_decode_prepare) and rows index
+// their image (row g -> image g / rows_per_image, batch-major).
+#include <initializer_list>
+
+#include "ssc_common.h"
+
+namespace {
+
+inline size_t r4(size_t x) { return (x + 3) & ~(size_t)3; }
+inline size_t r64(size_t x) { return (x + 63) & ~(size_t)63; }
+
+struct ImgLayout {
+  size_t mask, avg, pv, ga_avg, scratch, scratch_floats, total;
+  int Fp;
+};
+ImgLayout img_layout(const ssc_model_cfg* c, int nimg, int R) {
+  ImgLayout l;
+  l.Fp = (int)r4(c->F);
+  size_t o = 0;
+  l.mask = o; o += r64((size_t)nimg * R);
+  l.avg = o; o += r64((size_t)nimg * l.Fp);
+  l.pv = o; o += r64((size_t)nimg * R * c->A);
+  l.ga_avg = o; o += r64((size_t)nimg * 4 * c->H);
+  size_t a = (size_t)nimg * R * c->A, b = (size_t)nimg * 4 * c->H;
+  l.scratch_floats = 33 * (a > b ? a : b);
+  l.scratch = o; o += r64(l.scratch_floats);
+  l.total = o;
+  return l;
+}
+
+struct StepLayout {
+  size_t emb, q, att, z, attn_logits, proj, slabs, slab_floats, total;
+  int Ep, Ap, Fp, Zp;
+};
+StepLayout step_layout(const ssc_model_cfg* c, int G, int R) {
+  StepLayout l;
+  l.Ep = (int)r4(c->E); l.Ap = (int)r4(c->A); l.Fp = (int)r4(c->F); l.Zp = (int)r4(c->Z);
+  size_t o = 0;
+  l.emb = o; o += r64((size_t)G * l.Ep);
+  l.q = o; o += r64((size_t)G * l.Ap);
+  l.att = o; o += r64((size_t)G * l.Fp);
+  l.z = o; o += r64((size_t)G * l.Zp);
+  l.attn_logits = o; o += r64((size_t)G * R);
+  l.proj = o; o += r64(c->tied ? (size_t)G * l.Ep : 0);
+  size_t skinny = (size_t)33 * G * 4 * c->H;
+  size_t full = (size_t)1100 * 4096;
+  l.slab_floats = skinny > full ? skinny : full;
+  l.slabs = o; o += r64(l.slab_floats);
+  l.total = o;
+  return l;
+}
+
+struct Seg {
+  const float* A; int lda;
+  const float* B; int ldb;
+  int K;
+};
+
+void fill_desc(ssc_gemm_desc& d, std::initializer_list<Seg> segs, int M, int N) {
+  d = ssc_gemm_desc{};
+  int i = 0;
+  for (const Seg& s : segs) {
+    if (s.K <= 0) continue;
+    d.seg[i].A = s.A; d.seg[i].lda = s.lda; d.seg[i].B = s.B; d.seg[i].ldb = s.ldb; d.seg[i].K = s.K;
+    ++i;
+  }
+  d.nseg = i; d.M = M; d.N = N; d.a_kc = 1; d.b_kc = 1;
+}
+
+int gemm_nt(hipStream_t st, float* ws, size_t ws_floats, std::initializer_list<Seg> segs, int M, int N, float* Cc, int ldc,
+            const float* bias = nullptr) {
+  ssc_gemm_desc d;
+  fill_desc(d, segs, M, N);
+  d.C = Cc; d.ldc = ldc; d.bias = bias; d.splits = 0; d.workspace = ws; d.workspace_floats = ws_floats;
+  return ssc_gemm(&d, st);
+}
+
+int gemm_slabs(hipStream_t st, float* ws, size_t ws_floats, std::initializer_list<Seg> segs, int M, int N, int* nslab) {
+  ssc_gemm_desc d;
+  fill_desc(d, segs, M, N);
+  int ksteps = 0;
+  for (int i = 0; i < d.nseg; ++i) ksteps += ssc_cdiv(d.seg[i].K, 32);
+  int splits = ssc_gemm_auto_splits(M, N, ksteps);
+  while (splits > 1 && (size_t)splits * M * N > ws_floats) --splits;
+  int per = ssc_cdiv(ksteps, splits);
+  splits = ssc_cdiv(ksteps, per);
+  *nslab = splits;
+  return ssc_gemm_slabs(&d, splits, ws, st);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// beam-search kernels.  Selection order: value descending, index ascending ("k-pass selection":
+// pass k finds the best candidate strictly after the previous pick in that order).
+// ---------------------------------------------------------------------------------------------------
+struct Cand {
+  float v;
+  int i;
+};
+__device__ __forceinline__ bool better(float v, int i, const Cand& o) {  // (v,i) ranks before o
+  return (v > o.v) || (v == o.v && i < o.i);
+}
+__device__ __forceinline__ Cand wave_best(Cand c) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    Cand t;
+    t.v = __shfl_xor(c.v, o, 64);
+    t.i = __shfl_xor(c.i, o, 64);
+    if (t.i >= 0 && (c.i < 0 || better(t.v, t.i, c))) c = t;
+  }
+  return c;
+}
+__device__ __forceinline__ Cand block_best(Cand c, Cand* sh) {
+  int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  c = wave_best(c);
+  __syncthreads();
+  if (lane == 0) sh[wv] = c;
+  __syncthreads();
+  Cand r = sh[0];
+  for (int k = 1; k < nw; ++k)
+    if (sh[k].i >= 0 && (r.i < 0 || better(sh[k].v, sh[k].i, r))) r = sh[k];
+  return r;
+}
+
+// value of vocabulary entry v for a source row, as cbs.py builds it
+__device__ __forceinline__ float row_value(const float* __restrict__ lp, int v, bool ended, int end_index) {
+  if (ended) return v == end_index ? 0.f : -INFINITY;
+  return lp[v];
+}
+
+// first step: per (b, s): top-`beam` over v of (fsm[b,0,s,v] ? lp[b,v] : -inf)       cbs.py:127-145
+__global__ __launch_bounds__(256) void beam_first_kernel(const float* __restrict__ lp, int ldlp,
+                                                         const uint8_t* __restrict__ fsm, int S, int V, int beam,
+                                                         int64_t* __restrict__ pred, float* __restrict__ lp_out) {
+  __shared__ Cand sh[4];
+  int b = blockIdx.x / S, s = blockIdx.x % S;
+  const float* row = lp + (size_t)b * ldlp;
+  const uint8_t* m = fsm + (((size_t)b * S + 0) * S + s) * V;
+  Cand prev{INFINITY, -1};
+  for (int k = 0; k < beam; ++k) {
+    Cand best{-INFINITY, -1};
+    for (int v = threadIdx.x; v < V; v += blockDim.x) {
+      float x = m[v] ? row[v] : -INFINITY;
+      bool after_prev = (prev.i < 0) || (x < prev.v) || (x == prev.v && v > prev.i);
+      if (after_prev && (best.i < 0 || better(x, v, best))) best = Cand{x, v};
+    }
+    best = block_best(best, sh);
+    if (threadIdx.x == 0) {
+      pred[(size_t)blockIdx.x * beam + k] = best.i;
+      lp_out[(size_t)blockIdx.x * beam + k] = best.v;
+    }
+    prev = best;
+  }
+}
+
+// later steps, part A: per (source row g=(b,s,k), target state i): masked top-`per_node`     cbs.py:177-209
+__global__ __launch_bounds__(256) void beam_row_topk_kernel(const float* __restrict__ lp, int ldlp,
+                                                            const uint8_t* __restrict__ fsm,
+                                                            const int64_t* __restrict__ last_pred, int S, int V, int beam,
+                                                            int per_node, int end_index, float* __restrict__ sval,
+                                                            int64_t* __restrict__ sidx) {
+  __shared__ Cand sh[4];
+  int g = blockIdx.x, i = blockIdx.y;
+  int b = g / (S * beam), s = (g / beam) % S, k = g % beam;
+  const float* row = lp + (size_t)g * ldlp;
+  const uint8_t* m = fsm + (((size_t)b * S + s) * S + i) * V;
+  bool ended = last_pred[g] == end_index;
+  // scratch layout (b, i, s, k, n)
+  size_t base = ((((size_t)b * S + i) * S + s) * beam + k) * per_node;
+  Cand prev{INFINITY, -1};
+  for (int n = 0; n < per_node; ++n) {
+    Cand best{-INFINITY, -1};
+    for (int v = threadIdx.x; v < V; v += blockDim.x) {
+      float x = m[v] ? row_value(row, v, ended, end_index) : -1e20f;
+      bool after_prev = (prev.i < 0) || (x < prev.v) || (x == prev.v && v > prev.i);
+      if (after_prev && (best.i < 0 || better(x, v, best))) best = Cand{x, v};
+    }
+    best = block_best(best, sh);
+    if (threadIdx.x == 0) {
+      sval[base + n] = best.v;
+      sidx[base + n] = best.i;
+    }
+    prev = best;
+  }
+}
+
+// part B: per (b, target state i): top-`beam` over the S*beam*per_node summed candidates      cbs.py:210-234
+__global__ __launch_bounds__(64) void beam_merge_kernel(const float* __restrict__ sval, const int64_t* __restrict__ sidx,
+                                                        const float* __restrict__ last_lp, int S, int beam, int per_node,
+                                                        int64_t* __restrict__ pred, float* __restrict__ lp_out,
+                                                        int64_t* __restrict__ backptr) {
+  int b = blockIdx.x / S, i = blockIdx.x % S;
+  int lane = threadIdx.x;
+  int ncand = S * beam * per_node;
+  const float* sv = sval + (size_t)blockIdx.x * ncand;
+  const int64_t* si = sidx + (size_t)blockIdx.x * ncand;
+  const float* ll = last_lp + (size_t)b * S * beam;
+  Cand prev{INFINITY, -1};
+  for (int k = 0; k < beam; ++k) {
+    Cand best{-INFINITY, -1};
+    for (int cidx = lane; cidx < ncand; cidx += 64) {
+      float x = sv[cidx] + ll[cidx / per_node];
+      bool after_prev = (prev.i < 0) || (x < prev.v) || (x == prev.v && cidx > prev.i);
+      if (after_prev && (best.i < 0 || better(x, cidx, best))) best = Cand{x, cidx};
+    }
+    best = wave_best(best);
+    if (lane == 0) {
+      size_t o = (size_t)blockIdx.x * beam + k;
+      pred[o] = si[best.i];
+      lp_out[o] = best.v;
+      backptr[o] = best.i / per_node;
+    }
+    prev = best;
+  }
+}
+
+__global__ void gather_rows_kernel(const float* __restrict__ src, int ld, const int64_t* __restrict__ backptr,
+                                   int rows_per_batch, int Wd, float* __restrict__ dst) {
+  int row = blockIdx.y;
+  int b = row / rows_per_batch;
+  int x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= Wd) return;
+  size_t srow = (size_t)b * rows_per_batch + backptr[row];
+  dst[(size_t)row * ld + x] = src[srow * ld + x];
+}
+
+}  // namespace
+
+extern "C" size_t ssc_decode_image_bytes(const ssc_model_cfg* cfg, int nimg, int R) {
+  if (!cfg || nimg <= 0 || R <= 0) return 0;
+  return img_layout(cfg, nimg, R).total * sizeof(float);
+}
+
+extern "C" int ssc_decode_prepare(const ssc_model_cfg* cfg, const ssc_params* p, const float* feats, int nimg, int R,
+                                  void* imgbuf, size_t imgbuf_bytes, void* stream) {
+  if (!cfg || !p || !feats || !imgbuf || nimg <= 0 || R <= 0 || R > 256) return SSC_EINVAL;
+  ImgLayout l = img_layout(cfg, nimg, R);
+  if (imgbuf_bytes < l.total * sizeof(float)) return SSC_EWORKSPACE;
+  float* W = (float*)imgbuf;
+  hipStream_t st = (hipStream_t)stream;
+  const int F = cfg->F, A = cfg->A, E = cfg->E, H4 = 4 * cfg->H;
+  SSC_TRY(ssc_feat_prep(feats, nimg, R, F, W + l.mask, W + l.avg, st));
+  SSC_TRY(gemm_nt(st, W + l.scratch, l.scratch_floats, {{feats, F, p->wv, p->ld_wv, F}}, nimg * R, A, W + l.pv, A));
+  SSC_TRY(gemm_nt(st, W + l.scratch, l.scratch_floats, {{W + l.avg, F, p->att_w_ih + E, p->ld_att_w_ih, F}}, nimg, H4,
+                  W + l.ga_avg, H4));
+  return SSC_OK;
+}
+
+extern "C" size_t ssc_decode_step_workspace_bytes(const ssc_model_cfg* cfg, int G, int R) {
+  if (!cfg || G <= 0 || R <= 0) return 0;
+  return step_layout(cfg, G, R).total * sizeof(float);
+}
+
+extern "C" int ssc_decode_step(const ssc_model_cfg* cfg, const ssc_params* p, const ssc_decode_step_desc* d, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+  if (!cfg || !p || !d || !workspace) return SSC_EINVAL;
+  const int G = d->G, R = d->R, rpi = d->rows_per_image;
+  if (G <= 0 || R <= 0 || R > 256 || rpi <= 0 || G % rpi != 0) return SSC_EINVAL;
+  if (!d->feats || !d->imgbuf || !d->tokens || !d->eps || !d->h1 || !d->c1 || !d->hd || !d->cd || !d->h1_out ||
+      !d->c1_out || !d->hd_out || !d->cd_out || !d->alpha || !d->log_probs)
+    return SSC_EINVAL;
+  if ((cfg->S || cfg->pm_scale != 0.f) && !d->sentiment) return SSC_EINVAL;
+  const int nimg = G / rpi;
+  const ImgLayout il = img_layout(cfg, nimg, R);
+  const StepLayout l = step_layout(cfg, G, R);
+  if (workspace_bytes < l.total * sizeof(float)) return SSC_EWORKSPACE;
+  float* W = (float*)workspace;
+  const float* I = (const float*)d->imgbuf;
+  hipStream_t st = (hipStream_t)stream;
+  const int E = cfg->E, H = cfg->H, A = cfg->A, F = cfg->F, Z = cfg->Z, S = cfg->S, V = cfg->V, H4 = 4 * H;
+  float* slabs = W + l.slabs;
+  int ns = 0;
+
+  // embedding + attention LSTM (updown_captioner.py:430, updown_cell.py:143-148)
+  SSC_TRY(ssc_embed_gather(p->emb, p->ld_emb, d->tokens, G, E, W + l.emb, l.Ep, st));
+  {
+    const float* wr = p->att_w_ih + E + F;
+    SSC_TRY(gemm_slabs(st, slabs, l.slab_floats,
+                       {{W + l.emb, l.Ep, p->att_w_ih, p->ld_att_w_ih, E}, {d->h1, H, wr, p->ld_att_w_ih, H},
+                        {d->hd, H, wr + H, p->ld_att_w_ih, H}, {d->h1, H, p->att_w_hh, p->ld_att_w_hh, H}}, G, H4, &ns));
+    ssc_lstm_fwd_desc f{};
+    f.B = G; f.H = H;
+    f.slabs = slabs; f.nslab = ns; f.slab_stride = (size_t)G * H4;
+    f.add1 = I + il.ga_avg; f.ld_add1 = H4; f.rows_per_add1 = rpi;
+    f.b_ih = p->att_b_ih; f.b_hh = p->att_b_hh;
+    f.c_prev = d->c1; f.ld_cprev = H;
+    f.c_out = d->c1_out; f.ld_cout = H; f.h_out = d->h1_out; f.ld_hout = H;
+    SSC_TRY(ssc_lstm_fwd(&f, st));
+  }
+  // attention over the image's regions (attention.py:69-95, updown_cell.py:151-158)
+  SSC_TRY(gemm_nt(st, slabs, l.slab_floats, {{d->h1_out, H, p->wq, p->ld_wq, H}}, G, A, W + l.q, l.Ap));
+  SSC_TRY(ssc_attn_fwd(W + l.q, l.Ap, I + il.pv, p->wa, I + il.mask, d->feats, G, R, A, F, rpi, W + l.attn_logits, d->alpha,
+                       W + l.att, l.Fp, st));
+  // z ~ N(prior_mean, prior_var) (updown_cell.py:200-208)
+  SSC_TRY(ssc_latent_prior_sample(d->eps, Z, cfg->pm_scale != 0.f ? d->sentiment : nullptr, cfg->pm_scale, cfg->prior_var,
+                                  G, Z, W + l.z, l.Zp, st));
+  // decoder LSTM (updown_cell.py:211-229)
+  {
+    const float* wz = p->dec_w_ih + F + 2 * H + S;
+    SSC_TRY(gemm_slabs(st, slabs, l.slab_floats,
+                       {{W + l.att, l.Fp, p->dec_w_ih, p->ld_dec_w_ih, F}, {d->h1_out, H, p->dec_w_ih + F, p->ld_dec_w_ih, H},
+                        {d->hd, H, p->dec_w_ih + F + H, p->ld_dec_w_ih, H}, {W + l.z, l.Zp, wz, p->ld_dec_w_ih, Z},
+                        {d->hd, H, p->dec_w_hh, p->ld_dec_w_hh, H}}, G, H4, &ns));
+    ssc_lstm_fwd_desc f{};
+    f.B = G; f.H = H;
+    f.slabs = slabs; f.nslab = ns; f.slab_stride = (size_t)G * H4;
+    f.b_ih = p->dec_b_ih; f.b_hh = p->dec_b_hh;
+    if (S) { f.sent = d->sentiment; f.wcol = p->dec_w_ih + F + 2 * H; f.ldwcol = p->ld_dec_w_ih; }
+    f.c_prev = d->cd; f.ld_cprev = H;
+    f.c_out = d->cd_out; f.ld_cout = H; f.h_out = d->hd_out; f.ld_hout = H;
+    SSC_TRY(ssc_lstm_fwd(&f, st));
+  }
+  // vocabulary log-probabilities (updown_captioner.py:444-450)
+  if (cfg->tied) {
+    SSC_TRY(gemm_nt(st, slabs, l.slab_floats, {{d->hd_out, H, p->proj_w, p->ld_proj_w, H}}, G, E, W + l.proj, l.Ep));
+    SSC_TRY(ssc_bias_tanh(W + l.proj, l.Ep, G, E, p->proj_b, st));
+    SSC_TRY(gemm_nt(st, slabs, l.slab_floats, {{W + l.proj, l.Ep, p->emb, p->ld_emb, E}}, G, V, d->log_probs, V));
+  } else {
+    SSC_TRY(gemm_nt(st, slabs, l.slab_floats, {{d->hd_out, H, p->out_w, p->ld_out_w, H}}, G, V, d->log_probs, V, p->out_b));
+  }
+  SSC_TRY(ssc_log_softmax(d->log_probs, V, G, V, d->log_probs, V, st));
+  return SSC_OK;
+}
+
+extern "C" int ssc_beam_first(const float* log_probs, int ldlp, const uint8_t* fsm, int B, int S, int V, int beam,
+                              int64_t* pred, float* lp_out, void* stream) {
+  if (!log_probs || !fsm || !pred || !lp_out || B <= 0 || S <= 0 || V <= 0 || beam <= 0 || beam > V || ldlp < V)
+    return SSC_EINVAL;
+  hipLaunchKernelGGL(beam_first_kernel, dim3(B * S), dim3(256), 0, (hipStream_t)stream, log_probs, ldlp, fsm, S, V, beam,
+                     pred, lp_out);
+  SSC_CHECK_LAUNCH();
+  return SSC_OK;
+}
+
+extern "C" int ssc_beam_step(const float* log_probs, int ldlp, const uint8_t* fsm, const int64_t* last_pred,
+                             const float* last_lp, int B, int S, int V, int beam, int per_node, int end_index,
+                             int64_t* pred, float* lp_out, int64_t* backptr, float* scratch_val, int64_t* scratch_idx,
+                             void* stream) {
+  if (!log_probs || !fsm || !last_pred || !last_lp || !pred || !lp_out || !backptr || !scratch_val || !scratch_idx)
+    return SSC_EINVAL;
+  if (B <= 0 || S <= 0 || V <= 0 || beam <= 0 || per_node <= 0 || per_node > V || ldlp < V || end_index < 0 ||
+      end_index >= V || beam > S * beam * per_node)
+    return SSC_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(beam_row_topk_kernel, dim3(B * S * beam, S), dim3(256), 0, st, log_probs, ldlp, fsm, last_pred, S, V,
+                     beam, per_node, end_index, scratch_val, scratch_idx);
+  SSC_CHECK_LAUNCH();
+  hipLaunchKernelGGL(beam_merge_kernel, dim3(B * S), dim3(64), 0, st, scratch_val, scratch_idx, last_lp, S, beam, per_node,
+                     pred, lp_out, backptr);
+  SSC_CHECK_LAUNCH();
+  return SSC_OK;
+}
+
+extern "C" int ssc_gather_rows(const float* src, int ld, const int64_t* backptr, int B, int rows_per_batch, int Wd,
+                               float* dst, void* stream) {
+  if (!src || !backptr || !dst || B <= 0 || rows_per_batch <= 0 || Wd <= 0 || ld < Wd || src == dst) return SSC_EINVAL;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(ssc_cdiv(Wd, 256), B * rows_per_batch), dim3(256), 0, (hipStream_t)stream, src,
+                     ld, backptr, rows_per_batch, Wd, dst);
+  SSC_CHECK_LAUNCH();
+  return SSC_OK;
+}

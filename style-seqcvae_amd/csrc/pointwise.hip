@@ -1,0 +1,541 @@
+// Elementwise / small-reduction kernels of the var_updown hot path (gfx950, wave64).
+// All of them are HBM-bound byte movers; they are written for coalesced access along the contiguous
+// axis and 64-lane shuffle reductions.  Reference citations are on the C entry points in ssc.h.
+#include "ssc_common.h"
+
+thread_local int ssc_tls_hip_error = 0;
+
+extern "C" int ssc_version(void) { return 1; }
+extern "C" int ssc_last_hip_error(void) { return ssc_tls_hip_error; }
+extern "C" const char* ssc_arch(void) { return "gfx950"; }
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// feat_prep: mask[b,r] = (sum_f |v| > 0) ; avg[b,f] = sum_r mask*v / max(sum_r mask, 1e-8)
+// ---------------------------------------------------------------------------------------------
+__global__ void feat_mask_kernel(const float* __restrict__ feats, int BR, int F, float* __restrict__ mask) {
+  int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  int lane = threadIdx.x & 63;
+  if (row >= BR) return;
+  const float* p = feats + (size_t)row * F;
+  float s = 0.f;
+  for (int f = lane; f < F; f += 64) s += fabsf(p[f]);
+  s = ssc_wave_sum(s);
+  if (lane == 0) mask[row] = s > 0.f ? 1.f : 0.f;
+}
+
+__global__ void feat_avg_kernel(const float* __restrict__ feats, const float* __restrict__ mask, int R, int F,
+                                float* __restrict__ avg) {
+  int b = blockIdx.y;
+  int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= F) return;
+  const float* p = feats + (size_t)b * R * F + f;
+  const float* m = mask + (size_t)b * R;
+  float s = 0.f, n = 0.f;
+  for (int r = 0; r < R; ++r) {
+    float mr = m[r];
+    s += mr * p[(size_t)r * F];
+    n += mr;
+  }
+  avg[(size_t)b * F + f] = s / fmaxf(n, 1e-8f);
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void prep_tokens_kernel(const int64_t* __restrict__ caps, int B, int L, int pad, int boundary,
+                                   int64_t* __restrict__ tok, float* __restrict__ w, float* __restrict__ nvalid) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  int n = 0;
+  for (int j = 0; j < L; ++j) n += caps[(size_t)b * L + j] != pad;
+  tok[b] = boundary;
+  for (int j = 0; j < L; ++j) tok[(size_t)(1 + j) * B + b] = caps[(size_t)b * L + j];
+  tok[(size_t)(L + 1) * B + b] = 0;
+  tok[(size_t)(n + 1) * B + b] = boundary;
+  float nv = 0.f;
+  for (int t = 0; t <= L; ++t) {
+    float wt = tok[(size_t)(t + 1) * B + b] != pad ? 1.f : 0.f;
+    w[(size_t)t * B + b] = wt;
+    nv += wt;
+  }
+  nvalid[b] = nv;
+}
+
+__global__ void embed_gather_kernel(const float* __restrict__ table, int ldt, const int64_t* __restrict__ ids, int n, int E,
+                                    float* __restrict__ out, int ldo) {
+  int i = blockIdx.y;
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  out[(size_t)i * ldo + e] = table[(size_t)ids[i] * ldt + e];
+}
+
+__global__ void embed_scatter_kernel(float* __restrict__ dt, int ldt, const int64_t* __restrict__ ids, int n, int E,
+                                     const float* __restrict__ d, int ldd, int pad) {
+  int i = blockIdx.y;
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  int64_t id = ids[i];
+  if (id == pad) return;
+  atomicAdd(&dt[(size_t)id * ldt + e], d[(size_t)i * ldd + e]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// LSTM pointwise forward / backward
+// ---------------------------------------------------------------------------------------------
+__global__ void lstm_fwd_kernel(const ssc_lstm_fwd_desc d) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  int b = blockIdx.y;
+  if (j >= d.H) return;
+  const int H = d.H, H4 = 4 * d.H;
+  float pre[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    int n = g * H + j;
+    float v = 0.f;
+    for (int s = 0; s < d.nslab; ++s) v += d.slabs[(size_t)s * d.slab_stride + (size_t)b * H4 + n];
+    if (d.add0) v += d.add0[(size_t)b * d.ld_add0 + n];
+    if (d.add1) v += d.add1[(size_t)(b / d.rows_per_add1) * d.ld_add1 + n];
+    if (d.b_ih) v += d.b_ih[n];
+    if (d.b_hh) v += d.b_hh[n];
+    if (d.sent) v += d.sent[b] * d.wcol[(size_t)n * d.ldwcol];
+    pre[g] = v;
+  }
+  float ig = ssc_sigmoid(pre[0]), fg = ssc_sigmoid(pre[1]), gg = tanhf(pre[2]), og = ssc_sigmoid(pre[3]);
+  float cp = d.c_prev ? d.c_prev[(size_t)b * d.ld_cprev + j] : 0.f;
+  float c = fg * cp + ig * gg;
+  float h = og * tanhf(c);
+  if (d.gates_out) {
+    float* go = d.gates_out + (size_t)b * H4 + j;
+    go[0] = ig; go[H] = fg; go[2 * H] = gg; go[3 * H] = og;
+  }
+  d.c_out[(size_t)b * d.ld_cout + j] = c;
+  d.h_out[(size_t)b * d.ld_hout + j] = h;
+}
+
+__global__ void lstm_bwd_kernel(const ssc_lstm_bwd_desc d) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  int b = blockIdx.y;
+  if (j >= d.H) return;
+  const int H = d.H, H4 = 4 * d.H;
+  float dh = d.dh ? d.dh[(size_t)b * d.ld_dh + j] : 0.f;
+  if (d.dh2) dh += d.dh2[(size_t)b * d.ld_dh2 + j];
+  float dcin = d.dc_in ? d.dc_in[(size_t)b * d.ld_dcin + j] : 0.f;
+  const float* g = d.gates + (size_t)b * H4 + j;
+  float ig = g[0], fg = g[H], gg = g[2 * H], og = g[3 * H];
+  float cp = d.c_prev[(size_t)b * d.ld_cprev + j];
+  float tc = tanhf(d.c_new[(size_t)b * d.ld_cnew + j]);
+  float d_o = dh * tc;
+  float dc = dcin + dh * og * (1.f - tc * tc);
+  float dgi = dc * gg * ig * (1.f - ig);
+  float dgf = dc * cp * fg * (1.f - fg);
+  float dgg = dc * ig * (1.f - gg * gg);
+  float dgo = d_o * og * (1.f - og);
+  float* o = d.dG + (size_t)b * H4 + j;
+  o[0] = dgi; o[H] = dgf; o[2 * H] = dgg; o[3 * H] = dgo;
+  d.dc_prev[(size_t)b * d.ld_dcprev + j] = dc * fg;
+  if (d.dgsum) {
+    float* s = d.dgsum + (size_t)b * H4 + j;
+    s[0] += dgi; s[H] += dgf; s[2 * H] += dgg; s[3 * H] += dgo;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// latent head
+// ---------------------------------------------------------------------------------------------
+__global__ void latent_fwd_kernel(const ssc_latent_fwd_desc d) {
+  int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  int lane = threadIdx.x & 63;
+  if (b >= d.B) return;
+  const int Z = d.Z;
+  float pm = d.sent ? d.pm_scale * d.sent[b] : 0.f;
+  float pvar = d.prior_var;
+  float lpv = logf(pvar);
+  float acc = 0.f;
+  for (int z = lane; z < Z; z += 64) {
+    float m = 0.f, l = 0.f;
+    for (int s = 0; s < d.nslab; ++s) {
+      const float* row = d.mulv + (size_t)s * d.slab_stride + (size_t)b * d.ldmulv;
+      m += row[z];
+      l += row[Z + z];
+    }
+    m += d.bmu[z];
+    l += d.blv[z];
+    float var = expf(l);
+    float zz = d.eps[(size_t)b * d.ldeps + z] * sqrtf(var) + m;
+    d.mu[(size_t)b * d.ldz + z] = m;
+    d.lv[(size_t)b * d.ldz + z] = l;
+    d.z[(size_t)b * d.ldz + z] = zz;
+    if (d.kld_mode == 0) {
+      acc += 1.f + l - m * m - var;
+    } else {
+      float dm = m - pm;
+      acc += 1.f + l - lpv - (dm * dm + var) / (pvar + 0.00001f);
+    }
+  }
+  acc = ssc_wave_sum(acc);
+  if (lane == 0) d.kld_acc[b] += d.w[b] * (-0.5f * acc);
+}
+
+__global__ void latent_prior_sample_kernel(const float* __restrict__ eps, int ldeps, const float* __restrict__ sent,
+                                           float pm_scale, float sd, int G, int Z, float* __restrict__ z, int ldz) {
+  int g = blockIdx.y;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Z) return;
+  float pm = sent ? pm_scale * sent[g] : 0.f;
+  z[(size_t)g * ldz + i] = eps[(size_t)g * ldeps + i] * sd + pm;
+}
+
+__global__ void latent_bwd_kernel(const ssc_latent_bwd_desc d) {
+  int b = blockIdx.y;
+  int z = blockIdx.x * blockDim.x + threadIdx.x;
+  if (z >= d.Z) return;
+  float k = d.gk[b] * d.w[b];
+  float m = d.mu[(size_t)b * d.ldz + z], l = d.lv[(size_t)b * d.ldz + z];
+  float dz = d.dz[(size_t)b * d.lddz + z];
+  float e = d.eps[(size_t)b * d.ldeps + z];
+  float var = expf(l);
+  float dmu, dlv;
+  if (d.kld_mode == 0) {
+    dmu = dz + k * m;
+    dlv = dz * e * 0.5f * sqrtf(var) - 0.5f * k * (1.f - var);
+  } else {
+    float pm = d.sent ? d.pm_scale * d.sent[b] : 0.f;
+    float den = d.prior_var + 0.00001f;
+    dmu = dz + k * (m - pm) / den;
+    dlv = dz * e * 0.5f * sqrtf(var) - 0.5f * k * (1.f - var / den);
+  }
+  d.dmulv[(size_t)b * d.lddmulv + z] = dmu;
+  d.dmulv[(size_t)b * d.lddmulv + d.Z + z] = dlv;
+}
+
+// ---------------------------------------------------------------------------------------------
+// cross entropy over the vocabulary
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_reduce(float v, float* sh, bool is_max) {
+  int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  v = is_max ? ssc_wave_max(v) : ssc_wave_sum(v);
+  __syncthreads();
+  if (lane == 0) sh[wv] = v;
+  __syncthreads();
+  float r = sh[0];
+  for (int i = 1; i < nw; ++i) r = is_max ? fmaxf(r, sh[i]) : r + sh[i];
+  return r;
+}
+
+__global__ void ce_fwd_kernel(const float* __restrict__ logits, int ldl, const int64_t* __restrict__ targets,
+                              const float* __restrict__ w, int V, float* __restrict__ lse, float* __restrict__ nllw) {
+  __shared__ float sh[16];
+  int row = blockIdx.x;
+  const float* p = logits + (size_t)row * ldl;
+  float mx = -INFINITY;
+  for (int v = threadIdx.x; v < V; v += blockDim.x) mx = fmaxf(mx, p[v]);
+  mx = block_reduce(mx, sh, true);
+  float s = 0.f;
+  for (int v = threadIdx.x; v < V; v += blockDim.x) s += expf(p[v] - mx);
+  s = block_reduce(s, sh, false);
+  if (threadIdx.x == 0) {
+    float l = mx + logf(s);
+    lse[row] = l;
+    nllw[row] = w[row] * (l - p[targets[row]]);
+  }
+}
+
+__global__ void ce_loss_kernel(const float* __restrict__ nllw, const float* __restrict__ nvalid, int T, int B,
+                               float* __restrict__ loss) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float s = 0.f;
+  for (int t = 0; t < T; ++t) s += nllw[(size_t)t * B + b];
+  float n = nvalid[b];
+  loss[b] = n * (s / (n + 1e-13f));
+}
+
+__global__ void ce_bwd_kernel(float* __restrict__ logits, int ldl, const int64_t* __restrict__ targets,
+                              const float* __restrict__ w, const float* __restrict__ nvalid, const float* __restrict__ lse,
+                              const float* __restrict__ gl, int B, int V) {
+  int row = blockIdx.x;
+  int b = row % B;
+  float n = nvalid[b];
+  float coef = gl[b] * w[row] * (n / (n + 1e-13f));
+  float* p = logits + (size_t)row * ldl;
+  float l = lse[row];
+  int tgt = (int)targets[row];
+  if (coef == 0.f) {
+    for (int v = threadIdx.x; v < V; v += blockDim.x) p[v] = 0.f;
+    return;
+  }
+  for (int v = threadIdx.x; v < V; v += blockDim.x) {
+    float sm = expf(p[v] - l);
+    p[v] = (sm - (v == tgt ? 1.f : 0.f)) * coef;
+  }
+}
+
+__global__ void log_softmax_kernel(const float* __restrict__ logits, int ldl, int V, float* __restrict__ out, int ldo) {
+  __shared__ float sh[16];
+  int row = blockIdx.x;
+  const float* p = logits + (size_t)row * ldl;
+  float* o = out + (size_t)row * ldo;
+  float mx = -INFINITY;
+  for (int v = threadIdx.x; v < V; v += blockDim.x) mx = fmaxf(mx, p[v]);
+  mx = block_reduce(mx, sh, true);
+  float s = 0.f;
+  for (int v = threadIdx.x; v < V; v += blockDim.x) s += expf(p[v] - mx);
+  s = block_reduce(s, sh, false);
+  float l = mx + logf(s);
+  for (int v = threadIdx.x; v < V; v += blockDim.x) o[v] = p[v] - l;
+}
+
+// ---------------------------------------------------------------------------------------------
+// column sums, tanh, fill
+// ---------------------------------------------------------------------------------------------
+__global__ void colsum_kernel(const float* __restrict__ X, int ldx, int rows, int N, const float* __restrict__ wrow,
+                              float* __restrict__ out, int out_stride, int accumulate) {
+  __shared__ float sh[8][33];
+  int tx = threadIdx.x, ty = threadIdx.y;
+  int n = blockIdx.x * 32 + tx;
+  float s = 0.f;
+  if (n < N) {
+    for (int r = ty; r < rows; r += 8) {
+      float x = X[(size_t)r * ldx + n];
+      s += wrow ? wrow[r] * x : x;
+    }
+  }
+  sh[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && n < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t += sh[i][tx];
+    float* o = out + (size_t)n * out_stride;
+    *o = accumulate ? *o + t : t;
+  }
+}
+
+__global__ void bias_tanh_kernel(float* __restrict__ x, int ldx, int N, const float* __restrict__ bias) {
+  int r = blockIdx.y;
+  int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float* p = x + (size_t)r * ldx + n;
+  *p = tanhf(*p + (bias ? bias[n] : 0.f));
+}
+
+__global__ void tanh_bwd_kernel(float* __restrict__ dy, int lddy, const float* __restrict__ y, int ldy, int N) {
+  int r = blockIdx.y;
+  int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float yy = y[(size_t)r * ldy + n];
+  dy[(size_t)r * lddy + n] *= (1.f - yy * yy);
+}
+
+__global__ void fill_kernel(float* __restrict__ p, size_t n, float v) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) p[i] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// clip + SGD on flat buffers
+// ---------------------------------------------------------------------------------------------
+__global__ void sq_norm_partial_kernel(const float* __restrict__ g, size_t n, float* __restrict__ scratch) {
+  __shared__ float sh[16];
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t stride = (size_t)gridDim.x * blockDim.x;
+  float s = 0.f;
+  for (; i < n; i += stride) {
+    float v = g[i];
+    s += v * v;
+  }
+  s = block_reduce(s, sh, false);
+  if (threadIdx.x == 0) scratch[blockIdx.x] = s;
+}
+
+__global__ void sq_norm_final_kernel(const float* __restrict__ scratch, int nb, float* __restrict__ out) {
+  __shared__ float sh[16];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nb; i += blockDim.x) s += scratch[i];
+  s = block_reduce(s, sh, false);
+  if (threadIdx.x == 0) *out = s;
+}
+
+__global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, size_t n,
+                           const float* __restrict__ sqnorm, float gscale, float max_norm, float lr, float momentum,
+                           float wd, int first) {
+  float norm = sqrtf(*sqnorm) * gscale;
+  float coef = fminf(1.f, max_norm / (norm + 1e-6f)) * gscale;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    float pv = p[i];
+    float dd = g[i] * coef + wd * pv;
+    float b = first ? dd : momentum * buf[i] + dd;
+    buf[i] = b;
+    p[i] = pv - lr * b;
+  }
+}
+
+inline hipStream_t S(void* s) { return (hipStream_t)s; }
+
+}  // namespace
+
+// =============================================================================================
+extern "C" int ssc_feat_prep(const float* feats, int B, int R, int F, float* mask, float* avg, void* stream) {
+  if (!feats || !mask || !avg || B <= 0 || R <= 0 || F <= 0) return SSC_EINVAL;
+  int BR = B * R;
+  hipLaunchKernelGGL(feat_mask_kernel, dim3(ssc_cdiv(BR, 4)), dim3(256), 0, S(stream), feats, BR, F, mask);
+  SSC_CHECK_LAUNCH();
+  hipLaunchKernelGGL(feat_avg_kernel, dim3(ssc_cdiv(F, 256), B), dim3(256), 0, S(stream), feats, mask, R, F, avg);
+  SSC_CHECK_LAUNCH();
+  return SSC_OK;
+}
+
+extern "C" int ssc_prep_tokens(const int64_t* caps, int B, int L, int pad, int boundary, int64_t* tokens_tm, float* w_tm,
+                               float* nvalid, void* stream) {
+  if (!caps || !tokens_tm || !w_tm || !nvalid || B <= 0 || L <= 0) return SSC_EINVAL;
+  hipLaunchKernelGGL(prep_tokens_kernel, dim3(ssc_cdiv(B, 64)), dim3(64), 0, S(stream), caps, B, L, pad, boundary,
+                     tokens_tm, w_tm, nvalid);
+  SSC_CHECK_LAUNCH();
+  return SSC_OK;
+}
+
+extern "C" int ssc_embed_gather(const float* table, int ldt, const int64_t* ids, int n, int E, float* out, int ldo,
+                                void* stream) {
+  if (!table || !ids || !out || n <= 0 || E <= 0 || ldt < E || ldo < E) return SSC_EINVAL;
+  hipLaunchKernelGGL(embed_gather_kernel, dim3(ssc_cdiv(E, 256), n), dim3(256), 0, S(stream), table, ldt, ids, n, E, out,
+                     ldo);
+  SSC_CHECK_LAUNCH();
+  return SSC_OK;
+}
+
+extern "C" int ssc_embed_scatter_add(float* dtable, int ldt, const int64_t* ids, int n, int E, const float* d, int ldd,
+                                     int pad, void* stream) {
+  if (!dtable || !ids || !d || n <= 0 || E <= 0 || ldt < E || ldd < E) return SSC_EINVAL;
+  hipLaunchKernelGGL(embed_scatter_kernel, dim3(ssc_cdiv(E, 256), n), dim3(256), 0, S(stream), dtable, ldt, ids, n, E, d,
+                     ldd, pad);
+  SSC_CHECK_LAUNCH();
+  return SSC_OK;
+}
+
+extern "C" int ssc_lstm_fwd(const ssc_lstm_fwd_desc* d, void* stream) {
+  if (!d || d->B <= 0 || d->H <= 0 || !d->c_out || !d->h_out) return SSC_EINVAL;
+  if (d->nslab > 0 && !d->slabs) return SSC_EINVAL;
+  if (d->sent && !d->wcol) return SSC_EINVAL;
+  if (d->add1 && d->rows_per_add1 <= 0) return SSC_EINVAL;
+  hipLaunchKernelGGL(lstm_fwd_kernel, dim3(ssc_cdiv(d->H, 128), d->B), dim3(128), 0, S(stream), *d);
+  SSC_CHECK_LAUNCH();
+  return SSC_OK;
+}
+
+extern "C" int ssc_lstm_bwd(const ssc_lstm_bwd_desc* d, void* stream) {
+  if (!d || d->B <= 0 || d->H <= 0 || !d->gates || !d->c_prev || !d->c_new || !d->dG || !d->dc_prev) return SSC_EINVAL;
+  hipLaunchKernelGGL(lstm_bwd_kernel, dim3(ssc_cdiv(d->H, 128), d->B), dim3(128), 0, S(stream), *d);
+  SSC_CHECK_LAUNCH();
+  return SSC_OK;
+}
+
+extern "C" int ssc_latent_fwd(const ssc_latent_fwd_desc* d, void* stream) {
+  if (!d || d->B <= 0 || d->Z <= 0 || !d->mulv || d->nslab < 1 || !d->bmu || !d->blv || !d->eps || !d->w || !d->mu ||
+      !d->lv || !d->z || !d->kld_acc)
+    return SSC_EINVAL;
+  hipLaunchKernelGGL(latent_fwd_kernel, dim3(ssc_cdiv(d->B, 4)), dim3(256), 0, S(stream), *d);
+  SSC_CHECK_LAUNCH();
+  return SSC_OK;
+}
+
+extern "C" int ssc_latent_prior_sample(const float* eps, int ldeps, const float* sent, float pm_scale, float prior_var,
+                                       int G, int Z, float* z, int ldz, void* stream) {
+  if (!eps || !z || G <= 0 || Z <= 0) return SSC_EINVAL;
+  hipLaunchKernelGGL(latent_prior_sample_kernel, dim3(ssc_cdiv(Z, 64), G), dim3(64), 0, S(stream), eps, ldeps, sent,
+                     pm_scale, sqrtf(prior_var), G, Z, z, ldz);
+  SSC_CHECK_LAUNCH();
+  return SSC_OK;
+}
+
+extern "C" int ssc_latent_bwd(const ssc_latent_bwd_desc* d, void* stream) {
+  if (!d || d->B <= 0 || d->Z <= 0 || !d->dz || !d->eps || !d->mu || !d->lv || !d->w || !d->gk || !d->dmulv)
+    return SSC_EINVAL;
+  hipLaunchKernelGGL(latent_bwd_kernel, dim3(ssc_cdiv(d->Z, 64), d->B), dim3(64), 0, S(stream), *d);
+  SSC_CHECK_LAUNCH();
+  return SSC_OK;
+}
+
+// lse must hold 2*T*B floats: [lse | w*nll]
+extern "C" int ssc_ce_fwd(const float* logits, int ldl, const int64_t* targets, const float* w, const float* nvalid, int T,
+                          int B, int V, float* lse, float* loss, void* stream) {
+  if (!logits || !targets || !w || !nvalid || !lse || !loss || T <= 0 || B <= 0 || V <= 0 || ldl < V) return SSC_EINVAL;
+  int rows = T * B;
+  hipLaunchKernelGGL(ce_fwd_kernel, dim3(rows), dim3(256), 0, S(stream), logits, ldl, targets, w, V, lse, lse + rows);
+  SSC_CHECK_LAUNCH();
+  hipLaunchKernelGGL(ce_loss_kernel, dim3(ssc_cdiv(B, 64)), dim3(64), 0, S(stream), lse + rows, nvalid, T, B, loss);
+  SSC_CHECK_LAUNCH();
+  return SSC_OK;
+}
+
+extern "C" int ssc_ce_bwd(float* logits, int ldl, const int64_t* targets, const float* w, const float* nvalid,
+                          const float* lse, const float* gl, int T, int B, int V, void* stream) {
+  if (!logits || !targets || !w || !nvalid || !lse || !gl || T <= 0 || B <= 0 || V <= 0 || ldl < V) return SSC_EINVAL;
+  hipLaunchKernelGGL(ce_bwd_kernel, dim3(T * B), dim3(256), 0, S(stream), logits, ldl, targets, w, nvalid, lse, gl, B, V);
+  SSC_CHECK_LAUNCH();
+  return SSC_OK;
+}
+
+extern "C" int ssc_log_softmax(const float* logits, int ldl, int rows, int V, float* out, int ldo, void* stream) {
+  if (!logits || !out || rows <= 0 || V <= 0 || ldl < V || ldo < V) return SSC_EINVAL;
+  hipLaunchKernelGGL(log_softmax_kernel, dim3(rows), dim3(256), 0, S(stream), logits, ldl, V, out, ldo);
+  SSC_CHECK_LAUNCH();
+  return SSC_OK;
+}
+
+extern "C" int ssc_colsum(const float* X, int ldx, int rows, int N, const float* wrow, float* out, int out_stride,
+                          int accumulate, void* stream) {
+  if (!X || !out || rows <= 0 || N <= 0 || ldx < N || out_stride < 1) return SSC_EINVAL;
+  hipLaunchKernelGGL(colsum_kernel, dim3(ssc_cdiv(N, 32)), dim3(32, 8), 0, S(stream), X, ldx, rows, N, wrow, out,
+                     out_stride, accumulate);
+  SSC_CHECK_LAUNCH();
+  return SSC_OK;
+}
+
+extern "C" int ssc_bias_tanh(float* x, int ldx, int rows, int N, const float* bias, void* stream) {
+  if (!x || rows <= 0 || N <= 0 || ldx < N) return SSC_EINVAL;
+  hipLaunchKernelGGL(bias_tanh_kernel, dim3(ssc_cdiv(N, 256), rows), dim3(256), 0, S(stream), x, ldx, N, bias);
+  SSC_CHECK_LAUNCH();
+  return SSC_OK;
+}
+
+extern "C" int ssc_tanh_bwd(float* dy, int lddy, const float* y, int ldy, int rows, int N, void* stream) {
+  if (!dy || !y || rows <= 0 || N <= 0) return SSC_EINVAL;
+  hipLaunchKernelGGL(tanh_bwd_kernel, dim3(ssc_cdiv(N, 256), rows), dim3(256), 0, S(stream), dy, lddy, y, ldy, N);
+  SSC_CHECK_LAUNCH();
+  return SSC_OK;
+}
+
+extern "C" int ssc_fill(float* p, size_t n, float v, void* stream) {
+  if (!p) return SSC_EINVAL;
+  if (n == 0) return SSC_OK;
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(fill_kernel, dim3((unsigned)blocks), dim3(256), 0, S(stream), p, n, v);
+  SSC_CHECK_LAUNCH();
+  return SSC_OK;
+}
+
+extern "C" int ssc_sq_norm(const float* g, size_t n, float* scratch, float* out, void* stream) {
+  if (!g || !scratch || !out) return SSC_EINVAL;
+  const int nb = 1024;
+  hipLaunchKernelGGL(sq_norm_partial_kernel, dim3(nb), dim3(256), 0, S(stream), g, n, scratch);
+  SSC_CHECK_LAUNCH();
+  hipLaunchKernelGGL(sq_norm_final_kernel, dim3(1), dim3(256), 0, S(stream), scratch, nb, out);
+  SSC_CHECK_LAUNCH();
+  return SSC_OK;
+}
+
+extern "C" int ssc_sgd_step(float* p, const float* g, float* buf, size_t n, const float* sqnorm, float gscale,
+                            float max_norm, float lr, float momentum, float weight_decay, int first, void* stream) {
+  if (!p || !g || !buf || !sqnorm) return SSC_EINVAL;
+  if (n == 0) return SSC_OK;
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)blocks), dim3(256), 0, S(stream), p, g, buf, n, sqnorm, gscale, max_norm,
+                     lr, momentum, weight_decay, first);
+  SSC_CHECK_LAUNCH();
+  return SSC_OK;
+}

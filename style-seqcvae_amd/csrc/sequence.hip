@@ -1,0 +1,514 @@
+// Sequence-level runner: the T-step teacher-forced training forward of the Style-SeqCVAE captioner and
+// its hand-derived BPTT, launched from C++ on one HIP stream (graph-capturable, no host sync, no
+// allocation).  Reference: UpDownCaptioner.forward training branch
+// (var_updown/var_updown/models/updown_captioner.py:228-323), _decode_step (:371-455),
+// UpDownCell.forward (var_updown/var_updown/modules/updown_cell.py:86-231),
+// BottomUpTopDownAttention (updown-baseline/updown/modules/attention.py:36-125); the backward is
+// what autograd derives for them.
+//
+// Output-preserving restructurings:
+//  * time-invariant gate terms hoisted: emb_t W_ih^att[:, :E] for all t as one (T*B) x E GEMM, avg W_ih^att[:, E:E+F]
+//    once; pv = Wv v once;
+//  * torch.cat inputs never built: each K-segment of a gate GEMM reads its own source buffer;
+//  * vocabulary projection + CE over all T steps at once (M = T*B);
+//  * every weight gradient is one GEMM with K = T*B after the time loop.
+#include <initializer_list>
+
+#include "ssc_common.h"
+
+namespace {
+
+inline size_t r4(size_t x) { return (x + 3) & ~(size_t)3; }
+
+struct Layout {
+  int B, R, L, T;
+  int V, E, H, A, F, Z, S, tied;
+  int Ep, Hp, Ap, Fp, Zp, Vp, H4, XW;  // padded leading dims ; XW = F + 2H
+  size_t total = 0;                    // floats
+  size_t tok, w, nvalid, sent_all, mask, avg, pv, emb, ga_static, ga_avg;
+  size_t h1, c1, he, ce, hd, cd, gates_a, gates_e, gates_d, q, attn_logits, alpha, att, mu, lv, z, mulv;
+  size_t slabs, slab_floats, logits, lse, proj;
+  // backward
+  size_t dhdv, dga, dge, dgd, dga_sum, g_h1, g_c1, g_he, g_ce, g_cd, dz, dmulv, dx, dalpha, dq, dpv, dwa, demb, dproj;
+
+  size_t take(size_t n) {
+    size_t o = total;
+    total += (n + 63) & ~(size_t)63;
+    return o;
+  }
+};
+
+Layout make_layout(const ssc_model_cfg* c, int B, int R, int L) {
+  Layout l;
+  l.B = B; l.R = R; l.L = L; l.T = L + 1;
+  l.V = c->V; l.E = c->E; l.H = c->H; l.A = c->A; l.F = c->F; l.Z = c->Z; l.S = c->S; l.tied = c->tied;
+  l.Ep = (int)r4(l.E); l.Hp = (int)r4(l.H); l.Ap = (int)r4(l.A); l.Fp = (int)r4(l.F); l.Zp = (int)r4(l.Z);
+  l.Vp = (int)r4(l.V); l.H4 = 4 * l.H; l.XW = (int)r4(l.F + 2 * l.H);
+  const size_t T = l.T, TB = T * B, T1B = (T + 1) * (size_t)B;
+  l.tok = l.take(2 * (size_t)(L + 2) * B);
+  l.w = l.take(TB);
+  l.nvalid = l.take(B);
+  l.sent_all = l.take(TB);
+  l.mask = l.take((size_t)B * R);
+  l.avg = l.take((size_t)B * l.Fp);
+  l.pv = l.take((size_t)B * R * l.A);
+  l.emb = l.take(TB * l.Ep);
+  l.ga_static = l.take(TB * l.H4);
+  l.ga_avg = l.take((size_t)B * l.H4);
+  l.h1 = l.take(T1B * l.Hp); l.c1 = l.take(T1B * l.Hp);
+  l.he = l.take(T1B * l.Hp); l.ce = l.take(T1B * l.Hp);
+  l.hd = l.take(T1B * l.Hp); l.cd = l.take(T1B * l.Hp);
+  l.gates_a = l.take(TB * l.H4); l.gates_e = l.take(TB * l.H4); l.gates_d = l.take(TB * l.H4);
+  l.q = l.take(TB * l.Ap);
+  l.attn_logits = l.take((size_t)B * R);
+  l.alpha = l.take(TB * R);
+  l.att = l.take(TB * l.Fp);
+  l.mu = l.take(TB * l.Zp); l.lv = l.take(TB * l.Zp); l.z = l.take(TB * l.Zp);
+  l.mulv = l.take((size_t)B * 2 * l.Z);
+  // slab workspace: skinny GEMMs use up to 32 splits of (B x 4H); full GEMMs never exceed ~1024 tiles * 4096
+  size_t skinny = (size_t)33 * B * l.H4;
+  size_t full = (size_t)1100 * 4096;
+  l.slab_floats = skinny > full ? skinny : full;
+  l.slabs = l.take(l.slab_floats);
+  l.logits = l.take(TB * l.Vp);
+  l.lse = l.take(2 * TB);
+  l.proj = l.take(l.tied ? TB * l.Ep : 0);
+  // backward
+  l.dhdv = l.take(TB * l.Hp);
+  l.dga = l.take(TB * l.H4); l.dge = l.take(TB * l.H4); l.dgd = l.take(TB * l.H4);
+  l.dga_sum = l.take((size_t)B * l.H4);
+  l.g_h1 = l.take((size_t)B * l.Hp); l.g_c1 = l.take((size_t)B * l.Hp);
+  l.g_he = l.take((size_t)B * l.Hp); l.g_ce = l.take((size_t)B * l.Hp);
+  l.g_cd = l.take((size_t)B * l.Hp);
+  l.dz = l.take((size_t)B * l.Zp);
+  l.dmulv = l.take(TB * 2 * l.Z);
+  l.dx = l.take((size_t)B * l.XW);
+  l.dalpha = l.take((size_t)B * R);
+  l.dq = l.take(TB * l.Ap);
+  l.dpv = l.take((size_t)B * R * l.A);
+  l.dwa = l.take((size_t)B * l.A);
+  l.demb = l.take(TB * l.Ep);
+  l.dproj = l.take(l.tied ? TB * l.Ep : 0);
+  return l;
+}
+
+struct Seg {
+  const float* A; int lda;
+  const float* B; int ldb;
+  int K;
+};
+
+struct Ctx {
+  hipStream_t st;
+  float* slabs;
+  size_t slab_floats;
+};
+
+void fill_desc(ssc_gemm_desc& d, bool a_kc, bool b_kc, std::initializer_list<Seg> segs, int M, int N) {
+  d = ssc_gemm_desc{};
+  int i = 0;
+  for (const Seg& s : segs) {
+    if (s.K <= 0) continue;
+    d.seg[i].A = s.A; d.seg[i].lda = s.lda; d.seg[i].B = s.B; d.seg[i].ldb = s.ldb; d.seg[i].K = s.K;
+    ++i;
+  }
+  d.nseg = i;
+  d.M = M; d.N = N;
+  d.a_kc = a_kc; d.b_kc = b_kc;
+}
+
+// full GEMM into C (split-K through the shared slab workspace when it helps)
+int gemm(const Ctx& c, bool a_kc, bool b_kc, std::initializer_list<Seg> segs, int M, int N, float* C, int ldc,
+         const float* bias = nullptr, int accumulate = 0) {
+  ssc_gemm_desc d;
+  fill_desc(d, a_kc, b_kc, segs, M, N);
+  d.C = C; d.ldc = ldc; d.bias = bias; d.accumulate = accumulate;
+  d.splits = 0;
+  d.workspace = c.slabs; d.workspace_floats = c.slab_floats;
+  return ssc_gemm(&d, c.st);
+}
+
+// skinny GEMM that leaves its split-K slabs (M x N, ld N) in the slab workspace for a fused epilogue
+int gemm_to_slabs(const Ctx& c, std::initializer_list<Seg> segs, int M, int N, int* nslab) {
+  ssc_gemm_desc d;
+  fill_desc(d, true, true, segs, M, N);
+  int ksteps = 0;
+  for (int i = 0; i < d.nseg; ++i) ksteps += ssc_cdiv(d.seg[i].K, 32);
+  int splits = ssc_gemm_auto_splits(M, N, ksteps);
+  while (splits > 1 && (size_t)splits * M * N > c.slab_floats) --splits;
+  {
+    int per = ssc_cdiv(ksteps, splits);
+    splits = ssc_cdiv(ksteps, per);
+  }
+  *nslab = splits;
+  return ssc_gemm_slabs(&d, splits, c.slabs, c.st);
+}
+
+int check_cfg(const ssc_model_cfg* c, const ssc_params* p, const ssc_batch* b) {
+  if (!c || !p || !b) return SSC_EINVAL;
+  if (c->V <= 1 || c->E <= 0 || c->H <= 0 || c->A <= 0 || c->F <= 0 || c->Z <= 0) return SSC_EINVAL;
+  if (c->S != 0 && c->S != 1) return SSC_EINVAL;
+  if (b->B <= 0 || b->R <= 0 || b->L <= 0 || b->R > 256) return SSC_EINVAL;
+  if (!b->feats || !b->caps || !b->eps) return SSC_EINVAL;
+  if ((c->S || c->pm_scale != 0.f) && !b->sentiment) return SSC_EINVAL;
+  if (!p->emb || !p->att_w_ih || !p->att_w_hh || !p->att_b_ih || !p->att_b_hh || !p->wq || !p->wv || !p->wa ||
+      !p->enc_w_ih || !p->enc_w_hh || !p->enc_b_ih || !p->enc_b_hh || !p->dec_w_ih || !p->dec_w_hh || !p->dec_b_ih ||
+      !p->dec_b_hh || !p->fc_mean_w || !p->fc_mean_b || !p->fc_lv_w || !p->fc_lv_b)
+    return SSC_EINVAL;
+  if (c->tied ? (!p->proj_w || !p->proj_b) : (!p->out_w || !p->out_b)) return SSC_EINVAL;
+  return SSC_OK;
+}
+
+}  // namespace
+
+extern "C" size_t ssc_train_workspace_bytes(const ssc_model_cfg* cfg, int B, int R, int L) {
+  if (!cfg || B <= 0 || R <= 0 || L <= 0) return 0;
+  return make_layout(cfg, B, R, L).total * sizeof(float);
+}
+
+extern "C" void* ssc_train_workspace_view(const ssc_model_cfg* cfg, int B, int R, int L, void* workspace, int which,
+                                          int* ld) {
+  if (!cfg || !workspace) return nullptr;
+  Layout l = make_layout(cfg, B, R, L);
+  float* w = (float*)workspace;
+  int dummy;
+  if (!ld) ld = &dummy;
+  switch (which) {
+    case 0: *ld = l.Hp; return w + l.h1;
+    case 1: *ld = l.Hp; return w + l.c1;
+    case 2: *ld = l.Hp; return w + l.he;
+    case 3: *ld = l.Hp; return w + l.ce;
+    case 4: *ld = l.Hp; return w + l.hd;
+    case 5: *ld = l.Hp; return w + l.cd;
+    case 6: *ld = l.R; return w + l.alpha;
+    case 7: *ld = l.Zp; return w + l.mu;
+    case 8: *ld = l.Zp; return w + l.lv;
+    case 9: *ld = l.Vp; return w + l.logits;
+    case 10: *ld = l.B; return w + l.tok;
+    case 11: *ld = l.Fp; return w + l.att;
+    default: return nullptr;
+  }
+}
+
+extern "C" int ssc_train_fwd(const ssc_model_cfg* cfg, const ssc_params* p, const ssc_batch* bt, void* workspace,
+                             size_t workspace_bytes, float* loss, float* kld, void* stream) {
+  SSC_TRY(check_cfg(cfg, p, bt));
+  if (!workspace || !loss || !kld) return SSC_EINVAL;
+  if (!ssc_aligned16(workspace)) return SSC_EALIGN;
+  const Layout l = make_layout(cfg, bt->B, bt->R, bt->L);
+  if (workspace_bytes < l.total * sizeof(float)) return SSC_EWORKSPACE;
+  float* W = (float*)workspace;
+  hipStream_t st = (hipStream_t)stream;
+  Ctx c{st, W + l.slabs, l.slab_floats};
+  const int B = l.B, R = l.R, T = l.T, E = l.E, H = l.H, A = l.A, F = l.F, Z = l.Z, S = l.S, V = l.V, H4 = l.H4;
+  const int TB = T * B;
+  int64_t* tok = (int64_t*)(W + l.tok);
+  const size_t sH = (size_t)B * l.Hp;  // per-step stride of the state histories
+
+  // ---- per-sequence precompute --------------------------------------------------------------
+  SSC_TRY(ssc_prep_tokens(bt->caps, B, l.L, cfg->pad, cfg->boundary, tok, W + l.w, W + l.nvalid, st));
+  SSC_TRY(ssc_feat_prep(bt->feats, B, R, F, W + l.mask, W + l.avg, st));
+  SSC_TRY(gemm(c, true, true, {{bt->feats, F, p->wv, p->ld_wv, F}}, B * R, A, W + l.pv, A));
+  SSC_TRY(ssc_embed_gather(p->emb, p->ld_emb, tok, TB, E, W + l.emb, l.Ep, st));
+  SSC_TRY(gemm(c, true, true, {{W + l.emb, l.Ep, p->att_w_ih, p->ld_att_w_ih, E}}, TB, H4, W + l.ga_static, H4));
+  SSC_TRY(gemm(c, true, true, {{W + l.avg, F, p->att_w_ih + E, p->ld_att_w_ih, F}}, B, H4, W + l.ga_avg, H4));
+  // initial states (index 0 of every history) and the KL accumulator
+  for (size_t off : {l.h1, l.c1, l.he, l.ce, l.hd, l.cd}) SSC_TRY(ssc_fill(W + off, sH, 0.f, st));
+  SSC_TRY(ssc_fill(kld, B, 0.f, st));
+  if (l.Zp != Z) {  // keep pad columns of z finite (they are never read as K, but are memcpy'd in tests)
+    SSC_TRY(ssc_fill(W + l.z, (size_t)TB * l.Zp, 0.f, st));
+    SSC_TRY(ssc_fill(W + l.mu, (size_t)TB * l.Zp, 0.f, st));
+    SSC_TRY(ssc_fill(W + l.lv, (size_t)TB * l.Zp, 0.f, st));
+  }
+  const bool fc_adjacent = (p->fc_lv_w == p->fc_mean_w + (size_t)Z * p->ld_fc_mean_w) && p->ld_fc_lv_w == p->ld_fc_mean_w;
+
+  // ---- time loop ----------------------------------------------------------------------------------
+  for (int t = 0; t < T; ++t) {
+    float* h1p = W + l.h1 + t * sH; float* h1n = h1p + sH;
+    float* c1p = W + l.c1 + t * sH; float* c1n = c1p + sH;
+    float* hep = W + l.he + t * sH; float* hen = hep + sH;
+    float* cep = W + l.ce + t * sH; float* cen = cep + sH;
+    float* hdp = W + l.hd + t * sH; float* hdn = hdp + sH;
+    float* cdp = W + l.cd + t * sH; float* cdn = cdp + sH;
+    float* att = W + l.att + (size_t)t * B * l.Fp;
+    float* qt = W + l.q + (size_t)t * B * l.Ap;
+    float* zt = W + l.z + (size_t)t * B * l.Zp;
+    int ns = 0;
+
+    // (i) attention LSTM: x_a = [emb, avg, h1', hd'] (updown_cell.py:143-148)
+    {
+      ssc_lstm_fwd_desc d{};
+      d.B = B; d.H = H;
+      if (t > 0) {  // all recurrent inputs are zero at t = 0
+        const float* wr = p->att_w_ih + E + F;
+        SSC_TRY(gemm_to_slabs(c, {{h1p, l.Hp, wr, p->ld_att_w_ih, H}, {hdp, l.Hp, wr + H, p->ld_att_w_ih, H},
+                                  {h1p, l.Hp, p->att_w_hh, p->ld_att_w_hh, H}}, B, H4, &ns));
+        d.slabs = c.slabs; d.nslab = ns; d.slab_stride = (size_t)B * H4;
+      }
+      d.add0 = W + l.ga_static + (size_t)t * B * H4; d.ld_add0 = H4;
+      d.add1 = W + l.ga_avg; d.ld_add1 = H4; d.rows_per_add1 = 1;
+      d.b_ih = p->att_b_ih; d.b_hh = p->att_b_hh;
+      d.c_prev = c1p; d.ld_cprev = l.Hp;
+      d.gates_out = W + l.gates_a + (size_t)t * B * H4;
+      d.c_out = c1n; d.ld_cout = l.Hp; d.h_out = h1n; d.ld_hout = l.Hp;
+      SSC_TRY(ssc_lstm_fwd(&d, st));
+    }
+    // (ii)+(iii) attention (attention.py:69-95, updown_cell.py:151-158)
+    SSC_TRY(gemm(c, true, true, {{h1n, l.Hp, p->wq, p->ld_wq, H}}, B, A, qt, l.Ap));
+    SSC_TRY(ssc_attn_fwd(qt, l.Ap, W + l.pv, p->wa, W + l.mask, bt->feats, B, R, A, F, 1, W + l.attn_logits,
+                         W + l.alpha + (size_t)t * B * R, att, l.Fp, st));
+    // (iv) encoder LSTM: x_e = [att, h1, hd', (s)] (updown_cell.py:176-194)
+    {
+      SSC_TRY(gemm_to_slabs(c, {{att, l.Fp, p->enc_w_ih, p->ld_enc_w_ih, F}, {h1n, l.Hp, p->enc_w_ih + F, p->ld_enc_w_ih, H},
+                                {hdp, l.Hp, p->enc_w_ih + F + H, p->ld_enc_w_ih, t > 0 ? H : 0},
+                                {hep, l.Hp, p->enc_w_hh, p->ld_enc_w_hh, t > 0 ? H : 0}}, B, H4, &ns));
+      ssc_lstm_fwd_desc d{};
+      d.B = B; d.H = H;
+      d.slabs = c.slabs; d.nslab = ns; d.slab_stride = (size_t)B * H4;
+      d.b_ih = p->enc_b_ih; d.b_hh = p->enc_b_hh;
+      if (S) { d.sent = bt->sentiment; d.wcol = p->enc_w_ih + F + 2 * H; d.ldwcol = p->ld_enc_w_ih; }
+      d.c_prev = cep; d.ld_cprev = l.Hp;
+      d.gates_out = W + l.gates_e + (size_t)t * B * H4;
+      d.c_out = cen; d.ld_cout = l.Hp; d.h_out = hen; d.ld_hout = l.Hp;
+      SSC_TRY(ssc_lstm_fwd(&d, st));
+    }
+    // latent head: mean / log_var / z / KL (updown_cell.py:196-208, updown_captioner.py:295-303)
+    {
+      float* mulv = W + l.mulv;
+      if (fc_adjacent) {
+        SSC_TRY(gemm(c, true, true, {{hen, l.Hp, p->fc_mean_w, p->ld_fc_mean_w, H}}, B, 2 * Z, mulv, 2 * Z));
+      } else {
+        SSC_TRY(gemm(c, true, true, {{hen, l.Hp, p->fc_mean_w, p->ld_fc_mean_w, H}}, B, Z, mulv, 2 * Z));
+        SSC_TRY(gemm(c, true, true, {{hen, l.Hp, p->fc_lv_w, p->ld_fc_lv_w, H}}, B, Z, mulv + Z, 2 * Z));
+      }
+      ssc_latent_fwd_desc d{};
+      d.B = B; d.Z = Z;
+      d.mulv = mulv; d.ldmulv = 2 * Z; d.nslab = 1; d.slab_stride = 0;
+      d.bmu = p->fc_mean_b; d.blv = p->fc_lv_b;
+      d.eps = bt->eps + (size_t)t * B * Z; d.ldeps = Z;
+      d.kld_mode = cfg->kld_mode; d.sent = cfg->pm_scale != 0.f ? bt->sentiment : nullptr;
+      d.pm_scale = cfg->pm_scale; d.prior_var = cfg->prior_var;
+      d.w = W + l.w + (size_t)t * B;
+      d.mu = W + l.mu + (size_t)t * B * l.Zp; d.lv = W + l.lv + (size_t)t * B * l.Zp; d.z = zt; d.ldz = l.Zp;
+      d.kld_acc = kld;
+      SSC_TRY(ssc_latent_fwd(&d, st));
+    }
+    // (vi) decoder LSTM: x_d = [att, h1, hd', (s), z] (updown_cell.py:211-229)
+    {
+      const float* wz = p->dec_w_ih + F + 2 * H + S;
+      SSC_TRY(gemm_to_slabs(c, {{att, l.Fp, p->dec_w_ih, p->ld_dec_w_ih, F}, {h1n, l.Hp, p->dec_w_ih + F, p->ld_dec_w_ih, H},
+                                {hdp, l.Hp, p->dec_w_ih + F + H, p->ld_dec_w_ih, t > 0 ? H : 0},
+                                {zt, l.Zp, wz, p->ld_dec_w_ih, Z},
+                                {hdp, l.Hp, p->dec_w_hh, p->ld_dec_w_hh, t > 0 ? H : 0}}, B, H4, &ns));
+      ssc_lstm_fwd_desc d{};
+      d.B = B; d.H = H;
+      d.slabs = c.slabs; d.nslab = ns; d.slab_stride = (size_t)B * H4;
+      d.b_ih = p->dec_b_ih; d.b_hh = p->dec_b_hh;
+      if (S) { d.sent = bt->sentiment; d.wcol = p->dec_w_ih + F + 2 * H; d.ldwcol = p->ld_dec_w_ih; }
+      d.c_prev = cdp; d.ld_cprev = l.Hp;
+      d.gates_out = W + l.gates_d + (size_t)t * B * H4;
+      d.c_out = cdn; d.ld_cout = l.Hp; d.h_out = hdn; d.ld_hout = l.Hp;
+      SSC_TRY(ssc_lstm_fwd(&d, st));
+    }
+  }
+
+  // ---- vocabulary projection + CE over all steps (updown_captioner.py:444-445, 457-466) -----------
+  const float* hd_all = W + l.hd + sH;  // rows t*B+b = h_dec after step t
+  if (cfg->tied) {
+    SSC_TRY(gemm(c, true, true, {{hd_all, l.Hp, p->proj_w, p->ld_proj_w, H}}, TB, E, W + l.proj, l.Ep));
+    SSC_TRY(ssc_bias_tanh(W + l.proj, l.Ep, TB, E, p->proj_b, st));
+    SSC_TRY(gemm(c, true, true, {{W + l.proj, l.Ep, p->emb, p->ld_emb, E}}, TB, V, W + l.logits, l.Vp));
+  } else {
+    SSC_TRY(gemm(c, true, true, {{hd_all, l.Hp, p->out_w, p->ld_out_w, H}}, TB, V, W + l.logits, l.Vp, p->out_b));
+  }
+  SSC_TRY(ssc_ce_fwd(W + l.logits, l.Vp, tok + B, W + l.w, W + l.nvalid, T, B, V, W + l.lse, loss, st));
+  return SSC_OK;
+}
+
+extern "C" int ssc_train_bwd(const ssc_model_cfg* cfg, const ssc_params* p, const ssc_batch* bt, void* workspace,
+                             size_t workspace_bytes, const float* gl, const float* gk, const ssc_params* g, void* stream) {
+  SSC_TRY(check_cfg(cfg, p, bt));
+  if (!workspace || !gl || !gk || !g) return SSC_EINVAL;
+  const Layout l = make_layout(cfg, bt->B, bt->R, bt->L);
+  if (workspace_bytes < l.total * sizeof(float)) return SSC_EWORKSPACE;
+  float* W = (float*)workspace;
+  hipStream_t st = (hipStream_t)stream;
+  Ctx c{st, W + l.slabs, l.slab_floats};
+  const int B = l.B, R = l.R, T = l.T, E = l.E, H = l.H, A = l.A, F = l.F, Z = l.Z, S = l.S, V = l.V, H4 = l.H4;
+  const int TB = T * B, XW = l.XW;
+  int64_t* tok = (int64_t*)(W + l.tok);
+  const size_t sH = (size_t)B * l.Hp;
+  const float* hd_all = W + l.hd + sH;
+
+  // ---- vocabulary head ------------------------------------------------------------------------------
+  SSC_TRY(ssc_ce_bwd(W + l.logits, l.Vp, tok + B, W + l.w, W + l.nvalid, W + l.lse, gl, T, B, V, st));
+  const float* dlog = W + l.logits;
+  if (cfg->tied) {
+    float* dP = W + l.dproj;
+    SSC_TRY(gemm(c, true, false, {{dlog, l.Vp, p->emb, p->ld_emb, V}}, TB, E, dP, l.Ep));
+    SSC_TRY(ssc_tanh_bwd(dP, l.Ep, W + l.proj, l.Ep, TB, E, st));
+    SSC_TRY(gemm(c, true, false, {{dP, l.Ep, p->proj_w, p->ld_proj_w, E}}, TB, H, W + l.dhdv, l.Hp));
+    if (g->proj_w) SSC_TRY(gemm(c, false, false, {{dP, l.Ep, hd_all, l.Hp, TB}}, E, H, g->proj_w, g->ld_proj_w));
+    if (g->proj_b) SSC_TRY(ssc_colsum(dP, l.Ep, TB, E, nullptr, g->proj_b, 1, 0, st));
+  } else {
+    SSC_TRY(gemm(c, true, false, {{dlog, l.Vp, p->out_w, p->ld_out_w, V}}, TB, H, W + l.dhdv, l.Hp));
+    if (g->out_w) SSC_TRY(gemm(c, false, false, {{dlog, l.Vp, hd_all, l.Hp, TB}}, V, H, g->out_w, g->ld_out_w));
+    if (g->out_b) SSC_TRY(ssc_colsum(dlog, l.Vp, TB, V, nullptr, g->out_b, 1, 0, st));
+  }
+
+  // ---- carried gradients start at zero ----------------------------------------------------------------
+  for (size_t off : {l.g_h1, l.g_c1, l.g_he, l.g_ce, l.g_cd}) SSC_TRY(ssc_fill(W + off, sH, 0.f, st));
+  SSC_TRY(ssc_fill(W + l.dx, (size_t)B * XW, 0.f, st));
+  SSC_TRY(ssc_fill(W + l.dpv, (size_t)B * R * A, 0.f, st));
+  SSC_TRY(ssc_fill(W + l.dwa, (size_t)B * A, 0.f, st));
+  SSC_TRY(ssc_fill(W + l.dga_sum, (size_t)B * H4, 0.f, st));
+  float* dx = W + l.dx;            // [datt (F) | dh1 (H) | dhd' (H)] ; the dhd' block doubles as carried g_hd
+  float* g_hd = dx + F + H;        // ld XW
+  const int zcol = F + 2 * H + S;
+
+  for (int t = T - 1; t >= 0; --t) {
+    float* dgd = W + l.dgd + (size_t)t * B * H4;
+    float* dge = W + l.dge + (size_t)t * B * H4;
+    float* dga = W + l.dga + (size_t)t * B * H4;
+    float* dmulv = W + l.dmulv + (size_t)t * B * 2 * Z;
+    float* dq = W + l.dq + (size_t)t * B * l.Ap;
+    // 1. decoder LSTM
+    {
+      ssc_lstm_bwd_desc d{};
+      d.B = B; d.H = H;
+      d.dh = g_hd; d.ld_dh = XW;
+      d.dh2 = W + l.dhdv + (size_t)t * B * l.Hp; d.ld_dh2 = l.Hp;
+      d.dc_in = W + l.g_cd; d.ld_dcin = l.Hp;
+      d.gates = W + l.gates_d + (size_t)t * B * H4;
+      d.c_prev = W + l.cd + t * sH; d.ld_cprev = l.Hp;
+      d.c_new = W + l.cd + (t + 1) * sH; d.ld_cnew = l.Hp;
+      d.dG = dgd; d.dc_prev = W + l.g_cd; d.ld_dcprev = l.Hp;
+      SSC_TRY(ssc_lstm_bwd(&d, st));
+    }
+    // 2-3. dz and the latent head
+    SSC_TRY(gemm(c, true, false, {{dgd, H4, p->dec_w_ih + zcol, p->ld_dec_w_ih, H4}}, B, Z, W + l.dz, l.Zp));
+    {
+      ssc_latent_bwd_desc d{};
+      d.B = B; d.Z = Z;
+      d.dz = W + l.dz; d.lddz = l.Zp;
+      d.eps = bt->eps + (size_t)t * B * Z; d.ldeps = Z;
+      d.mu = W + l.mu + (size_t)t * B * l.Zp; d.lv = W + l.lv + (size_t)t * B * l.Zp; d.ldz = l.Zp;
+      d.kld_mode = cfg->kld_mode; d.sent = cfg->pm_scale != 0.f ? bt->sentiment : nullptr;
+      d.pm_scale = cfg->pm_scale; d.prior_var = cfg->prior_var;
+      d.w = W + l.w + (size_t)t * B; d.gk = gk;
+      d.dmulv = dmulv; d.lddmulv = 2 * Z;
+      SSC_TRY(ssc_latent_bwd(&d, st));
+    }
+    // 4. dhe = g_he + dmu Wmu + dlv Wlv
+    SSC_TRY(gemm(c, true, false, {{dmulv, 2 * Z, p->fc_mean_w, p->ld_fc_mean_w, Z}, {dmulv + Z, 2 * Z, p->fc_lv_w, p->ld_fc_lv_w, Z}},
+                 B, H, W + l.g_he, l.Hp, nullptr, 1));
+    // 5. encoder LSTM
+    {
+      ssc_lstm_bwd_desc d{};
+      d.B = B; d.H = H;
+      d.dh = W + l.g_he; d.ld_dh = l.Hp;
+      d.dc_in = W + l.g_ce; d.ld_dcin = l.Hp;
+      d.gates = W + l.gates_e + (size_t)t * B * H4;
+      d.c_prev = W + l.ce + t * sH; d.ld_cprev = l.Hp;
+      d.c_new = W + l.ce + (t + 1) * sH; d.ld_cnew = l.Hp;
+      d.dG = dge; d.dc_prev = W + l.g_ce; d.ld_dcprev = l.Hp;
+      SSC_TRY(ssc_lstm_bwd(&d, st));
+    }
+    // 6. [datt | dh1 | dhd'] = dGd W_ih^dec[:, :F+2H] + dGe W_ih^enc[:, :F+2H]
+    SSC_TRY(gemm(c, true, false, {{dgd, H4, p->dec_w_ih, p->ld_dec_w_ih, H4}, {dge, H4, p->enc_w_ih, p->ld_enc_w_ih, H4}}, B,
+                 F + 2 * H, dx, XW));
+    // 7. attention backward
+    SSC_TRY(ssc_attn_bwd(dx, XW, W + l.q + (size_t)t * B * l.Ap, l.Ap, W + l.pv, p->wa, W + l.alpha + (size_t)t * B * R,
+                         bt->feats, B, R, A, F, dq, l.Ap, W + l.dpv, W + l.dwa, W + l.dalpha, st));
+    // 8. dh1 = g_h1 + dx[h1] + dq Wq
+    SSC_TRY(gemm(c, true, false, {{dq, l.Ap, p->wq, p->ld_wq, A}}, B, H, W + l.g_h1, l.Hp, nullptr, 1));
+    // 9. attention LSTM
+    {
+      ssc_lstm_bwd_desc d{};
+      d.B = B; d.H = H;
+      d.dh = W + l.g_h1; d.ld_dh = l.Hp;
+      d.dh2 = dx + F; d.ld_dh2 = XW;
+      d.dc_in = W + l.g_c1; d.ld_dcin = l.Hp;
+      d.gates = W + l.gates_a + (size_t)t * B * H4;
+      d.c_prev = W + l.c1 + t * sH; d.ld_cprev = l.Hp;
+      d.c_new = W + l.c1 + (t + 1) * sH; d.ld_cnew = l.Hp;
+      d.dG = dga; d.dc_prev = W + l.g_c1; d.ld_dcprev = l.Hp;
+      d.dgsum = W + l.dga_sum;
+      SSC_TRY(ssc_lstm_bwd(&d, st));
+    }
+    // 10. gradients carried to step t-1
+    if (t > 0) {
+      const float* wr = p->att_w_ih + E + F;
+      SSC_TRY(gemm(c, true, false, {{dga, H4, wr, p->ld_att_w_ih, H4}, {dga, H4, p->att_w_hh, p->ld_att_w_hh, H4}}, B, H,
+                   W + l.g_h1, l.Hp));
+      SSC_TRY(gemm(c, true, false, {{dga, H4, wr + H, p->ld_att_w_ih, H4}, {dgd, H4, p->dec_w_hh, p->ld_dec_w_hh, H4}}, B, H,
+                   g_hd, XW, nullptr, 1));
+      SSC_TRY(gemm(c, true, false, {{dge, H4, p->enc_w_hh, p->ld_enc_w_hh, H4}}, B, H, W + l.g_he, l.Hp));
+    }
+  }
+
+  // ---- weight gradients: one K = T*B GEMM per block ----------------------------------------------------
+  const float* dga = W + l.dga; const float* dge = W + l.dge; const float* dgd = W + l.dgd;
+  const float* h1_prev = W + l.h1; const float* h1_new = W + l.h1 + sH;
+  const float* hd_prev = W + l.hd; const float* he_prev = W + l.he; const float* he_new = W + l.he + sH;
+  const float* att = W + l.att;
+  // sentiment replicated over time (row = t*B+b) for the rank-1 column gradients
+  if (S) {
+    for (int t = 0; t < T; ++t)
+      if (hipMemcpyAsync(W + l.sent_all + (size_t)t * B, bt->sentiment, B * sizeof(float), hipMemcpyDeviceToDevice, st) !=
+          hipSuccess)
+        return SSC_EHIP;
+  }
+  // attention LSTM
+  if (g->att_w_ih) {
+    float* gw = g->att_w_ih; int ld = g->ld_att_w_ih;
+    SSC_TRY(gemm(c, false, false, {{dga, H4, W + l.emb, l.Ep, TB}}, H4, E, gw, ld));
+    SSC_TRY(gemm(c, false, false, {{W + l.dga_sum, H4, W + l.avg, F, B}}, H4, F, gw + E, ld));
+    SSC_TRY(gemm(c, false, false, {{dga, H4, h1_prev, l.Hp, TB}}, H4, H, gw + E + F, ld));
+    SSC_TRY(gemm(c, false, false, {{dga, H4, hd_prev, l.Hp, TB}}, H4, H, gw + E + F + H, ld));
+  }
+  if (g->att_w_hh) SSC_TRY(gemm(c, false, false, {{dga, H4, h1_prev, l.Hp, TB}}, H4, H, g->att_w_hh, g->ld_att_w_hh));
+  if (g->att_b_ih) SSC_TRY(ssc_colsum(dga, H4, TB, H4, nullptr, g->att_b_ih, 1, 0, st));
+  if (g->att_b_hh) SSC_TRY(ssc_colsum(dga, H4, TB, H4, nullptr, g->att_b_hh, 1, 0, st));
+  if (g->emb && !cfg->tied) {
+    SSC_TRY(gemm(c, true, false, {{dga, H4, p->att_w_ih, p->ld_att_w_ih, H4}}, TB, E, W + l.demb, l.Ep));
+    // zero the table gradient, then scatter-add rows by token id (padding_idx row gets none)
+    if (hipMemset2DAsync(g->emb, (size_t)g->ld_emb * sizeof(float), 0, (size_t)E * sizeof(float), V, st) != hipSuccess)
+      return SSC_EHIP;
+    SSC_TRY(ssc_embed_scatter_add(g->emb, g->ld_emb, tok, TB, E, W + l.demb, l.Ep, cfg->pad, st));
+  }
+  // attention projections
+  if (g->wq) SSC_TRY(gemm(c, false, false, {{W + l.dq, l.Ap, h1_new, l.Hp, TB}}, A, H, g->wq, g->ld_wq));
+  if (g->wv) SSC_TRY(gemm(c, false, false, {{W + l.dpv, A, bt->feats, F, B * R}}, A, F, g->wv, g->ld_wv));
+  if (g->wa) SSC_TRY(ssc_colsum(W + l.dwa, A, B, A, nullptr, g->wa, 1, 0, st));
+  // encoder LSTM
+  if (g->enc_w_ih) {
+    float* gw = g->enc_w_ih; int ld = g->ld_enc_w_ih;
+    SSC_TRY(gemm(c, false, false, {{dge, H4, att, l.Fp, TB}}, H4, F, gw, ld));
+    SSC_TRY(gemm(c, false, false, {{dge, H4, h1_new, l.Hp, TB}}, H4, H, gw + F, ld));
+    SSC_TRY(gemm(c, false, false, {{dge, H4, hd_prev, l.Hp, TB}}, H4, H, gw + F + H, ld));
+    if (S) SSC_TRY(ssc_colsum(dge, H4, TB, H4, W + l.sent_all, gw + F + 2 * H, ld, 0, st));
+  }
+  if (g->enc_w_hh) SSC_TRY(gemm(c, false, false, {{dge, H4, he_prev, l.Hp, TB}}, H4, H, g->enc_w_hh, g->ld_enc_w_hh));
+  if (g->enc_b_ih) SSC_TRY(ssc_colsum(dge, H4, TB, H4, nullptr, g->enc_b_ih, 1, 0, st));
+  if (g->enc_b_hh) SSC_TRY(ssc_colsum(dge, H4, TB, H4, nullptr, g->enc_b_hh, 1, 0, st));
+  // latent heads
+  const float* dmulv = W + l.dmulv;
+  if (g->fc_mean_w) SSC_TRY(gemm(c, false, false, {{dmulv, 2 * Z, he_new, l.Hp, TB}}, Z, H, g->fc_mean_w, g->ld_fc_mean_w));
+  if (g->fc_lv_w) SSC_TRY(gemm(c, false, false, {{dmulv + Z, 2 * Z, he_new, l.Hp, TB}}, Z, H, g->fc_lv_w, g->ld_fc_lv_w));
+  if (g->fc_mean_b) SSC_TRY(ssc_colsum(dmulv, 2 * Z, TB, Z, nullptr, g->fc_mean_b, 1, 0, st));
+  if (g->fc_lv_b) SSC_TRY(ssc_colsum(dmulv + Z, 2 * Z, TB, Z, nullptr, g->fc_lv_b, 1, 0, st));
+  // decoder LSTM (skipped while frozen: train.py:156-161)
+  if (g->dec_w_ih) {
+    float* gw = g->dec_w_ih; int ld = g->ld_dec_w_ih;
+    SSC_TRY(gemm(c, false, false, {{dgd, H4, att, l.Fp, TB}}, H4, F, gw, ld));
+    SSC_TRY(gemm(c, false, false, {{dgd, H4, h1_new, l.Hp, TB}}, H4, H, gw + F, ld));
+    SSC_TRY(gemm(c, false, false, {{dgd, H4, hd_prev, l.Hp, TB}}, H4, H, gw + F + H, ld));
+    if (S) SSC_TRY(ssc_colsum(dgd, H4, TB, H4, W + l.sent_all, gw + F + 2 * H, ld, 0, st));
+    SSC_TRY(gemm(c, false, false, {{dgd, H4, W + l.z, l.Zp, TB}}, H4, Z, gw + zcol, ld));
+  }
+  if (g->dec_w_hh) SSC_TRY(gemm(c, false, false, {{dgd, H4, hd_prev, l.Hp, TB}}, H4, H, g->dec_w_hh, g->ld_dec_w_hh));
+  if (g->dec_b_ih) SSC_TRY(ssc_colsum(dgd, H4, TB, H4, nullptr, g->dec_b_ih, 1, 0, st));
+  if (g->dec_b_hh) SSC_TRY(ssc_colsum(dgd, H4, TB, H4, nullptr, g->dec_b_hh, 1, 0, st));
+  return SSC_OK;
+}

@@ -1,0 +1,46 @@
+// Internal helpers shared by the HIP translation units of libssc_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "ssc.h"
+
+extern thread_local int ssc_tls_hip_error;
+
+#define SSC_CHECK_LAUNCH()                         \
+  do {                                             \
+    hipError_t e__ = hipGetLastError();            \
+    if (e__ != hipSuccess) {                       \
+      ssc_tls_hip_error = (int)e__;                \
+      return SSC_EHIP;                             \
+    }                                              \
+  } while (0)
+
+#define SSC_TRY(expr)            \
+  do {                           \
+    int rc__ = (expr);           \
+    if (rc__ != SSC_OK) return rc__; \
+  } while (0)
+
+static inline bool ssc_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+static inline int ssc_cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline size_t ssc_round_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
+
+#define SSC_WAVE 64
+__device__ __forceinline__ bool ssc_aligned16_dev(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+
+__device__ __forceinline__ float ssc_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float ssc_wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float ssc_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// internal cross-TU entry points (not part of the C ABI)
+int ssc_gemm_slabs(const ssc_gemm_desc* d, int splits, float* slabs, hipStream_t st);  // partial slabs only

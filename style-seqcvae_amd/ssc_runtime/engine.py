@@ -1,0 +1,307 @@
+"""Training / decoding engine over the C ABI: flat parameter + gradient buffers, the fused
+T-step forward/BPTT, clip + SGD, and the data-parallel gradient exchange.
+
+Reference for the behaviour reproduced here: UpDownCaptioner.forward
+(var_updown/var_updown/models/updown_captioner.py:228-368) and the optimiser loop of
+var_updown/scripts/train.py:154-176.
+"""
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import lib as _lib
+
+P_CELL = "_updown_cell."
+P_ATT = P_CELL + "_attention_lstm_cell."
+P_ENC = P_CELL + "_language_lstm_cell_encoder."
+P_DEC = P_CELL + "_language_lstm_cell_decoder."
+P_BUTD = P_CELL + "_butd_attention."
+
+# state_dict key -> ssc_params field
+FIELD_OF = {
+    "_embedding_layer.weight": "emb",
+    P_ATT + "weight_ih": "att_w_ih", P_ATT + "weight_hh": "att_w_hh", P_ATT + "bias_ih": "att_b_ih", P_ATT + "bias_hh": "att_b_hh",
+    P_BUTD + "_query_vector_projection_layer.weight": "wq",
+    P_BUTD + "_image_features_projection_layer.weight": "wv",
+    P_BUTD + "_attention_layer.weight": "wa",
+    P_ENC + "weight_ih": "enc_w_ih", P_ENC + "weight_hh": "enc_w_hh", P_ENC + "bias_ih": "enc_b_ih", P_ENC + "bias_hh": "enc_b_hh",
+    P_CELL + "fc_mean.weight": "fc_mean_w", P_CELL + "fc_mean.bias": "fc_mean_b",
+    P_CELL + "fc_log_var.weight": "fc_lv_w", P_CELL + "fc_log_var.bias": "fc_lv_b",
+    "_output_layer.weight": "out_w", "_output_layer.bias": "out_b",
+    "_output_projection.0.weight": "proj_w", "_output_projection.0.bias": "proj_b",
+    P_DEC + "weight_ih": "dec_w_ih", P_DEC + "weight_hh": "dec_w_hh", P_DEC + "bias_ih": "dec_b_ih", P_DEC + "bias_hh": "dec_b_hh",
+}
+HAS_LD = dict(_lib.PARAM_FIELDS)
+
+
+@dataclass
+class ModelDims:
+    """Hot-path hyper-parameters (mirror of ssc_model_cfg)."""
+    V: int
+    E: int
+    H: int
+    A: int
+    F: int
+    Z: int
+    S: int = 0            # sentiment columns on the language LSTMs (updown_cell.py:47-81)
+    tied: bool = False    # E in {300,600}: frozen tied embedding (updown_captioner.py:75,112-119)
+    kld_mode: int = 0     # 0: SENTIMENT_VAE == 0 formula, 1 otherwise (updown_captioner.py:298-303)
+    pm_scale: float = 0.0  # prior_mean = pm_scale * sentiment
+    prior_var: float = 1.0
+    pad: int = 0
+    boundary: int = 1
+
+    def cfg(self) -> _lib.ModelCfg:
+        return _lib.ModelCfg(self.V, self.E, self.H, self.A, self.F, self.Z, self.S, int(self.tied), self.kld_mode,
+                             float(self.pm_scale), float(self.prior_var), self.pad, self.boundary)
+
+    def param_shapes(self) -> "Dict[str, Tuple[int, ...]]":
+        V, E, H, A, F, Z, S = self.V, self.E, self.H, self.A, self.F, self.Z, self.S
+        sh = {"_embedding_layer.weight": (V, E)}
+        sh[P_ATT + "weight_ih"] = (4 * H, E + F + 2 * H)
+        sh[P_ATT + "weight_hh"] = (4 * H, H)
+        sh[P_ATT + "bias_ih"] = (4 * H,)
+        sh[P_ATT + "bias_hh"] = (4 * H,)
+        sh[P_BUTD + "_query_vector_projection_layer.weight"] = (A, H)
+        sh[P_BUTD + "_image_features_projection_layer.weight"] = (A, F)
+        sh[P_BUTD + "_attention_layer.weight"] = (1, A)
+        sh[P_ENC + "weight_ih"] = (4 * H, S + F + 2 * H)
+        sh[P_ENC + "weight_hh"] = (4 * H, H)
+        sh[P_ENC + "bias_ih"] = (4 * H,)
+        sh[P_ENC + "bias_hh"] = (4 * H,)
+        sh[P_CELL + "fc_mean.weight"] = (Z, H)
+        sh[P_CELL + "fc_log_var.weight"] = (Z, H)      # adjacent to fc_mean.weight: one (2Z,H) GEMM operand
+        sh[P_CELL + "fc_mean.bias"] = (Z,)
+        sh[P_CELL + "fc_log_var.bias"] = (Z,)
+        if self.tied:
+            sh["_output_projection.0.weight"] = (E, H)
+            sh["_output_projection.0.bias"] = (E,)
+        else:
+            sh["_output_layer.weight"] = (V, H)
+            sh["_output_layer.bias"] = (V,)
+        # decoder LSTM last: one contiguous range that the freeze schedule (train.py:156-161) can skip
+        sh[P_DEC + "weight_ih"] = (4 * H, S + F + 2 * H + Z)
+        sh[P_DEC + "weight_hh"] = (4 * H, H)
+        sh[P_DEC + "bias_ih"] = (4 * H,)
+        sh[P_DEC + "bias_hh"] = (4 * H,)
+        return sh
+
+
+def _r4(x):
+    return (x + 3) // 4 * 4
+
+
+class FlatStore:
+    """One flat fp32 device buffer holding every tensor of `shapes` (16-B aligned offsets, rows of 2-D
+    weights padded to a multiple of 4 floats so that 16 B/lane loads stay legal), exposed as views."""
+
+    def __init__(self, shapes: "Dict[str, Tuple[int, ...]]", device, zero=True):
+        self.shapes = dict(shapes)
+        self.offsets: Dict[str, Tuple[int, int]] = {}
+        off = 0
+        for name, shp in shapes.items():
+            n = shp[0] * _r4(shp[1]) if len(shp) == 2 and shp[0] > 1 else _r4(shp[-1])
+            self.offsets[name] = (off, n)
+            off += (n + 63) // 64 * 64
+        self.numel = off
+        self.flat = torch.zeros(off, dtype=torch.float32, device=device) if zero else torch.empty(
+            off, dtype=torch.float32, device=device)
+        self.views: Dict[str, torch.Tensor] = {}
+        for name, shp in shapes.items():
+            o, n = self.offsets[name]
+            if len(shp) == 2 and shp[0] > 1:
+                ld = _r4(shp[1])
+                self.views[name] = self.flat[o:o + n].view(shp[0], ld)[:, :shp[1]]
+            else:
+                self.views[name] = self.flat[o:o + shp[-1]].view(*shp)
+
+    def range_of(self, names: Sequence[str]) -> Tuple[int, int]:
+        """[lo, hi) flat range covering `names` (must be laid out consecutively)."""
+        lo = min(self.offsets[n][0] for n in names)
+        hi = max(self.offsets[n][0] + (self.offsets[n][1] + 63) // 64 * 64 for n in names)
+        return lo, hi
+
+    def c_struct(self, only: Optional[Sequence[str]] = None) -> _lib.Params:
+        s = _lib.Params()
+        for name, view in self.views.items():
+            if only is not None and name not in only:
+                continue
+            f = FIELD_OF[name]
+            setattr(s, f, view.data_ptr())
+            if HAS_LD[f]:
+                setattr(s, "ld_" + f, view.stride(0))
+        return s
+
+
+def params_struct(tensors: "Dict[str, torch.Tensor]") -> _lib.Params:
+    """ssc_params over arbitrary (row-major, unit inner stride) tensors."""
+    s = _lib.Params()
+    for name, t in tensors.items():
+        if name not in FIELD_OF:
+            continue
+        f = FIELD_OF[name]
+        if t.dim() == 2 and t.stride(1) != 1 and t.size(0) > 1:
+            raise ValueError(f"{name}: inner stride must be 1")
+        setattr(s, f, t.data_ptr())
+        if HAS_LD[f]:
+            setattr(s, "ld_" + f, t.stride(0) if t.size(0) > 1 else t.size(1))
+    return s
+
+
+class TrainEngine:
+    """Owns parameters, gradients and the activation workspace of one model replica on one GPU."""
+
+    def __init__(self, dims: ModelDims, device=None):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("TrainEngine needs a ROCm GPU (no CPU fallback)")
+        self.dims = dims
+        self.device = torch.device(device if device is not None else "cuda")
+        shapes = dims.param_shapes()
+        self.params = FlatStore(shapes, self.device)
+        self.grads = FlatStore(shapes, self.device)
+        self.momentum = None
+        self._ws = None
+        self._ws_key = None
+        self._cfg = dims.cfg()
+        self._keep = None
+        self._scratch = torch.zeros(1024 + 8, dtype=torch.float32, device=self.device)
+        names = list(shapes)
+        self.decoder_names = [n for n in names if n.startswith(P_DEC)]
+        self.frozen_names = ["_embedding_layer.weight"] if dims.tied else []
+        self.steps_done = 0
+
+    # ---- parameters --------------------------------------------------------------------------------
+    def load_state_dict(self, sd: "Dict[str, torch.Tensor]"):
+        for name, view in self.params.views.items():
+            src = sd[name]
+            view.copy_(src.to(self.device, torch.float32).view_as(view))
+
+    def state_dict(self) -> "Dict[str, torch.Tensor]":
+        out = {k: v.detach().clone().contiguous() for k, v in self.params.views.items()}
+        if self.dims.tied:
+            out["_output_layer.weight"] = out["_embedding_layer.weight"]
+        return out
+
+    def grad_dict(self) -> "Dict[str, torch.Tensor]":
+        return {k: v.detach().clone().contiguous() for k, v in self.grads.views.items()}
+
+    # ---- fused forward / backward ----------------------------------------------------------------------
+    def _workspace(self, B, R, L):
+        key = (B, R, L)
+        if self._ws_key != key:
+            nbytes = self.lib.ssc_train_workspace_bytes(C.byref(self._cfg), B, R, L)
+            self._ws = torch.empty(nbytes // 4 + 64, dtype=torch.float32, device=self.device)
+            self._ws_key = key
+        return self._ws
+
+    def _batch(self, feats, caps, sentiment, eps):
+        B, R, F = feats.shape
+        L = caps.shape[1]
+        assert F == self.dims.F and feats.is_contiguous() and caps.is_contiguous() and eps.is_contiguous()
+        assert caps.dtype == torch.int64 and feats.dtype == torch.float32 and eps.dtype == torch.float32
+        assert tuple(eps.shape) == (L + 1, B, self.dims.Z), eps.shape
+        sent = None
+        if sentiment is not None:
+            sent = sentiment.reshape(B).to(torch.float32).contiguous()
+        bt = _lib.Batch(B, R, L, feats.data_ptr(), caps.data_ptr(), sent.data_ptr() if sent is not None else None,
+                        eps.data_ptr())
+        return bt, sent
+
+    def forward(self, feats, caps, sentiment, eps):
+        """-> (loss (B,), kld (B,)); keeps activations for backward()."""
+        bt, sent = self._batch(feats, caps, sentiment, eps)
+        ws = self._workspace(bt.B, bt.R, bt.L)
+        loss = torch.empty(bt.B, dtype=torch.float32, device=self.device)
+        kld = torch.empty(bt.B, dtype=torch.float32, device=self.device)
+        p = self.params.c_struct()
+        self.lib.ssc_train_fwd(C.byref(self._cfg), C.byref(p), C.byref(bt), _lib.ptr(ws), ws.numel() * 4, _lib.ptr(loss),
+                               _lib.ptr(kld), _lib.stream_ptr())
+        self._keep = (bt, feats, caps, sent, eps)
+        return loss, kld
+
+    def backward(self, gl, gk, skip: Sequence[str] = ()):
+        """Writes d(sum_b gl_b loss_b + gk_b kld_b)/dparam into self.grads for every parameter not in `skip`
+        (nor frozen)."""
+        bt = self._keep[0]
+        ws = self._workspace(bt.B, bt.R, bt.L)
+        skipset = set(skip) | set(self.frozen_names)
+        only = [n for n in self.grads.views if n not in skipset]
+        p = self.params.c_struct()
+        g = self.grads.c_struct(only=only)
+        gl = gl.to(torch.float32).contiguous()
+        gk = gk.to(torch.float32).contiguous()
+        self.lib.ssc_train_bwd(C.byref(self._cfg), C.byref(p), C.byref(bt), _lib.ptr(ws), ws.numel() * 4, _lib.ptr(gl),
+                               _lib.ptr(gk), C.byref(g), _lib.stream_ptr())
+
+    def workspace_view(self, which, T1=None):
+        """Saved activations of the last forward (test hook; see ssc_train_workspace_view)."""
+        bt = self._keep[0]
+        ws = self._workspace(bt.B, bt.R, bt.L)
+        ld = C.c_int(0)
+        p = self.lib.ssc_train_workspace_view(C.byref(self._cfg), bt.B, bt.R, bt.L, _lib.ptr(ws), which, C.byref(ld))
+        off = (p - ws.data_ptr()) // 4
+        T, B = bt.L + 1, bt.B
+        d = self.dims
+        if which <= 5:
+            return ws[off:off + (T + 1) * B * ld.value].view(T + 1, B, ld.value)[:, :, :d.H]
+        if which == 6:
+            return ws[off:off + T * B * bt.R].view(T, B, bt.R)
+        if which in (7, 8):
+            return ws[off:off + T * B * ld.value].view(T, B, ld.value)[:, :, :d.Z]
+        if which == 9:
+            return ws[off:off + T * B * ld.value].view(T, B, ld.value)[:, :, :d.V]
+        if which == 11:
+            return ws[off:off + T * B * ld.value].view(T, B, ld.value)[:, :, :d.F]
+        raise ValueError(which)
+
+    # ---- optimiser (train.py:126-134,173-176) ---------------------------------------------------------
+    def trainable_range(self, decoder_frozen: bool) -> Tuple[int, int]:
+        """The flat layout is [frozen tied embedding | always-trainable | decoder LSTM], so the trainable part is
+        one contiguous range whatever the freeze schedule (train.py:156-161) says."""
+        lo, hi = 0, self.params.numel
+        if self.frozen_names:
+            lo = self.params.range_of(self.frozen_names)[1]
+        if decoder_frozen:
+            hi = self.params.range_of(self.decoder_names)[0]
+        return lo, hi
+
+    def clip_sgd_step(self, lr, momentum=0.9, weight_decay=0.001, max_norm=12.5, decoder_frozen=False, gscale=1.0):
+        """clip_grad_norm_(max_norm) + SGD(momentum, weight_decay) on the flat buffers, skipping frozen ranges
+        (torch>=2 semantics: parameters without a gradient are not touched).  Momentum buffers start at zero,
+        which reproduces torch's lazily created buffer (first step: buf = d_p).  Returns the squared grad norm."""
+        if self.momentum is None:
+            self.momentum = torch.zeros_like(self.params.flat)
+        lo, hi = self.trainable_range(decoder_frozen)
+        st = _lib.stream_ptr()
+        sq = self._scratch[1024:1025]
+        self.lib.ssc_sq_norm(_lib.ptr(self.grads.flat[lo:hi]), hi - lo, _lib.ptr(self._scratch), _lib.ptr(sq), st)
+        self.lib.ssc_sgd_step(_lib.ptr(self.params.flat[lo:hi]), _lib.ptr(self.grads.flat[lo:hi]),
+                              _lib.ptr(self.momentum[lo:hi]), hi - lo, _lib.ptr(sq), float(gscale), float(max_norm),
+                              float(lr), float(momentum), float(weight_decay), 0, st)
+        self.steps_done += 1
+        return sq
+
+    # ---- data parallel -----------------------------------------------------------------------------------
+    def allreduce_grads(self, group=None):
+        """One RCCL all-reduce (sum) over the flat gradient buffer; the 1/world_size is folded into the SGD kernel."""
+        import torch.distributed as dist
+
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(self.grads.flat, op=dist.ReduceOp.SUM, group=group)
+            return dist.get_world_size(group)
+        return 1
+
+    def train_step(self, feats, caps, sentiment, eps, lr, kld_weight=750.0, momentum=0.9, weight_decay=0.001,
+                   max_norm=12.5, decoder_frozen=False, group=None):
+        """fwd + bwd + (all-reduce) + clip + SGD: one iteration of train.py:154-176.  Returns (loss, kld) per row."""
+        loss, kld = self.forward(feats, caps, sentiment, eps)
+        B = loss.numel()
+        gl = torch.full((B,), 1.0 / B, dtype=torch.float32, device=self.device)
+        gk = torch.full((B,), 1.0 / (B * kld_weight), dtype=torch.float32, device=self.device)
+        self.backward(gl, gk, skip=self.decoder_names if decoder_frozen else ())
+        world = self.allreduce_grads(group)
+        self.clip_sgd_step(lr, momentum, weight_decay, max_norm, decoder_frozen, gscale=1.0 / world)
+        return loss, kld

@@ -1,0 +1,188 @@
+"""ctypes binding of libssc_hip.so - mirrors include/ssc.h one to one."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libssc_hip.so")
+SSC_MAX_SEG = 6
+
+c_float_p = C.POINTER(C.c_float)
+c_i64_p = C.POINTER(C.c_int64)
+vp = C.c_void_p
+
+
+class SscError(RuntimeError):
+    CODES = {-1: "SSC_EINVAL", -2: "SSC_EALIGN", -3: "SSC_EHIP", -4: "SSC_EWORKSPACE"}
+
+    def __init__(self, fn, rc, hip=0):
+        super().__init__(f"{fn} failed: {self.CODES.get(rc, rc)}" + (f" (hipError {hip})" if rc == -3 else ""))
+        self.rc = rc
+
+
+class GemmSeg(C.Structure):
+    _fields_ = [("A", vp), ("B", vp), ("lda", C.c_int), ("ldb", C.c_int), ("K", C.c_int)]
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [("seg", GemmSeg * SSC_MAX_SEG), ("nseg", C.c_int), ("M", C.c_int), ("N", C.c_int), ("a_kc", C.c_int),
+                ("b_kc", C.c_int), ("C", vp), ("ldc", C.c_int), ("bias", vp), ("accumulate", C.c_int),
+                ("splits", C.c_int), ("workspace", vp), ("workspace_floats", C.c_size_t)]
+
+
+class LstmFwdDesc(C.Structure):
+    _fields_ = [("B", C.c_int), ("H", C.c_int), ("slabs", vp), ("nslab", C.c_int), ("slab_stride", C.c_size_t),
+                ("add0", vp), ("ld_add0", C.c_int), ("add1", vp), ("ld_add1", C.c_int), ("rows_per_add1", C.c_int),
+                ("b_ih", vp), ("b_hh", vp), ("sent", vp), ("wcol", vp), ("ldwcol", C.c_int), ("c_prev", vp),
+                ("ld_cprev", C.c_int), ("gates_out", vp), ("c_out", vp), ("ld_cout", C.c_int), ("h_out", vp),
+                ("ld_hout", C.c_int)]
+
+
+class LstmBwdDesc(C.Structure):
+    _fields_ = [("B", C.c_int), ("H", C.c_int), ("dh", vp), ("ld_dh", C.c_int), ("dh2", vp), ("ld_dh2", C.c_int),
+                ("dc_in", vp), ("ld_dcin", C.c_int), ("gates", vp), ("c_prev", vp), ("ld_cprev", C.c_int),
+                ("c_new", vp), ("ld_cnew", C.c_int), ("dG", vp), ("dc_prev", vp), ("ld_dcprev", C.c_int), ("dgsum", vp)]
+
+
+class LatentFwdDesc(C.Structure):
+    _fields_ = [("B", C.c_int), ("Z", C.c_int), ("mulv", vp), ("ldmulv", C.c_int), ("nslab", C.c_int),
+                ("slab_stride", C.c_size_t), ("bmu", vp), ("blv", vp), ("eps", vp), ("ldeps", C.c_int),
+                ("kld_mode", C.c_int), ("sent", vp), ("pm_scale", C.c_float), ("prior_var", C.c_float), ("w", vp),
+                ("mu", vp), ("lv", vp), ("z", vp), ("ldz", C.c_int), ("kld_acc", vp)]
+
+
+class LatentBwdDesc(C.Structure):
+    _fields_ = [("B", C.c_int), ("Z", C.c_int), ("dz", vp), ("lddz", C.c_int), ("eps", vp), ("ldeps", C.c_int),
+                ("mu", vp), ("lv", vp), ("ldz", C.c_int), ("kld_mode", C.c_int), ("sent", vp), ("pm_scale", C.c_float),
+                ("prior_var", C.c_float), ("w", vp), ("gk", vp), ("dmulv", vp), ("lddmulv", C.c_int)]
+
+
+class ModelCfg(C.Structure):
+    _fields_ = [("V", C.c_int), ("E", C.c_int), ("H", C.c_int), ("A", C.c_int), ("F", C.c_int), ("Z", C.c_int),
+                ("S", C.c_int), ("tied", C.c_int), ("kld_mode", C.c_int), ("pm_scale", C.c_float),
+                ("prior_var", C.c_float), ("pad", C.c_int), ("boundary", C.c_int)]
+
+
+# (field, has_ld) in the exact order of ssc_params
+PARAM_FIELDS = [("emb", True), ("att_w_ih", True), ("att_w_hh", True), ("att_b_ih", False), ("att_b_hh", False),
+                ("wq", True), ("wv", True), ("wa", False), ("enc_w_ih", True), ("enc_w_hh", True), ("enc_b_ih", False),
+                ("enc_b_hh", False), ("dec_w_ih", True), ("dec_w_hh", True), ("dec_b_ih", False), ("dec_b_hh", False),
+                ("fc_mean_w", True), ("fc_mean_b", False), ("fc_lv_w", True), ("fc_lv_b", False), ("out_w", True),
+                ("out_b", False), ("proj_w", True), ("proj_b", False)]
+
+
+def _param_fields():
+    f = []
+    for name, has_ld in PARAM_FIELDS:
+        f.append((name, vp))
+        if has_ld:
+            f.append(("ld_" + name, C.c_int))
+    return f
+
+
+class Params(C.Structure):
+    _fields_ = _param_fields()
+
+
+class Batch(C.Structure):
+    _fields_ = [("B", C.c_int), ("R", C.c_int), ("L", C.c_int), ("feats", vp), ("caps", vp), ("sentiment", vp),
+                ("eps", vp)]
+
+
+class DecodeStepDesc(C.Structure):
+    _fields_ = [("G", C.c_int), ("R", C.c_int), ("rows_per_image", C.c_int), ("feats", vp), ("imgbuf", vp),
+                ("tokens", vp), ("sentiment", vp), ("eps", vp), ("h1", vp), ("c1", vp), ("hd", vp), ("cd", vp),
+                ("h1_out", vp), ("c1_out", vp), ("hd_out", vp), ("cd_out", vp), ("alpha", vp), ("log_probs", vp)]
+
+
+# name -> (restype, argtypes).  Every symbol include/ssc.h declares is listed; tests check they all resolve.
+_i, _f, _sz = C.c_int, C.c_float, C.c_size_t
+SYMBOLS = {
+    "ssc_version": (_i, []),
+    "ssc_last_hip_error": (_i, []),
+    "ssc_arch": (C.c_char_p, []),
+    "ssc_gemm": (_i, [C.POINTER(GemmDesc), vp]),
+    "ssc_gemm_auto_splits": (_i, [_i, _i, _i]),
+    "ssc_feat_prep": (_i, [vp, _i, _i, _i, vp, vp, vp]),
+    "ssc_prep_tokens": (_i, [vp, _i, _i, _i, _i, vp, vp, vp, vp]),
+    "ssc_embed_gather": (_i, [vp, _i, vp, _i, _i, vp, _i, vp]),
+    "ssc_embed_scatter_add": (_i, [vp, _i, vp, _i, _i, vp, _i, _i, vp]),
+    "ssc_lstm_fwd": (_i, [C.POINTER(LstmFwdDesc), vp]),
+    "ssc_lstm_bwd": (_i, [C.POINTER(LstmBwdDesc), vp]),
+    "ssc_attn_logits": (_i, [vp, _i, vp, vp, _i, _i, _i, _i, vp, vp]),
+    "ssc_attn_fwd": (_i, [vp, _i, vp, vp, vp, vp, _i, _i, _i, _i, _i, vp, vp, vp, _i, vp]),
+    "ssc_attn_bwd": (_i, [vp, _i, vp, _i, vp, vp, vp, vp, _i, _i, _i, _i, vp, _i, vp, vp, vp, vp]),
+    "ssc_latent_fwd": (_i, [C.POINTER(LatentFwdDesc), vp]),
+    "ssc_latent_prior_sample": (_i, [vp, _i, vp, _f, _f, _i, _i, vp, _i, vp]),
+    "ssc_latent_bwd": (_i, [C.POINTER(LatentBwdDesc), vp]),
+    "ssc_ce_fwd": (_i, [vp, _i, vp, vp, vp, _i, _i, _i, vp, vp, vp]),
+    "ssc_ce_bwd": (_i, [vp, _i, vp, vp, vp, vp, vp, _i, _i, _i, vp]),
+    "ssc_log_softmax": (_i, [vp, _i, _i, _i, vp, _i, vp]),
+    "ssc_colsum": (_i, [vp, _i, _i, _i, vp, vp, _i, _i, vp]),
+    "ssc_bias_tanh": (_i, [vp, _i, _i, _i, vp, vp]),
+    "ssc_tanh_bwd": (_i, [vp, _i, vp, _i, _i, _i, vp]),
+    "ssc_fill": (_i, [vp, _sz, _f, vp]),
+    "ssc_sq_norm": (_i, [vp, _sz, vp, vp, vp]),
+    "ssc_sgd_step": (_i, [vp, vp, vp, _sz, vp, _f, _f, _f, _f, _f, _i, vp]),
+    "ssc_train_workspace_bytes": (_sz, [C.POINTER(ModelCfg), _i, _i, _i]),
+    "ssc_train_fwd": (_i, [C.POINTER(ModelCfg), C.POINTER(Params), C.POINTER(Batch), vp, _sz, vp, vp, vp]),
+    "ssc_train_bwd": (_i, [C.POINTER(ModelCfg), C.POINTER(Params), C.POINTER(Batch), vp, _sz, vp, vp, C.POINTER(Params), vp]),
+    "ssc_train_workspace_view": (vp, [C.POINTER(ModelCfg), _i, _i, _i, vp, _i, C.POINTER(C.c_int)]),
+    "ssc_decode_image_bytes": (_sz, [C.POINTER(ModelCfg), _i, _i]),
+    "ssc_decode_prepare": (_i, [C.POINTER(ModelCfg), C.POINTER(Params), vp, _i, _i, vp, _sz, vp]),
+    "ssc_decode_step_workspace_bytes": (_sz, [C.POINTER(ModelCfg), _i, _i]),
+    "ssc_decode_step": (_i, [C.POINTER(ModelCfg), C.POINTER(Params), C.POINTER(DecodeStepDesc), vp, _sz, vp]),
+    "ssc_beam_first": (_i, [vp, _i, vp, _i, _i, _i, _i, vp, vp, vp]),
+    "ssc_beam_step": (_i, [vp, _i, vp, vp, vp, _i, _i, _i, _i, _i, _i, vp, vp, vp, vp, vp, vp]),
+    "ssc_gather_rows": (_i, [vp, _i, vp, _i, _i, _i, vp, vp]),
+}
+
+_lib = None
+
+
+class _Lib:
+    def __init__(self, cdll):
+        self._cdll = cdll
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(cdll, name)  # AttributeError if the .so lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+            setattr(self, "_raw_" + name, fn)
+
+    def __getattr__(self, name):
+        raw = self.__dict__.get("_raw_" + name)
+        if raw is None:
+            raise AttributeError(name)
+        if raw.restype is not C.c_int or name in ("ssc_version", "ssc_last_hip_error", "ssc_gemm_auto_splits"):
+            return raw
+
+        def checked(*a):
+            rc = raw(*a)
+            if rc != 0:
+                raise SscError(name, rc, self._raw_ssc_last_hip_error())
+            return rc
+
+        return checked
+
+
+def load():
+    """Load libssc_hip.so.  Raises (never falls back) when the extension is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} not found: build it with `python style-seqcvae_amd/build.py` "
+                              "(the HIP extension is mandatory; there is no CPU fallback)")
+        _lib = _Lib(C.CDLL(LIB_PATH))
+    return _lib
+
+
+def ptr(t):
+    """Device (or host) pointer of a torch tensor as c_void_p (None -> NULL)."""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,83 @@
+"""GPU: fused T-step forward + BPTT (ssc_train_fwd / ssc_train_bwd through the C ABI) against
+(a) the committed golden vectors produced by the reference itself and (b) the CPU oracle on seeded
+inputs at medium size.  Tolerance (BASELINE.json north_star): 1e-4 abs, fp32."""
+import pytest
+import torch
+
+import oracle
+from goldenlib import group, load
+from gpuutil import dev, engine_from, maxdiff
+
+pytestmark = pytest.mark.gpu
+
+TRAIN = ["g1_train_sv1", "g2_train_sv0", "g3_train_tied", "g4_train_prior", "g4b_train_simple", "g7_train_odd"]
+TOL = 1e-4
+
+
+@pytest.mark.parametrize("name", TRAIN)
+def test_train_matches_reference_golden(name):
+    d, cfgd = load(name)
+    cfg = oracle.OracleConfig(**cfgd)
+    params = group(d, "param/")
+    ins = group(d, "in/")
+    eng = engine_from(cfg, params)
+    loss, kld = eng.forward(dev(ins["feats"]), dev(ins["caps"]), dev(ins["sentiment"]), dev(ins["eps"]))
+    exp = group(d, "out/")
+    assert maxdiff(loss, exp["loss"]) < TOL
+    assert maxdiff(kld, exp["kld"]) < TOL
+    T = ins["eps"].shape[0]
+    names = {0: "h1", 1: "c1", 2: "h_encoder", 3: "c_encoder", 4: "h_decoder", 5: "c_decoder"}
+    for t in (0, 1, T - 1):
+        st = group(d, f"step{t}/")
+        for which, key in names.items():
+            assert maxdiff(eng.workspace_view(which)[t + 1], st[key]) < TOL, (t, key)
+        assert maxdiff(eng.workspace_view(6)[t], st["alpha"]) < TOL
+        assert maxdiff(eng.workspace_view(7)[t], st["mean"]) < TOL
+        assert maxdiff(eng.workspace_view(8)[t], st["log_var"]) < TOL
+        assert maxdiff(eng.workspace_view(9)[t], st["logits"]) < TOL
+    B = loss.numel()
+    gl = torch.full((B,), 1.0 / B, device="cuda")
+    gk = torch.full((B,), 1.0 / (B * 750.0), device="cuda")
+    eng.backward(gl, gk)
+    got = eng.grad_dict()
+    grads = group(d, "grad/")
+    for k, g in grads.items():
+        if k == "_output_layer.weight" and cfg.tied:
+            continue
+        assert maxdiff(got[k], g) < TOL, k
+        scale = g.abs().max().item()
+        assert maxdiff(got[k], g) <= 1e-4 * max(scale, 1e-3) + 2e-6, (k, scale)
+
+
+@pytest.mark.parametrize("sv,B,R,dims", [
+    (1, 8, 36, dict(V=1000, E=200, H=256, A=128, F=512, Z=64, L=12)),
+    (0, 5, 10, dict(V=777, E=100, H=130, A=70, F=260, Z=30, L=9)),
+])
+def test_train_matches_oracle_medium(sv, B, R, dims):
+    cfg = oracle.OracleConfig(vocab_size=dims["V"], image_feature_size=dims["F"], embedding_size=dims["E"],
+                              hidden_size=dims["H"], attention_projection_size=dims["A"], z_space=dims["Z"],
+                              max_caption_length=dims["L"], sentiment_vae=sv, senti_prior_multip=0.5)
+    params = oracle.init_params(cfg, seed=5)
+    g = torch.Generator().manual_seed(17)
+    L, T = dims["L"], dims["L"] + 1
+    feats = torch.randn(B, R, dims["F"], generator=g)
+    feats[0, R - 3:] = 0
+    caps = torch.zeros(B, L, dtype=torch.long)
+    for b in range(B):
+        n = int(torch.randint(3, L + 1, (1,), generator=g))
+        caps[b, :n] = torch.randint(2, dims["V"], (n,), generator=g)
+    senti = torch.randint(-1, 2, (B, 1), generator=g).float()
+    eps = torch.randn(T, B, dims["Z"], generator=g)
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    out = oracle.train_forward(p, cfg, feats, caps, senti, eps)
+    oracle.train_objective(out, cfg).backward()
+    eng = engine_from(cfg, params)
+    loss, kld = eng.forward(dev(feats), dev(caps), dev(senti), dev(eps))
+    assert maxdiff(loss, out["loss"]) < TOL * 5  # loss ~ O(80): relative 1e-5
+    assert maxdiff(kld, out["kld"]) < TOL * 5
+    gl = torch.full((B,), 1.0 / B, device="cuda")
+    gk = torch.full((B,), 1.0 / (B * cfg.kld_weight), device="cuda")
+    eng.backward(gl, gk)
+    got = eng.grad_dict()
+    for k, v in p.items():
+        assert maxdiff(got[k], v.grad) < TOL, k
