@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""Headline benchmark: captions/sec of one Style-SeqCVAE (var_updown) train step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N=1 directly; N>1 under torch.distributed.run)
+
+A "step" = one pass of the hot path over one minibatch per GPU: fused T-step forward + BPTT (HIP kernels behind
+libssc_hip.so) + RCCL all-reduce of the flat gradient buffer + clip_grad_norm + SGD(momentum, wd)
+(reference: var_updown/scripts/train.py:154-176).  Workload = BASELINE.json configs[1] ("C2": B=64/GPU, 36x2048
+region features, 20-token captions, Z=128, V=10000; E/H/A from the reference Config defaults 1000/1200/768,
+SENTIMENT_VAE=1).  Inputs are synthetic and resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "style-seqcvae_amd"))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
+MFMA_F32_PEAK_TF = 157.3   # MI355X_MICROARCH.md: fp32 MFMA = fp32 vector peak
+
+C2 = dict(B=64, R=36, F=2048, L=20, Z=128, V=10000, E=1000, H=1200, A=768)
+
+
+def synth_batch(seed, B, R, F, L, V, Z, device):
+    g = torch.Generator().manual_seed(seed)
+    feats = torch.randn(B, R, F, generator=g)
+    lens = torch.randint(8, L + 1, (B,), generator=g)
+    caps = torch.zeros(B, L, dtype=torch.long)
+    ids = torch.randint(2, V, (B, L), generator=g)
+    for b in range(B):
+        caps[b, : lens[b]] = ids[b, : lens[b]]
+    senti = torch.randint(-1, 2, (B, 1), generator=g).float()
+    eps = torch.randn(L + 1, B, Z, generator=g)
+    return tuple(t.to(device) for t in (feats, caps, senti, eps))
+
+
+def fused_step_bytes(c):
+    """algorithmic bytes of ONE fused attention+LSTM step (rows #7-#11, excl. vocab), fp32, S=1."""
+    B, R, F, E, H, A, Z = c["B"], c["R"], c["F"], c["E"], c["H"], c["A"], c["Z"]
+    H4, s = 4 * H, 1
+    w_att = H4 * (E + F + 2 * H + H) + 2 * H4
+    w_enc = H4 * (F + 2 * H + s + H) + 2 * H4
+    w_dec = H4 * (F + 2 * H + s + Z + H) + 2 * H4
+    weights = w_att + A * H + A + w_enc + 2 * (Z * H + Z) + w_dec
+    acts = B * (R * F + R * A + F + E + 12 * H + 4 * Z + R)
+    return 4 * (weights + acts)
+
+
+def cpu_baseline(c, seconds_budget=25.0):
+    """The CPU oracle (oracle/: pure-torch restatement pinned to the reference) timed on this box's host cores on
+    the same workload: full train step (fwd + autograd bwd + clip + SGD), bounded sample."""
+    import oracle
+
+    cfg = oracle.OracleConfig(vocab_size=c["V"], image_feature_size=c["F"], embedding_size=c["E"], hidden_size=c["H"],
+                              attention_projection_size=c["A"], z_space=c["Z"], max_caption_length=c["L"],
+                              sentiment_vae=1, senti_prior_multip=0.5)
+    params = {k: v.requires_grad_(True) for k, v in oracle.init_params(cfg, seed=2).items()}
+    feats, caps, senti, eps = synth_batch(1234, c["B"], c["R"], c["F"], c["L"], c["V"], c["Z"], "cpu")
+    opt = torch.optim.SGD(list(params.values()), lr=0.015, momentum=0.9, weight_decay=0.001)
+    cores = torch.get_num_threads()
+
+    def step():
+        opt.zero_grad()
+        out = oracle.train_forward(params, cfg, feats, caps, senti, eps)
+        oracle.train_objective(out, cfg).backward()
+        torch.nn.utils.clip_grad_norm_(list(params.values()), 12.5)
+        opt.step()
+
+    step()  # warm-up
+    times = []
+    t_start = time.time()
+    while len(times) < 5 and (time.time() - t_start) < seconds_budget:
+        t0 = time.time()
+        step()
+        times.append(time.time() - t0)
+    med = sorted(times)[len(times) // 2]
+    return {"value": c["B"] / med, "unit": "captions/s", "cores": cores, "kind": "port",
+            "sample": f"{len(times)} train steps (fwd+bwd+clip+SGD) of the C2 minibatch (B={c['B']}) after 1 warm-up, "
+                      f"median {med:.2f} s/step, torch {torch.__version__} CPU, os.cpu_count()={os.cpu_count()}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch", type=int, default=C2["B"])
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from ssc_runtime import lib as L
+    from ssc_runtime.vocab import Vocabulary
+    from var_updown.models import UpDownCaptioner
+
+    c = dict(C2)
+    c["B"] = args.batch
+    torch.manual_seed(2)  # RANDOM_SEED of the shipped yaml; identical replicas on every rank (default torch inits)
+    model = UpDownCaptioner(Vocabulary.synthetic(c["V"]), image_feature_size=c["F"], embedding_size=c["E"],
+                            hidden_size=c["H"], attention_projection_size=c["A"], max_caption_length=c["L"], beam_size=5,
+                            z_space=c["Z"], prior_std=1.0, simple_vae=False, latent_embedding="glove", sentiment_vae=1,
+                            senti_prior_multip=0.5, device=device).to(device)
+    eng = model._engine()  # flat parameter / gradient store + fused kernels; the module's parameters are views of it
+    batches = [synth_batch(1234 + rank + 100 * i, c["B"], c["R"], c["F"], c["L"], c["V"], c["Z"], device) for i in range(4)]
+    total_iters = 70000
+
+    def step(i):
+        feats, caps, senti, eps = batches[i % len(batches)]
+        lr = 0.015 * (1 - i / total_iters)
+        eng.train_step(feats, caps, senti, eps, lr=lr, kld_weight=750.0, momentum=0.9, weight_decay=0.001,
+                       max_norm=12.5, decoder_frozen=False)
+
+    for i in range(args.warmup):
+        step(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss_probe = eng.forward(*batches[0])[0].mean().item()
+
+    result = None
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        value = world * c["B"] * args.steps / elapsed
+        # ---- roofline leg: in-situ hipEvent timing of every GEMM launch over 2 further steps -----------------------
+        lib = L.load()
+        lib.ssc_prof_enable(1)
+        nprof = 2
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fwd_ms = []
+        for i in range(nprof):
+            feats, caps, senti, eps = batches[i % len(batches)]
+            ev0.record()
+            eng.forward(feats, caps, senti, eps)
+            ev1.record()
+            torch.cuda.synchronize()
+            fwd_ms.append(ev0.elapsed_time(ev1))
+            B = c["B"]
+            eng.backward(torch.full((B,), 1.0 / B, device=device), torch.full((B,), 1.0 / (B * 750.0), device=device))
+        buf = torch.zeros(4096 * 6, dtype=torch.float32)
+        n = lib.ssc_prof_collect(buf.data_ptr(), 4096)
+        lib.ssc_prof_enable(0)
+        rec = buf[: n * 6].view(n, 6)
+        names = {0: "gemm_kernel<NT> (forward: x W^T)", 1: "gemm_kernel<NN> (backward: dG W)", 3: "gemm_kernel<TN> (dW = dG^T X)"}
+        agg = {}
+        for kind, M, N, K, splits, msr in rec.tolist():
+            a = agg.setdefault(int(kind), dict(ms=0.0, flops=0.0, bytes=0.0, n=0))
+            a["ms"] += msr
+            a["flops"] += 2.0 * M * N * K
+            a["bytes"] += 4.0 * (K * (M + N) + M * N * splits)
+            a["n"] += 1
+        dom = max(agg, key=lambda k: agg[k]["ms"])
+        d = agg[dom]
+        tf = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+        # the recurrent (per-timestep) gate GEMMs of the fused attention+LSTM step: NT launches with M == B, N == 4H
+        step_recs = [r for r in rec.tolist() if int(r[0]) == 0 and int(r[1]) == c["B"] and int(r[2]) == 4 * c["H"]]
+        roofline = {"bound": "mfma", "kernel": names[dom], "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                    "frac": tf / MFMA_F32_PEAK_TF, "traffic": None, "launches_per_step": d["n"] / nprof,
+                    "avg_launch_us": d["ms"] / d["n"] * 1e3, "algorithmic_GBps": gbs,
+                    "hbm_frac_of_8TBps": gbs / HBM_PEAK_GBS,
+                    "share_of_gemm_time": d["ms"] / sum(a["ms"] for a in agg.values())}
+        T = c["L"] + 1
+        fused = fused_step_bytes(c)
+        fwd_step_us = (sum(fwd_ms) / len(fwd_ms)) / T * 1e3   # whole forward / T: upper bound on one fused step
+        roofline_step = {"bound": "hbm", "scope": "fused attention+LSTM step (SURVEY §8(d)), forward, incl. its share of "
+                         "the hoisted/vocab work", "achieved": fused / (fwd_step_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": fused / (fwd_step_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                         "algorithmic_bytes_per_step": fused, "us_per_step": fwd_step_us,
+                         "gate_gemm_us_per_step": sum(r[5] for r in step_recs) / nprof / T * 1e3}
+        result = {"metric": "captions/sec (train step)", "value": value, "unit": "captions/s", "n_gpus": world,
+                  "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+                  "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                  "config": {"workload": "C2 train step: fwd+bwd+allreduce+clip+SGD, B=%d/GPU, R=36, F=2048, L=20 (T=21), "
+                                         "Z=128, V=10000, E=1000, H=1200, A=768, SENTIMENT_VAE=1" % c["B"],
+                             "global_batch": world * c["B"], "parallelism": f"dp{world}", "loss_probe": loss_probe},
+                  "roofline": roofline, "roofline_step": roofline_step,
+                  "gemm_time_ms_per_step": {names[k]: agg[k]["ms"] / nprof for k in agg}}
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(c)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -68,6 +68,12 @@ typedef struct {
 } ssc_gemm_desc;
 
 int ssc_gemm(const ssc_gemm_desc* d, void* stream);
+
+/* In-situ GEMM profiling for bench.py's roofline leg (process-global switch, not thread-safe, off by default):
+ * while enabled every GEMM launch is bracketed by a hipEvent pair on its stream.  ssc_prof_collect synchronises the
+ * device and writes up to max_records x 6 floats {kind (0 NT,1 NN,3 TN), M, N, sum K, splits, milliseconds}. */
+int ssc_prof_enable(int on);
+int ssc_prof_collect(float* out, int max_records);
 int ssc_gemm_auto_splits(int M, int N, int ksteps); /* the split count ssc_gemm picks for splits=0 */
 
 /* ------------------------------------------------------------------------------------------------
@@ -303,7 +309,7 @@ typedef struct {
   const float* h1; const float* c1; const float* hd; const float* cd;
   float* h1_out; float* c1_out; float* hd_out; float* cd_out;
   float* alpha;              /* (G,R) */
-  float* log_probs;          /* (G,V) ld V */
+  float* log_probs;          /* (G,V) ld V; NULL: stop after the cell (UpDownCell.forward) */
 } ssc_decode_step_desc;
 size_t ssc_decode_step_workspace_bytes(const ssc_model_cfg* cfg, int G, int R);
 int ssc_decode_step(const ssc_model_cfg* cfg, const ssc_params* p, const ssc_decode_step_desc* d, void* workspace,
@@ -325,6 +331,9 @@ int ssc_beam_step(const float* log_probs, int ldlp, const uint8_t* fsm, const in
                   int64_t* backptr, float* scratch_val, int64_t* scratch_idx, void* stream);
 int ssc_gather_rows(const float* src, int ld, const int64_t* backptr, int B, int rows_per_batch, int W, float* dst,
                     void* stream);
+/* back-trace (cbs.py:252-277): preds (steps,B,SB) int64, backptrs (steps-1,B,SB) int64 -> out (B,SB,steps). */
+int ssc_beam_backtrace(const int64_t* preds, const int64_t* backptrs, int steps, int B, int SB, int64_t* out,
+                       void* stream);
 
 #ifdef __cplusplus
 }

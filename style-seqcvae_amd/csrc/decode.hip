@@ -221,6 +221,21 @@ __global__ __launch_bounds__(64) void beam_merge_kernel(const float* __restrict_
   }
 }
 
+// back-trace of the beam (cbs.py:252-277): preds (steps,B,SB), backptrs (steps-1,B,SB) -> out (B,SB,steps)
+__global__ void beam_backtrace_kernel(const int64_t* __restrict__ preds, const int64_t* __restrict__ backptrs, int steps,
+                                      int B, int SB, int64_t* __restrict__ out) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= B * SB) return;
+  int b = j / SB;
+  int64_t idx = j % SB;
+  size_t plane = (size_t)B * SB;
+  int64_t* o = out + (size_t)j * steps;
+  for (int t = steps - 1; t >= 0; --t) {
+    o[t] = preds[(size_t)t * plane + (size_t)b * SB + idx];
+    if (t > 0) idx = backptrs[(size_t)(t - 1) * plane + (size_t)b * SB + idx];
+  }
+}
+
 __global__ void gather_rows_kernel(const float* __restrict__ src, int ld, const int64_t* __restrict__ backptr,
                                    int rows_per_batch, int Wd, float* __restrict__ dst) {
   int row = blockIdx.y;
@@ -264,7 +279,7 @@ extern "C" int ssc_decode_step(const ssc_model_cfg* cfg, const ssc_params* p, co
   const int G = d->G, R = d->R, rpi = d->rows_per_image;
   if (G <= 0 || R <= 0 || R > 256 || rpi <= 0 || G % rpi != 0) return SSC_EINVAL;
   if (!d->feats || !d->imgbuf || !d->tokens || !d->eps || !d->h1 || !d->c1 || !d->hd || !d->cd || !d->h1_out ||
-      !d->c1_out || !d->hd_out || !d->cd_out || !d->alpha || !d->log_probs)
+      !d->c1_out || !d->hd_out || !d->cd_out || !d->alpha)
     return SSC_EINVAL;
   if ((cfg->S || cfg->pm_scale != 0.f) && !d->sentiment) return SSC_EINVAL;
   const int nimg = G / rpi;
@@ -317,7 +332,8 @@ extern "C" int ssc_decode_step(const ssc_model_cfg* cfg, const ssc_params* p, co
     f.c_out = d->cd_out; f.ld_cout = H; f.h_out = d->hd_out; f.ld_hout = H;
     SSC_TRY(ssc_lstm_fwd(&f, st));
   }
-  // vocabulary log-probabilities (updown_captioner.py:444-450)
+  // vocabulary log-probabilities (updown_captioner.py:444-450); skipped when only the cell output is wanted
+  if (!d->log_probs) return SSC_OK;
   if (cfg->tied) {
     SSC_TRY(gemm_nt(st, slabs, l.slab_floats, {{d->hd_out, H, p->proj_w, p->ld_proj_w, H}}, G, E, W + l.proj, l.Ep));
     SSC_TRY(ssc_bias_tanh(W + l.proj, l.Ep, G, E, p->proj_b, st));
@@ -363,6 +379,15 @@ extern "C" int ssc_gather_rows(const float* src, int ld, const int64_t* backptr,
   if (!src || !backptr || !dst || B <= 0 || rows_per_batch <= 0 || Wd <= 0 || ld < Wd || src == dst) return SSC_EINVAL;
   hipLaunchKernelGGL(gather_rows_kernel, dim3(ssc_cdiv(Wd, 256), B * rows_per_batch), dim3(256), 0, (hipStream_t)stream, src,
                      ld, backptr, rows_per_batch, Wd, dst);
+  SSC_CHECK_LAUNCH();
+  return SSC_OK;
+}
+
+extern "C" int ssc_beam_backtrace(const int64_t* preds, const int64_t* backptrs, int steps, int B, int SB, int64_t* out,
+                                  void* stream) {
+  if (!preds || !out || steps <= 0 || B <= 0 || SB <= 0 || (steps > 1 && !backptrs)) return SSC_EINVAL;
+  hipLaunchKernelGGL(beam_backtrace_kernel, dim3(ssc_cdiv(B * SB, 64)), dim3(64), 0, (hipStream_t)stream, preds, backptrs,
+                     steps, B, SB, out);
   SSC_CHECK_LAUNCH();
   return SSC_OK;
 }

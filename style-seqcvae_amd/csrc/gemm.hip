@@ -260,6 +260,16 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int nslab, 
 
 typedef void (*gemm_fn)(const KArgs);
 
+// ---- optional in-situ profiling (bench.py roofline leg): hipEvent pair around every GEMM launch ------
+struct ProfRec {
+  hipEvent_t e0, e1;
+  int kind, M, N, K, splits;
+};
+constexpr int PROF_MAX = 4096;
+ProfRec* g_prof = nullptr;
+int g_prof_n = 0;
+bool g_prof_on = false;
+
 int build_args(const ssc_gemm_desc* d, KArgs& k) {
   if (!d || d->nseg < 1 || d->nseg > SSC_MAX_SEG || d->M <= 0 || d->N <= 0) return SSC_EINVAL;
   k.nseg = d->nseg;
@@ -293,7 +303,17 @@ int launch(const ssc_gemm_desc* d, KArgs& k, int splits, hipStream_t st) {
   else if (d->a_kc && !d->b_kc) fn = gemm_kernel<true, false>;
   else if (!d->a_kc && !d->b_kc) fn = gemm_kernel<false, false>;
   else fn = gemm_kernel<false, true>;
+  ProfRec* rec = nullptr;
+  if (g_prof_on && g_prof && g_prof_n < PROF_MAX) {
+    rec = &g_prof[g_prof_n++];
+    rec->kind = (d->a_kc ? 0 : 2) + (d->b_kc ? 0 : 1);  // 0 NT, 1 NN, 3 TN
+    rec->M = d->M; rec->N = d->N; rec->splits = splits;
+    rec->K = 0;
+    for (int i = 0; i < d->nseg; ++i) rec->K += d->seg[i].K;
+    (void)hipEventRecord(rec->e0, st);
+  }
   hipLaunchKernelGGL(fn, grid, dim3(256), 0, st, k);
+  if (rec) (void)hipEventRecord(rec->e1, st);
   SSC_CHECK_LAUNCH();
   return SSC_OK;
 }
@@ -364,4 +384,33 @@ extern "C" int ssc_gemm(const ssc_gemm_desc* d, void* stream) {
                      k.slab_stride, d->M, d->N, d->C, d->ldc, d->bias, d->accumulate);
   SSC_CHECK_LAUNCH();
   return SSC_OK;
+}
+
+// ---- profiling control (process-global, not thread-safe; used by bench.py only) ------------------------
+extern "C" int ssc_prof_enable(int on) {
+  if (on && !g_prof) {
+    g_prof = new ProfRec[PROF_MAX];
+    for (int i = 0; i < PROF_MAX; ++i) {
+      if (hipEventCreate(&g_prof[i].e0) != hipSuccess || hipEventCreate(&g_prof[i].e1) != hipSuccess) return SSC_EHIP;
+    }
+  }
+  g_prof_on = on != 0;
+  if (on) g_prof_n = 0;
+  return SSC_OK;
+}
+
+// out: n records x 6 floats {kind, M, N, K, splits, milliseconds}; returns the record count (<= max_records)
+extern "C" int ssc_prof_collect(float* out, int max_records) {
+  if (!out || !g_prof) return 0;
+  if (hipDeviceSynchronize() != hipSuccess) return SSC_EHIP;
+  int n = g_prof_n < max_records ? g_prof_n : max_records;
+  for (int i = 0; i < n; ++i) {
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, g_prof[i].e0, g_prof[i].e1);
+    float* o = out + (size_t)i * 6;
+    o[0] = (float)g_prof[i].kind; o[1] = (float)g_prof[i].M; o[2] = (float)g_prof[i].N; o[3] = (float)g_prof[i].K;
+    o[4] = (float)g_prof[i].splits; o[5] = ms;
+  }
+  g_prof_n = 0;
+  return n;
 }

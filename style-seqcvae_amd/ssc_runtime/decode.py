@@ -1,0 +1,153 @@
+"""Eval-mode decode step + constrained beam search over the C ABI (ssc_decode_*, ssc_beam_*).
+
+Reference: UpDownCaptioner._decode_step eval branch (var_updown/var_updown/models/updown_captioner.py:371-455),
+ConstrainedBeamSearch.search (updown-baseline/updown/modules/cbs.py:59-277).
+"""
+import ctypes as C
+from typing import Callable, Dict, Optional, Tuple
+
+import torch
+
+from . import lib as _lib
+from .engine import ModelDims
+
+STATE_KEYS = ("h1", "c1", "h_encoder", "c_encoder", "h_decoder", "c_decoder")
+
+
+class ImageContext:
+    """Per-image terms computed once per image set (mask, avg, pv, hoisted gate term): ssc_decode_prepare."""
+
+    def __init__(self, feats: torch.Tensor, buf: torch.Tensor):
+        self.feats = feats
+        self.buf = buf
+        self.nimg, self.R, _ = feats.shape
+
+
+class DecodeEngine:
+    def __init__(self, dims: ModelDims, params_struct_fn: Callable[[], "_lib.Params"], device):
+        self.lib = _lib.load()
+        self.dims = dims
+        self.device = torch.device(device)
+        self._cfg = dims.cfg()
+        self._params = params_struct_fn
+        self._ws = None
+        self._ws_key = None
+
+    def prepare(self, feats: torch.Tensor) -> ImageContext:
+        assert feats.is_cuda and feats.dtype == torch.float32 and feats.dim() == 3 and feats.size(2) == self.dims.F
+        feats = feats.contiguous()
+        nimg, R, _ = feats.shape
+        nbytes = self.lib.ssc_decode_image_bytes(C.byref(self._cfg), nimg, R)
+        buf = torch.empty(nbytes // 4 + 64, dtype=torch.float32, device=self.device)
+        p = self._params()
+        self.lib.ssc_decode_prepare(C.byref(self._cfg), C.byref(p), _lib.ptr(feats), nimg, R, _lib.ptr(buf), buf.numel() * 4,
+                                    _lib.stream_ptr())
+        return ImageContext(feats, buf)
+
+    def zero_states(self, G: int) -> Dict[str, torch.Tensor]:
+        return {k: torch.zeros(G, self.dims.H, dtype=torch.float32, device=self.device) for k in STATE_KEYS}
+
+    def step(self, ctx: ImageContext, tokens: torch.Tensor, states: Optional[Dict[str, torch.Tensor]],
+             sentiment: Optional[torch.Tensor], eps: torch.Tensor, want_log_probs: bool = True,
+             emb_table: Optional[torch.Tensor] = None
+             ) -> Tuple[Optional[torch.Tensor], Dict[str, torch.Tensor], torch.Tensor]:
+        """One eval decode step for G rows (row g -> image g // (G / nimg)).  Returns (log_probs (G,V) or None,
+        new states, alpha (G,R)).  h_encoder / c_encoder are carried through untouched (updown_cell.py:176-203)."""
+        d = self.dims
+        G = tokens.numel()
+        assert G % ctx.nimg == 0, (G, ctx.nimg)
+        rpi = G // ctx.nimg
+        if states is None:
+            states = self.zero_states(G)
+        st = {k: v.contiguous() for k, v in states.items()}
+        tokens = tokens.to(torch.int64).contiguous()
+        eps = eps.to(self.device, torch.float32).contiguous()
+        assert tuple(eps.shape) == (G, d.Z), eps.shape
+        sent = sentiment.reshape(G).to(torch.float32).contiguous() if sentiment is not None else None
+        key = (G, ctx.R)
+        if self._ws_key != key:
+            nbytes = self.lib.ssc_decode_step_workspace_bytes(C.byref(self._cfg), G, ctx.R)
+            self._ws = torch.empty(nbytes // 4 + 64, dtype=torch.float32, device=self.device)
+            self._ws_key = key
+        new = {k: torch.empty_like(st[k]) for k in ("h1", "c1", "h_decoder", "c_decoder")}
+        alpha = torch.empty(G, ctx.R, dtype=torch.float32, device=self.device)
+        lp = torch.empty(G, d.V, dtype=torch.float32, device=self.device) if want_log_probs else None
+        desc = _lib.DecodeStepDesc(G, ctx.R, rpi, ctx.feats.data_ptr(), ctx.buf.data_ptr(), tokens.data_ptr(),
+                                   sent.data_ptr() if sent is not None else None, eps.data_ptr(),
+                                   st["h1"].data_ptr(), st["c1"].data_ptr(), st["h_decoder"].data_ptr(),
+                                   st["c_decoder"].data_ptr(), new["h1"].data_ptr(), new["c1"].data_ptr(),
+                                   new["h_decoder"].data_ptr(), new["c_decoder"].data_ptr(), alpha.data_ptr(),
+                                   lp.data_ptr() if lp is not None else None)
+        p = self._params()
+        if emb_table is not None:  # rows of `emb_table` are the token embeddings themselves (UpDownCell.forward API)
+            p.emb = emb_table.data_ptr()
+            p.ld_emb = emb_table.stride(0)
+        self.lib.ssc_decode_step(C.byref(self._cfg), C.byref(p), C.byref(desc), _lib.ptr(self._ws), self._ws.numel() * 4,
+                                 _lib.stream_ptr())
+        out_states = dict(st)
+        out_states.update(new)
+        return lp, out_states, alpha
+
+
+    def _step_from_embedding(self, ctx, token_embedding, states, sentiment, eps):
+        G = token_embedding.size(0)
+        table = token_embedding.to(self.device, torch.float32).contiguous()
+        ids = torch.arange(G, dtype=torch.int64, device=self.device)
+        return self.step(ctx, ids, states, sentiment, eps, want_log_probs=False, emb_table=table)
+
+
+DecodeEngine.step_from_embedding = DecodeEngine._step_from_embedding
+
+
+def cbs_search(start_predictions: torch.Tensor, start_state, step: Callable, fsm: torch.Tensor, end_index: int,
+               max_steps: int, beam_size: int, per_node_beam_size: int, early_stop: bool = True):
+    """Constrained beam search with on-device bookkeeping (ssc_beam_first / ssc_beam_step / ssc_gather_rows /
+    ssc_beam_backtrace).  `step(tokens (G,), state) -> (log_probs (G,V), state, ...)` as in cbs.py:127,170.
+    Returns (predictions (B,S,beam,steps) int64, log_probs (B,S,beam))."""
+    lib = _lib.load()
+    st = _lib.stream_ptr
+    B, S, _, V = fsm.shape
+    dev = start_predictions.device
+    assert fsm.is_cuda and fsm.dtype == torch.uint8
+    fsm = fsm.contiguous()
+    SB = S * beam_size
+    preds = torch.empty(max_steps, B, SB, dtype=torch.int64, device=dev)
+    backs = torch.empty(max(max_steps - 1, 1), B, SB, dtype=torch.int64, device=dev)
+    last_lp = torch.empty(B, S, beam_size, dtype=torch.float32, device=dev)
+    out = step(start_predictions, start_state)
+    lp0, state = out[0], out[1]
+    lp0 = lp0.contiguous()
+    assert lp0.shape == (B, V), lp0.shape
+    lib.ssc_beam_first(_lib.ptr(lp0), lp0.stride(0), _lib.ptr(fsm), B, S, V, beam_size, _lib.ptr(preds[0]), _lib.ptr(last_lp),
+                       st())
+    # enlarge states to (B*S*beam, *) batch-major (cbs.py:10-17,152-155)
+    def enlarge(t):
+        _, *rest = t.shape
+        return t.view(B, 1, 1, *rest).expand(B, S, beam_size, *rest).reshape(-1, *rest).contiguous()
+
+    state = {k: enlarge(v) for k, v in state.items()}
+    sval = torch.empty(B * S * SB * per_node_beam_size, dtype=torch.float32, device=dev)
+    sidx = torch.empty(B * S * SB * per_node_beam_size, dtype=torch.int64, device=dev)
+    nsteps = 1
+    for t in range(1, max_steps):
+        last = preds[t - 1].reshape(B * SB)
+        if early_stop and bool((last == end_index).all()):  # cbs.py:167 (host sync, as in the reference)
+            break
+        out = step(last, state)
+        lp, state = out[0].contiguous(), out[1]
+        new_lp = torch.empty_like(last_lp)
+        lib.ssc_beam_step(_lib.ptr(lp), lp.stride(0), _lib.ptr(fsm), _lib.ptr(last), _lib.ptr(last_lp), B, S, V, beam_size,
+                          per_node_beam_size, end_index, _lib.ptr(preds[t]), _lib.ptr(new_lp), _lib.ptr(backs[t - 1]),
+                          _lib.ptr(sval), _lib.ptr(sidx), st())
+        last_lp = new_lp
+        new_state = {}
+        for k, v in state.items():  # cbs.py:236-250
+            v2 = v.reshape(B * SB, -1).contiguous()
+            dst = torch.empty_like(v2)
+            lib.ssc_gather_rows(_lib.ptr(v2), v2.stride(0), _lib.ptr(backs[t - 1]), B, SB, v2.size(1), _lib.ptr(dst), st())
+            new_state[k] = dst.view_as(v)
+        state = new_state
+        nsteps += 1
+    allp = torch.empty(B, SB, nsteps, dtype=torch.int64, device=dev)
+    lib.ssc_beam_backtrace(_lib.ptr(preds), _lib.ptr(backs), nsteps, B, SB, _lib.ptr(allp), st())
+    return allp.view(B, S, beam_size, nsteps), last_lp

@@ -172,6 +172,20 @@ class TrainEngine:
         self.decoder_names = [n for n in names if n.startswith(P_DEC)]
         self.frozen_names = ["_embedding_layer.weight"] if dims.tied else []
         self.steps_done = 0
+        self.fwd_version = 0
+
+    def adopt(self, named: "Dict[str, torch.nn.Parameter]"):
+        """Re-home nn.Parameters into the flat store (copy once, then `param.data` IS the view).  Cheap when they
+        already live there; re-adopts after .to()/.cuda() or any external re-binding of param.data."""
+        for name, p in named.items():
+            view = self.params.views[name]
+            if p.data_ptr() != view.data_ptr() or p.stride() != view.stride() or p.device != view.device:
+                with torch.no_grad():
+                    view.copy_(p.data.to(self.device, torch.float32))
+                p.data = view
+
+    def param_version(self):
+        return (self.params.flat._version, self.steps_done)
 
     # ---- parameters --------------------------------------------------------------------------------
     def load_state_dict(self, sd: "Dict[str, torch.Tensor]"):
@@ -220,6 +234,7 @@ class TrainEngine:
         self.lib.ssc_train_fwd(C.byref(self._cfg), C.byref(p), C.byref(bt), _lib.ptr(ws), ws.numel() * 4, _lib.ptr(loss),
                                _lib.ptr(kld), _lib.stream_ptr())
         self._keep = (bt, feats, caps, sent, eps)
+        self.fwd_version += 1
         return loss, kld
 
     def backward(self, gl, gk, skip: Sequence[str] = ()):

@@ -102,6 +102,8 @@ SYMBOLS = {
     "ssc_arch": (C.c_char_p, []),
     "ssc_gemm": (_i, [C.POINTER(GemmDesc), vp]),
     "ssc_gemm_auto_splits": (_i, [_i, _i, _i]),
+    "ssc_prof_enable": (_i, [_i]),
+    "ssc_prof_collect": (_i, [vp, _i]),
     "ssc_feat_prep": (_i, [vp, _i, _i, _i, vp, vp, vp]),
     "ssc_prep_tokens": (_i, [vp, _i, _i, _i, _i, vp, vp, vp, vp]),
     "ssc_embed_gather": (_i, [vp, _i, vp, _i, _i, vp, _i, vp]),
@@ -134,6 +136,7 @@ SYMBOLS = {
     "ssc_beam_first": (_i, [vp, _i, vp, _i, _i, _i, _i, vp, vp, vp]),
     "ssc_beam_step": (_i, [vp, _i, vp, vp, vp, _i, _i, _i, _i, _i, _i, vp, vp, vp, vp, vp, vp]),
     "ssc_gather_rows": (_i, [vp, _i, vp, _i, _i, _i, vp, vp]),
+    "ssc_beam_backtrace": (_i, [vp, vp, _i, _i, _i, vp, vp]),
 }
 
 _lib = None
@@ -152,7 +155,7 @@ class _Lib:
         raw = self.__dict__.get("_raw_" + name)
         if raw is None:
             raise AttributeError(name)
-        if raw.restype is not C.c_int or name in ("ssc_version", "ssc_last_hip_error", "ssc_gemm_auto_splits"):
+        if raw.restype is not C.c_int or name in ("ssc_version", "ssc_last_hip_error", "ssc_gemm_auto_splits", "ssc_prof_collect"):
             return raw
 
         def checked(*a):

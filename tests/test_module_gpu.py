@@ -1,0 +1,132 @@
+"""GPU: the drop-in module API (var_updown.models.UpDownCaptioner mirror) through autograd, torch.optim.SGD and
+clip_grad_norm_ exactly as var_updown/scripts/train.py:154-176 drives it, against reference goldens; the eval
+decode step against the reference's _decode_step goldens; fused clip+SGD against the same fixture."""
+import pytest
+import torch
+
+import oracle
+from goldenlib import group, load
+from gpuutil import dev, engine_from, maxdiff
+from ssc_runtime.vocab import Vocabulary
+from var_updown.models import UpDownCaptioner
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def build_model(cfg: "oracle.OracleConfig", params=None, beam=5, cls=UpDownCaptioner):
+    m = cls(Vocabulary.synthetic(cfg.vocab_size), cfg.image_feature_size, cfg.embedding_size, cfg.hidden_size,
+            cfg.attention_projection_size, max_caption_length=cfg.max_caption_length, beam_size=beam,
+            use_cbs=cfg.tied, z_space=cfg.z_space, prior_std=cfg.prior_std, simple_vae=cfg.simple_vae,
+            latent_embedding="glove", sentiment_vae=cfg.sentiment_vae, senti_prior_multip=cfg.senti_prior_multip,
+            device=torch.device("cuda"))
+    if params is not None:
+        sd = dict(params)
+        if cfg.tied:
+            sd["_output_layer.weight"] = sd["_embedding_layer.weight"]
+        m.load_state_dict(sd)
+    return m.cuda()
+
+
+def test_state_dict_keys_and_seeded_init_match_reference():
+    d, cfgd = load("g1_train_sv1")
+    cfg = oracle.OracleConfig(**cfgd)
+    torch.manual_seed(2)  # the fixture's reference model was built under manual_seed(2)
+    m = build_model(cfg)
+    sd = m.state_dict()
+    ref = group(d, "param/")
+    assert set(sd.keys()) == set(ref.keys())
+    for k, v in ref.items():
+        assert torch.equal(sd[k].cpu(), v), k
+    assert hasattr(m._updown_cell, "_language_lstm_cell_decoder")
+
+
+def test_dropin_training_loop_matches_reference():
+    d, cfgd = load("g6_sgd")
+    cfg = oracle.OracleConfig(**cfgd)
+    m = build_model(cfg, group(d, "param/"))
+    m.train()
+    ins = group(d, "in/")
+    feats, caps, senti = dev(ins["feats"]), dev(ins["caps"]), dev(ins["sentiment"])
+    opt = torch.optim.SGD(m.parameters(), lr=0.015, momentum=0.9, weight_decay=0.001)
+    for it in (1, 2):
+        for p in m._updown_cell._language_lstm_cell_decoder.parameters():  # train.py:156-161
+            p.requires_grad = it != 1
+        opt.zero_grad()
+        m._eps_override = ins["eps"]
+        out = m(feats, None, None, caps, senti)  # positional, as train.py:167
+        loss = out["loss"].mean() + out["kld"].mean() / 750.0
+        loss.backward()
+        norm = torch.nn.utils.clip_grad_norm_(m.parameters(), 0.5)
+        opt.step()
+        assert abs(float(norm) - float(d[f"out/norm{it}"])) < 1e-4
+        sd = m.state_dict()
+        for k, v in group(d, f"after{it}/").items():
+            assert maxdiff(sd[k], v) < 1e-5, (it, k)
+
+
+def test_fused_clip_sgd_matches_reference():
+    d, cfgd = load("g6_sgd")
+    cfg = oracle.OracleConfig(**cfgd)
+    eng = engine_from(cfg, group(d, "param/"))
+    ins = group(d, "in/")
+    args = (dev(ins["feats"]), dev(ins["caps"]), dev(ins["sentiment"]), dev(ins["eps"]))
+    for it in (1, 2):
+        eng.train_step(*args, lr=0.015, kld_weight=750.0, momentum=0.9, weight_decay=0.001, max_norm=0.5,
+                       decoder_frozen=(it == 1))
+        sd = eng.state_dict()
+        for k, v in group(d, f"after{it}/").items():
+            assert maxdiff(sd[k], v) < 1e-5, (it, k)
+
+
+@pytest.mark.parametrize("name", ["g5_decode_sv1", "g5b_decode_sv0"])
+def test_eval_decode_step_matches_reference(name):
+    d, cfgd = load(name)
+    cfg = oracle.OracleConfig(**cfgd)
+    m = build_model(cfg, group(d, "param/"))
+    m.eval()
+    ins = group(d, "in/")
+    feats, senti = dev(ins["feats"]), dev(ins["sentiment"])
+    m._eps_override = [ins["eps0"], ins["eps1"]]
+    lp0, st0, pm, plv, al0 = m._decode_step(feats, None, dev(ins["tok0"]), None, sentiment=senti)
+    assert maxdiff(lp0, torch.from_numpy(d["out/lp0"])) < TOL
+    assert maxdiff(al0, torch.from_numpy(d["out/alpha0"])) < TOL
+    for k, v in group(d, "out/st0/").items():
+        assert maxdiff(st0[k], v) < TOL, k
+    st_in = {k: dev(v) for k, v in group(d, "in/st1/").items()}
+    lp1, st1, _, _, al1 = m._decode_step(feats, None, dev(ins["tok1"]), st_in, sentiment=senti)
+    assert maxdiff(lp1, torch.from_numpy(d["out/lp1"])) < TOL
+    assert maxdiff(al1, torch.from_numpy(d["out/alpha1"])) < TOL
+    for k, v in group(d, "out/st1/").items():
+        assert maxdiff(st1[k], v) < TOL, k
+    assert pm.shape == (ins["tok0"].numel(), cfg.z_space) and plv.shape == pm.shape
+
+
+def test_tied_module_and_cpu_call_fails_loudly():
+    d, cfgd = load("g3_train_tied")
+    cfg = oracle.OracleConfig(**cfgd)
+    params = group(d, "param/")
+
+    class Tied(UpDownCaptioner):
+        def _initialize_glove(self):
+            return params["_embedding_layer.weight"].clone()
+
+    m = build_model(cfg, params, cls=Tied)
+    assert m._output_layer.weight is m._embedding_layer.weight and not m._embedding_layer.weight.requires_grad
+    m.train()
+    ins = group(d, "in/")
+    m._eps_override = ins["eps"]
+    out = m(dev(ins["feats"]), None, None, dev(ins["caps"]), dev(ins["sentiment"]))
+    assert maxdiff(out["loss"], torch.from_numpy(d["out/loss"])) < TOL
+    (out["loss"].mean() + out["kld"].mean() / 750.0).backward()
+    for k, g in group(d, "grad/").items():
+        if k.startswith("_output_layer") or k.startswith("_embedding"):
+            continue
+        assert maxdiff(dict(m.named_parameters())[k].grad, g) < TOL, k
+    assert m._embedding_layer.weight.grad is None
+    cpu_model = build_model.__wrapped__(cfg) if hasattr(build_model, "__wrapped__") else None
+    m2 = Tied(Vocabulary.synthetic(cfg.vocab_size), cfg.image_feature_size, cfg.embedding_size, cfg.hidden_size,
+              cfg.attention_projection_size, max_caption_length=cfg.max_caption_length, use_cbs=True,
+              z_space=cfg.z_space, prior_std=1.0, latent_embedding="glove", sentiment_vae=1, device="cpu")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m2(ins["feats"], None, None, ins["caps"], ins["sentiment"])
