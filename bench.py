@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", type=int, default=C2["B"])
+    ap.add_argument("--dump-gemm", default="", help="write the per-shape GEMM timing table (roofline leg) to this file")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -180,6 +181,18 @@ def main():
             a["flops"] += 2.0 * M * N * K
             a["bytes"] += 4.0 * (K * (M + N) + M * N * splits)
             a["n"] += 1
+        if args.dump_gemm:
+            shapes = {}
+            for kind, M, N, K, splits, msr in rec.tolist():
+                e = shapes.setdefault((int(kind), int(M), int(N), int(K), int(splits)), [0, 0.0])
+                e[0] += 1
+                e[1] += msr
+            with open(args.dump_gemm, "w") as f:
+                f.write("kind,M,N,K,splits,calls_per_step,avg_us,total_ms_per_step,TFLOPs,algGBps\n")
+                for (kind, M, N, K, sp), (cnt, tot) in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
+                    us = tot / cnt * 1e3
+                    f.write(f"{names[kind][12:14]},{M},{N},{K},{sp},{cnt / nprof:.1f},{us:.1f},{tot / nprof:.3f},"
+                            f"{2.0 * M * N * K / us / 1e6:.1f},{4.0 * (K * (M + N) + M * N * sp) / us / 1e3:.0f}\n")
         dom = max(agg, key=lambda k: agg[k]["ms"])
         d = agg[dom]
         tf = d["flops"] / (d["ms"] * 1e-3) / 1e12

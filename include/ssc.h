@@ -210,6 +210,12 @@ int ssc_log_softmax(const float* logits, int ldl, int rows, int V, float* out, i
 /* out[n] (+)= sum_rows wrow[row]*X[row,n]  (bias grads: wrow=0 -> weights 1; sentiment column grads) */
 int ssc_colsum(const float* X, int ldx, int rows, int N, const float* wrow, float* out, int out_stride, int accumulate,
                void* stream);
+/* same, two-stage for many rows: scratch >= 16*N floats; out2 (optional, stride 1) receives a second copy
+ * (nn.LSTMCell's bias_ih / bias_hh gradients are the same vector). */
+int ssc_colsum2(const float* X, int ldx, int rows, int N, const float* wrow, float* out, int out_stride, float* out2,
+                int accumulate, float* scratch, void* stream);
+/* dst[i] = src[i*stride]: one weight column made contiguous (the rank-1 sentiment column, updown_cell.py:181-184) */
+int ssc_copy_strided(const float* src, size_t stride, int n, float* dst, void* stream);
 /* y = tanh(x + bias) (tied output projection, updown_captioner.py:115-117) and its backward dy*(1-y^2) */
 int ssc_bias_tanh(float* x, int ldx, int rows, int N, const float* bias, void* stream);
 int ssc_tanh_bwd(float* dy, int lddy, const float* y, int ldy, int rows, int N, void* stream);

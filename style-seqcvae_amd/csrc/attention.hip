@@ -149,36 +149,85 @@ __global__ __launch_bounds__(256) void attn_dalpha_kernel(const float* __restric
 }
 
 // dl = alpha * (dalpha - sum alpha*dalpha)   (masked rows have alpha == 0; the 1e-13 term is inert in fp32,
-// see DESIGN.md "attention backward").  Then per (g, a): u = tanh(q+pv); dpre = dl*wa*(1-u^2).
-__global__ __launch_bounds__(64) void attn_bwd_apply_kernel(const float* __restrict__ q, int ldq,
-                                                            const float* __restrict__ pv, const float* __restrict__ wa,
-                                                            const float* __restrict__ alpha,
-                                                            const float* __restrict__ dalpha, int G, int R, int A,
-                                                            float* __restrict__ dq, int lddq, float* __restrict__ dpv_acc,
-                                                            float* __restrict__ dwa_acc) {
+// see DESIGN.md "attention backward").  Then per (g, r, a): u = tanh(q+pv); dpre = dl*wa*(1-u^2);
+// dpv_acc += dpre; dq[g,a] = sum_r dpre; dwa_acc[g,a] += sum_r dl*u.
+// One 256-thread workgroup per (row g, 256-wide slice of A): wave w takes regions r = w, w+4, ... with its 64 lanes
+// on 4 consecutive a each (16 B/lane, coalesced), the four waves' partial sums meet in LDS.
+__global__ __launch_bounds__(256) void attn_bwd_apply_kernel(const float* __restrict__ q, int ldq,
+                                                             const float* __restrict__ pv, const float* __restrict__ wa,
+                                                             const float* __restrict__ alpha,
+                                                             const float* __restrict__ dalpha, int G, int R, int A,
+                                                             float* __restrict__ dq, int lddq, float* __restrict__ dpv_acc,
+                                                             float* __restrict__ dwa_acc) {
   __shared__ float sdl[64 * MAXR_LANE];
-  int g = blockIdx.y, chunk = blockIdx.x, lane = threadIdx.x;
+  __shared__ float red[2][4][256];
+  const int g = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // every wave derives c = sum_r alpha*dalpha redundantly (R is small), wave 0 publishes dl
   float c = 0.f;
   for (int r = lane; r < R; r += 64) c += alpha[(size_t)g * R + r] * dalpha[(size_t)g * R + r];
   c = ssc_wave_sum(c);
-  for (int r = lane; r < R; r += 64) sdl[r] = alpha[(size_t)g * R + r] * (dalpha[(size_t)g * R + r] - c);
+  if (wave == 0)
+    for (int r = lane; r < R; r += 64) sdl[r] = alpha[(size_t)g * R + r] * (dalpha[(size_t)g * R + r] - c);
   __syncthreads();
-  for (int k = 0; k < 4; ++k) {
-    int a = chunk * 256 + k * 64 + lane;
-    if (a >= A) continue;
-    float qa = q[(size_t)g * ldq + a], w = wa[a];
-    float dqa = 0.f, dw = 0.f;
-    for (int r = 0; r < R; ++r) {
-      size_t off = ((size_t)g * R + r) * A + a;
-      float u = tanhf(qa + pv[off]);
-      float dl = sdl[r];
-      float dpre = dl * w * (1.f - u * u);
-      dpv_acc[off] += dpre;
-      dqa += dpre;
-      dw += dl * u;
+  const int a0 = chunk * 256 + lane * 4;
+  float dqa[4] = {0.f, 0.f, 0.f, 0.f}, dw[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool vec = ((A & 3) == 0) && ((ldq & 3) == 0) && ssc_aligned16_dev(q) && ssc_aligned16_dev(pv) &&
+                   ssc_aligned16_dev(wa) && ssc_aligned16_dev(dpv_acc);
+  if (vec) {
+    if (a0 < A) {
+      const float4 qv = *reinterpret_cast<const float4*>(q + (size_t)g * ldq + a0);
+      const float4 wv = *reinterpret_cast<const float4*>(wa + a0);
+      const float qa[4] = {qv.x, qv.y, qv.z, qv.w}, ww[4] = {wv.x, wv.y, wv.z, wv.w};
+      for (int r = wave; r < R; r += 4) {
+        const size_t off = ((size_t)g * R + r) * A + a0;
+        const float4 p4 = *reinterpret_cast<const float4*>(pv + off);
+        float4 acc = *reinterpret_cast<const float4*>(dpv_acc + off);
+        const float pp[4] = {p4.x, p4.y, p4.z, p4.w};
+        float dp[4];
+        const float dl = sdl[r];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float u = tanhf(qa[k] + pp[k]);
+          dp[k] = dl * ww[k] * (1.f - u * u);
+          dqa[k] += dp[k];
+          dw[k] += dl * u;
+        }
+        acc.x += dp[0]; acc.y += dp[1]; acc.z += dp[2]; acc.w += dp[3];
+        *reinterpret_cast<float4*>(dpv_acc + off) = acc;
+      }
     }
-    dq[(size_t)g * lddq + a] = dqa;
-    dwa_acc[(size_t)g * A + a] += dw;
+  } else {
+    for (int k = 0; k < 4; ++k) {
+      int a = chunk * 256 + k * 64 + lane;  // scalar path: lane-contiguous a
+      if (a >= A) continue;
+      float qa = q[(size_t)g * ldq + a], w = wa[a];
+      for (int r = wave; r < R; r += 4) {
+        size_t off = ((size_t)g * R + r) * A + a;
+        float u = tanhf(qa + pv[off]);
+        float dl = sdl[r];
+        float dpre = dl * w * (1.f - u * u);
+        dpv_acc[off] += dpre;
+        dqa[k] += dpre;
+        dw[k] += dl * u;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    red[0][wave][lane * 4 + k] = dqa[k];
+    red[1][wave][lane * 4 + k] = dw[k];
+  }
+  __syncthreads();
+  // thread tid finalises slot tid of the 256-wide slice; slot -> a depends on the path's lane mapping
+  {
+    float s0 = red[0][0][tid] + red[0][1][tid] + red[0][2][tid] + red[0][3][tid];
+    float s1 = red[1][0][tid] + red[1][1][tid] + red[1][2][tid] + red[1][3][tid];
+    int l = tid >> 2, k = tid & 3;
+    int a = vec ? (chunk * 256 + l * 4 + k) : (chunk * 256 + k * 64 + l);
+    if (a < A) {
+      dq[(size_t)g * lddq + a] = s0;
+      dwa_acc[(size_t)g * A + a] += s1;
+    }
   }
 }
 
@@ -213,7 +262,7 @@ extern "C" int ssc_attn_bwd(const float* datt, int lddatt, const float* q, int l
   hipLaunchKernelGGL(attn_dalpha_kernel, dim3(ssc_cdiv(G * R, 4)), dim3(256), 0, (hipStream_t)stream, datt, lddatt, feats,
                      G, R, F, scratch_dalpha);
   SSC_CHECK_LAUNCH();
-  hipLaunchKernelGGL(attn_bwd_apply_kernel, dim3(ssc_cdiv(A, 256), G), dim3(64), 0, (hipStream_t)stream, q, ldq, pv, wa,
+  hipLaunchKernelGGL(attn_bwd_apply_kernel, dim3(ssc_cdiv(A, 256), G), dim3(256), 0, (hipStream_t)stream, q, ldq, pv, wa,
                      alpha, scratch_dalpha, G, R, A, dq, lddq, dpv_acc, dwa_acc);
   SSC_CHECK_LAUNCH();
   return SSC_OK;

@@ -37,7 +37,7 @@ ImgLayout img_layout(const ssc_model_cfg* c, int nimg, int R) {
 }
 
 struct StepLayout {
-  size_t emb, q, att, z, attn_logits, proj, slabs, slab_floats, total;
+  size_t emb, q, att, z, attn_logits, proj, wcol, slabs, slab_floats, total;
   int Ep, Ap, Fp, Zp;
 };
 StepLayout step_layout(const ssc_model_cfg* c, int G, int R) {
@@ -50,6 +50,7 @@ StepLayout step_layout(const ssc_model_cfg* c, int G, int R) {
   l.z = o; o += r64((size_t)G * l.Zp);
   l.attn_logits = o; o += r64((size_t)G * R);
   l.proj = o; o += r64(c->tied ? (size_t)G * l.Ep : 0);
+  l.wcol = o; o += r64((size_t)4 * c->H);
   size_t skinny = (size_t)33 * G * 4 * c->H;
   size_t full = (size_t)1100 * 4096;
   l.slab_floats = skinny > full ? skinny : full;
@@ -327,7 +328,10 @@ extern "C" int ssc_decode_step(const ssc_model_cfg* cfg, const ssc_params* p, co
     f.B = G; f.H = H;
     f.slabs = slabs; f.nslab = ns; f.slab_stride = (size_t)G * H4;
     f.b_ih = p->dec_b_ih; f.b_hh = p->dec_b_hh;
-    if (S) { f.sent = d->sentiment; f.wcol = p->dec_w_ih + F + 2 * H; f.ldwcol = p->ld_dec_w_ih; }
+    if (S) {
+      SSC_TRY(ssc_copy_strided(p->dec_w_ih + F + 2 * H, p->ld_dec_w_ih, H4, W + l.wcol, st));
+      f.sent = d->sentiment; f.wcol = W + l.wcol; f.ldwcol = 1;
+    }
     f.c_prev = d->cd; f.ld_cprev = H;
     f.c_out = d->cd_out; f.ld_cout = H; f.h_out = d->hd_out; f.ld_hout = H;
     SSC_TRY(ssc_lstm_fwd(&f, st));

@@ -27,8 +27,6 @@ namespace {
 
 constexpr int BM = 64, BN = 64, BK = 32;
 constexpr int KC_LD = BK + 4;  // 36 floats: 144 B rows, 16-B aligned, conflict-free b128 reads
-constexpr int MC_LD = 64;
-constexpr int TILE_FLOATS = 64 * KC_LD;  // 2304 >= 32*64
 
 struct KSeg {
   const float* A;
@@ -49,107 +47,107 @@ struct KArgs {
   int steps_total, steps_per_split;
 };
 
-// ---- global -> register staging of one 64 x 32 operand tile (8 floats per thread) ------------------
-template <bool KC>
-__device__ __forceinline__ void load_tile(float (&r)[8], const float* __restrict__ base, int ld, int rows, int K,
-                                          int row0, int k0, int tid, bool VEC) {
-  if (KC && VEC) {
+// ---- global -> register staging of one ROWS x 32 operand tile (ROWS/8 floats per thread) --------------
+// Loads are UNCONDITIONAL: out-of-range rows / k are clamped to a valid address and (for k) zeroed with a select
+// afterwards.  No exec-masked branch surrounds a load, so hipcc keeps counted vmcnt waits and the register
+// prefetch really stays in flight (a guarded load makes it branch and wait vmcnt(0) per element).
+// Out-of-range ROWS need no zeroing: they only feed output rows / columns the epilogue never stores.
+// VEC (16 B/lane) requires: base 16-B aligned, ld % 4 == 0 and K % 4 == 0 (KC) resp. rows % 4 == 0 (MC), so a
+// float4 is never partially out of range.
+// The k-range select is DEFERRED to store_tile (bit u of the returned mask = element/vector u is in range): consuming
+// a loaded value right after its load would force the wait to the load site and serialise the prefetch.
+template <bool KC, int ROWS, bool VEC>
+__device__ __forceinline__ unsigned load_tile(float (&r)[ROWS / 8], const float* __restrict__ base, int ld, int rows, int K,
+                                              int row0, int k0, int tid) {
+  constexpr int NV = ROWS / 32;  // float4 per thread
+  unsigned okm = 0;
+  if constexpr (KC && VEC) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < NV; ++u) {
       int idx = tid + 256 * u;
       int row = idx >> 3, kq = idx & 7;
-      int grow = row0 + row, k = k0 + 4 * kq;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (grow < rows) {
-        const float* p = base + (size_t)grow * ld + k;
-        if (k + 3 < K) {
-          v = *reinterpret_cast<const float4*>(p);
-        } else {
-          if (k < K) v.x = p[0];
-          if (k + 1 < K) v.y = p[1];
-          if (k + 2 < K) v.z = p[2];
-        }
-      }
+      int grow = min(row0 + row, rows - 1), k = k0 + 4 * kq;
+      float4 v = *reinterpret_cast<const float4*>(base + (size_t)grow * ld + min(k, K - 4));
+      okm |= (k < K ? 1u : 0u) << u;
       r[4 * u] = v.x; r[4 * u + 1] = v.y; r[4 * u + 2] = v.z; r[4 * u + 3] = v.w;
     }
-  } else if (KC && !VEC) {
+  } else if constexpr (KC && !VEC) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < 4 * NV; ++u) {
       int idx = tid + 256 * u;
       int row = idx >> 5, kk = idx & 31;
-      int grow = row0 + row, k = k0 + kk;
-      r[u] = (grow < rows && k < K) ? base[(size_t)grow * ld + k] : 0.f;
+      int grow = min(row0 + row, rows - 1), k = k0 + kk;
+      r[u] = base[(size_t)grow * ld + min(k, K - 1)];
+      okm |= (k < K ? 1u : 0u) << u;
     }
-  } else if (!KC && VEC) {
+  } else if constexpr (!KC && VEC) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < NV; ++u) {
       int idx = tid + 256 * u;
-      int kk = idx >> 4, mq = idx & 15;
-      int gk = k0 + kk, gm = row0 + 4 * mq;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (gk < K) {
-        const float* p = base + (size_t)gk * ld + gm;
-        if (gm + 3 < rows) {
-          v = *reinterpret_cast<const float4*>(p);
-        } else {
-          if (gm < rows) v.x = p[0];
-          if (gm + 1 < rows) v.y = p[1];
-          if (gm + 2 < rows) v.z = p[2];
-        }
-      }
+      int kk = idx / (ROWS / 4), mq = idx % (ROWS / 4);
+      int gk = k0 + kk, gm = min(row0 + 4 * mq, rows - 4);
+      float4 v = *reinterpret_cast<const float4*>(base + (size_t)min(gk, K - 1) * ld + gm);
+      okm |= (gk < K ? 1u : 0u) << u;
       r[4 * u] = v.x; r[4 * u + 1] = v.y; r[4 * u + 2] = v.z; r[4 * u + 3] = v.w;
     }
   } else {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < 4 * NV; ++u) {
       int idx = tid + 256 * u;
-      int kk = idx >> 6, m = idx & 63;
-      int gk = k0 + kk, gm = row0 + m;
-      r[u] = (gk < K && gm < rows) ? base[(size_t)gk * ld + gm] : 0.f;
+      int kk = idx / ROWS, m = idx % ROWS;
+      int gk = k0 + kk, gm = min(row0 + m, rows - 1);
+      r[u] = base[(size_t)min(gk, K - 1) * ld + gm];
+      okm |= (gk < K ? 1u : 0u) << u;
     }
   }
+  return okm;
 }
 
-template <bool KC>
-__device__ __forceinline__ void store_tile(float* __restrict__ s, const float (&r)[8], int tid, bool VEC) {
-  if (KC && VEC) {
+template <bool KC, int ROWS, bool VEC>
+__device__ __forceinline__ void store_tile(float* __restrict__ s, const float (&r)[ROWS / 8], int tid, unsigned okm) {
+  constexpr int NV = ROWS / 32;
+#define SSC_SEL(u, x) (((okm >> (u)) & 1u) ? (x) : 0.f)
+  if constexpr (KC && VEC) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < NV; ++u) {
       int idx = tid + 256 * u;
       int row = idx >> 3, kq = idx & 7;
-      *reinterpret_cast<float4*>(&s[row * KC_LD + 4 * kq]) = make_float4(r[4 * u], r[4 * u + 1], r[4 * u + 2], r[4 * u + 3]);
+      *reinterpret_cast<float4*>(&s[row * KC_LD + 4 * kq]) =
+          make_float4(SSC_SEL(u, r[4 * u]), SSC_SEL(u, r[4 * u + 1]), SSC_SEL(u, r[4 * u + 2]), SSC_SEL(u, r[4 * u + 3]));
     }
-  } else if (KC && !VEC) {
+  } else if constexpr (KC && !VEC) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < 4 * NV; ++u) {
       int idx = tid + 256 * u;
-      s[(idx >> 5) * KC_LD + (idx & 31)] = r[u];
+      s[(idx >> 5) * KC_LD + (idx & 31)] = SSC_SEL(u, r[u]);
     }
-  } else if (!KC && VEC) {
+  } else if constexpr (!KC && VEC) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < NV; ++u) {
       int idx = tid + 256 * u;
-      int kk = idx >> 4, mq = idx & 15;
-      *reinterpret_cast<float4*>(&s[kk * MC_LD + 4 * mq]) = make_float4(r[4 * u], r[4 * u + 1], r[4 * u + 2], r[4 * u + 3]);
+      int kk = idx / (ROWS / 4), mq = idx % (ROWS / 4);
+      *reinterpret_cast<float4*>(&s[kk * ROWS + 4 * mq]) =
+          make_float4(SSC_SEL(u, r[4 * u]), SSC_SEL(u, r[4 * u + 1]), SSC_SEL(u, r[4 * u + 2]), SSC_SEL(u, r[4 * u + 3]));
     }
   } else {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < 4 * NV; ++u) {
       int idx = tid + 256 * u;
-      s[(idx >> 6) * MC_LD + (idx & 63)] = r[u];
+      s[(idx / ROWS) * ROWS + (idx % ROWS)] = SSC_SEL(u, r[u]);
     }
   }
+#undef SSC_SEL
 }
 
 // fragment of 4 k-values (k = chunk*8 + 4*half + j) for tile row/col `rc`
-template <bool KC>
+template <bool KC, int ROWS>
 __device__ __forceinline__ void read_frag(float (&f)[4], const float* __restrict__ s, int rc, int chunk, int half) {
   if constexpr (KC) {
     float4 v = *reinterpret_cast<const float4*>(&s[rc * KC_LD + chunk * 8 + 4 * half]);
     f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
   } else {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) f[j] = s[(chunk * 8 + 4 * half + j) * MC_LD + rc];
+    for (int j = 0; j < 4; ++j) f[j] = s[(chunk * 8 + 4 * half + j) * ROWS + rc];
   }
 }
 
@@ -164,81 +162,259 @@ __device__ __forceinline__ void locate(const KArgs& a, int step, int& seg, int& 
   k0 = rem * BK;
 }
 
-template <bool A_KC, bool B_KC>
+// Walks the k-steps of the segment list one step at a time, keeping the current segment's descriptor in scalar
+// registers: the steady-state loop then issues no scalar (kernarg) loads - they only happen on a segment change.
+struct Cursor {
+  const float* A;
+  const float* B;
+  int lda, ldb, K, k0, seg, left;  // left = k-steps remaining in this segment after the current one
+  __device__ __forceinline__ void fetch(const KArgs& g) {
+    A = g.seg[seg].A; B = g.seg[seg].B; lda = g.seg[seg].lda; ldb = g.seg[seg].ldb; K = g.seg[seg].K;
+  }
+  __device__ __forceinline__ void init(const KArgs& g, int step) {
+    locate(g, step, seg, k0);
+    fetch(g);
+    left = g.seg[seg].nsteps - 1 - k0 / BK;
+  }
+  // move to the next k-step unless `stay` (past the end of this workgroup's range: keep re-reading the last tile)
+  __device__ __forceinline__ void advance(const KArgs& g, bool stay) {
+    if (stay) return;
+    if (left > 0) {
+      --left;
+      k0 += BK;
+    } else {
+      ++seg;
+      fetch(g);
+      k0 = 0;
+      left = g.seg[seg].nsteps - 1;
+    }
+  }
+};
+
+// One staged operand-pair (A tile + B tile of one k-step) held in registers between its global load and its LDS store.
+// Generic (4 B/lane) form: compiler-managed loads.
+template <bool A_KC, bool B_KC, int RA, int RB, bool VEC>
+struct Stage {
+  static constexpr int NLOADS = 0;  // not hand-counted
+  float a[RA / 8], b[RB / 8];
+  unsigned oka, okb;
+  __device__ __forceinline__ void load(const KArgs& g, const Cursor& c, int m0, int n0, int tid) {
+    oka = load_tile<A_KC, RA, VEC>(a, c.A, c.lda, g.M, c.K, m0, c.k0, tid);
+    okb = load_tile<B_KC, RB, VEC>(b, c.B, c.ldb, g.N, c.K, n0, c.k0, tid);
+  }
+  template <int YOUNGER>
+  __device__ __forceinline__ void wait() {}
+  __device__ __forceinline__ void store(float* As, float* Bs, int tid) const {
+    store_tile<A_KC, RA, VEC>(As, a, tid, oka);
+    store_tile<B_KC, RB, VEC>(Bs, b, tid, okb);
+  }
+};
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// 16 B/lane form: the loads are inline asm (global_load_dwordx4) and the waits are hand-counted.  hipcc's own
+// waitcnt insertion turned the register prefetch into load -> vmcnt(0) -> use (conservative merges at the loop's
+// joins, and a register copy scheduled right behind the loads); with asm loads nothing is consumed before
+// wait<YOUNGER>() - `s_waitcnt vmcnt(YOUNGER)` leaves exactly the younger stage's loads in flight - and the
+// "+v" operands pin every use of the staged registers behind that wait (cdna_hip_programming.md §5.7).
+// All loads are unconditional (clamped addresses), so the counts are static.
+template <bool A_KC, bool B_KC, int RA, int RB>
+struct Stage<A_KC, B_KC, RA, RB, true> {
+  static constexpr int NVA = RA / 32, NVB = RB / 32;
+  static constexpr int NLOADS = NVA + NVB;
+  f32x4 a[NVA], b[NVB];
+  unsigned oka, okb;
+
+  template <bool KC, int ROWS, int NV>
+  static __device__ __forceinline__ unsigned issue(f32x4 (&r)[NV], const float* __restrict__ base, int ld, int rows, int K,
+                                                   int row0, int k0, int tid) {
+    unsigned okm = 0;
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      int idx = tid + 256 * u;
+      const float* p;
+      if constexpr (KC) {
+        int row = idx >> 3, kq = idx & 7;
+        int grow = min(row0 + row, rows - 1), k = k0 + 4 * kq;
+        p = base + (size_t)grow * ld + min(k, K - 4);
+        okm |= (k < K ? 1u : 0u) << u;
+      } else {
+        int kk = idx / (ROWS / 4), mq = idx % (ROWS / 4);
+        int gk = k0 + kk, gm = min(row0 + 4 * mq, rows - 4);
+        p = base + (size_t)min(gk, K - 1) * ld + gm;
+        okm |= (gk < K ? 1u : 0u) << u;
+      }
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(r[u]) : "v"(p) : "memory");
+    }
+    return okm;
+  }
+
+  __device__ __forceinline__ void load(const KArgs& g, const Cursor& c, int m0, int n0, int tid) {
+    oka = issue<A_KC, RA, NVA>(a, c.A, c.lda, g.M, c.K, m0, c.k0, tid);
+    okb = issue<B_KC, RB, NVB>(b, c.B, c.ldb, g.N, c.K, n0, c.k0, tid);
+  }
+
+  template <int YOUNGER>
+  __device__ __forceinline__ void wait() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER) : "memory");
+    if constexpr (NVA == 2 && NVB == 2) {
+      asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1])::"memory");
+    } else {
+      static_assert(NVA == 4 && NVB == 4, "unsupported tile");
+      asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3])::"memory");
+    }
+  }
+
+  template <bool KC, int ROWS, int NV>
+  static __device__ __forceinline__ void put(float* __restrict__ s, const f32x4 (&r)[NV], int tid, unsigned okm) {
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      int idx = tid + 256 * u;
+      const bool ok = (okm >> u) & 1u;
+      float4 v = make_float4(ok ? r[u][0] : 0.f, ok ? r[u][1] : 0.f, ok ? r[u][2] : 0.f, ok ? r[u][3] : 0.f);
+      if constexpr (KC) {
+        int row = idx >> 3, kq = idx & 7;
+        *reinterpret_cast<float4*>(&s[row * KC_LD + 4 * kq]) = v;
+      } else {
+        int kk = idx / (ROWS / 4), mq = idx % (ROWS / 4);
+        *reinterpret_cast<float4*>(&s[kk * ROWS + 4 * mq]) = v;
+      }
+    }
+  }
+
+  __device__ __forceinline__ void store(float* As, float* Bs, int tid) const {
+    put<A_KC, RA, NVA>(As, a, tid, oka);
+    put<B_KC, RB, NVB>(Bs, b, tid, okb);
+  }
+};
+
+// WM x WN MFMA tiles (32x32 each) per wave; block tile (64*WM) x (64*WN); PF = k-steps prefetched in registers.
+template <bool A_KC, bool B_KC, int WM, int WN, int PF, bool VEC>
 __global__ __launch_bounds__(256) void gemm_kernel(const KArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[4 * TILE_FLOATS];  // As[2], Bs[2]
+  constexpr int RA = 64 * WM, RB = 64 * WN;
+  constexpr int TA = RA * KC_LD, TB = RB * KC_LD;  // floats per LDS buffer (KC image is the larger one)
+  __shared__ __attribute__((aligned(16))) float lds[2 * TA + 2 * TB];
   float* As = lds;
-  float* Bs = lds + 2 * TILE_FLOATS;
+  float* Bs = lds + 2 * TA;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int half = lane >> 5, l31 = lane & 31;
-  const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM, z = blockIdx.z;
+  const int n0 = blockIdx.x * RB, m0 = blockIdx.y * RA, z = blockIdx.z;
 
   const int s_lo = z * a.steps_per_split;
   int s_hi = s_lo + a.steps_per_split;
   if (s_hi > a.steps_total) s_hi = a.steps_total;
 
-  f32x16 acc;
+  f32x16 acc[WM][WN];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < WN; ++ni)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mi][ni][i] = 0.f;
 
-  float ra[8], rb[8];
-  bool va = false, vb = false;
+  typedef Stage<A_KC, B_KC, RA, RB, VEC> StageT;
+  constexpr int NL = StageT::NLOADS;
+  StageT st0, st1;
+  const int s_last = s_hi - 1;
+  // prologue: tile s_lo -> LDS[0]; tiles s_lo+1 (and s_lo+2 when PF == 2) stay in flight in registers.  Loads are
+  // unconditional - a step index past the end is clamped and re-reads the last tile, which is never stored.
+  Cursor cur;
+  int s_ld = s_lo;  // step the cursor points at (the newest tile requested)
   if (s_lo < s_hi) {
-    int sg, k0;
-    locate(a, s_lo, sg, k0);
-    va = a.seg[sg].avec != 0;
-    vb = a.seg[sg].bvec != 0;
-    load_tile<A_KC>(ra, a.seg[sg].A, a.seg[sg].lda, a.M, a.seg[sg].K, m0, k0, tid, va);
-    load_tile<B_KC>(rb, a.seg[sg].B, a.seg[sg].ldb, a.N, a.seg[sg].K, n0, k0, tid, vb);
-    store_tile<A_KC>(As, ra, tid, va);
-    store_tile<B_KC>(Bs, rb, tid, vb);
+    cur.init(a, s_lo);
+    st0.load(a, cur, m0, n0, tid);
+    st0.template wait<0>();
+    st0.store(As, Bs, tid);
+    cur.advance(a, s_ld >= s_last); s_ld = min(s_ld + 1, s_last);
+    st0.load(a, cur, m0, n0, tid);
+    if constexpr (PF == 2) {
+      cur.advance(a, s_ld >= s_last); s_ld = min(s_ld + 1, s_last);
+      st1.load(a, cur, m0, n0, tid);
+    }
   }
   __syncthreads();
 
-  for (int s = s_lo; s < s_hi; ++s) {
-    const int cur = (s - s_lo) & 1;
-    const bool more = (s + 1) < s_hi;
-    if (more) {
-      int sg, k0;
-      locate(a, s + 1, sg, k0);
-      va = a.seg[sg].avec != 0;
-      vb = a.seg[sg].bvec != 0;
-      load_tile<A_KC>(ra, a.seg[sg].A, a.seg[sg].lda, a.M, a.seg[sg].K, m0, k0, tid, va);
-      load_tile<B_KC>(rb, a.seg[sg].B, a.seg[sg].ldb, a.N, a.seg[sg].K, n0, k0, tid, vb);
-    }
-    const float* as = As + cur * TILE_FLOATS;
-    const float* bs = Bs + cur * TILE_FLOATS;
+  // All fragment reads of a k-step are issued up front when registers allow (one exposed LDS latency per step
+  // instead of one per 8-wide chunk); the 2x2 wave tile reads chunk by chunk to stay inside the register budget.
+  auto compute = [&](int buf) {
+    const float* as = As + buf * TA;
+    const float* bs = Bs + buf * TB;
+    constexpr int CH = (WM * WN == 1) ? 4 : 1;  // chunks fetched per batch
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      float fa[4], fb[4];
-      read_frag<A_KC>(fa, as, wm * 32 + l31, c, half);
-      read_frag<B_KC>(fb, bs, wn * 32 + l31, c, half);
+    for (int c0 = 0; c0 < 4; c0 += CH) {
+      float fa[CH][WM][4], fb[CH][WN][4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j], fb[j], acc, 0, 0, 0);
+      for (int c = 0; c < CH; ++c) {
+#pragma unroll
+        for (int mi = 0; mi < WM; ++mi) read_frag<A_KC, RA>(fa[c][mi], as, (wm * WM + mi) * 32 + l31, c0 + c, half);
+#pragma unroll
+        for (int ni = 0; ni < WN; ++ni) read_frag<B_KC, RB>(fb[c][ni], bs, (wn * WN + ni) * 32 + l31, c0 + c, half);
+      }
+#pragma unroll
+      for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < WN; ++ni)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][mi][j], fb[c][ni][j], acc[mi][ni], 0, 0, 0);
     }
-    if (more) {
-      store_tile<A_KC>(As + (cur ^ 1) * TILE_FLOATS, ra, tid, va);
-      store_tile<B_KC>(Bs + (cur ^ 1) * TILE_FLOATS, rb, tid, vb);
-    }
-    __syncthreads();
-  }
+  };
 
-  // epilogue: acc[r] -> row (r&3) + 8*(r>>2) + 4*half, col l31 of the wave's 32x32 tile
+  // steady state: tile s is in LDS[cur]; tile s+1 sits in stage X (older loads), tile s+2 in stage Y (younger, PF == 2)
+  for (int s = s_lo; s < s_hi; s += 2) {
+    {  // even: X = st0, Y = st1
+      compute(0);
+      st0.template wait<(PF == 2) ? NL : 0>();
+      if (s + 1 < s_hi) st0.store(As + TA, Bs + TB, tid);
+      cur.advance(a, s_ld >= s_last); s_ld = min(s_ld + 1, s_last);
+      st0.load(a, cur, m0, n0, tid);
+      __syncthreads();
+    }
+    if (s + 1 < s_hi) {  // odd: X = st1 (PF == 2) or st0 (PF == 1)
+      compute(1);
+      if constexpr (PF == 2) {
+        st1.template wait<NL>();
+        if (s + 2 < s_hi) st1.store(As, Bs, tid);
+        cur.advance(a, s_ld >= s_last); s_ld = min(s_ld + 1, s_last);
+        st1.load(a, cur, m0, n0, tid);
+      } else {
+        st0.template wait<0>();
+        if (s + 2 < s_hi) st0.store(As, Bs, tid);
+        cur.advance(a, s_ld >= s_last); s_ld = min(s_ld + 1, s_last);
+        st0.load(a, cur, m0, n0, tid);
+      }
+      __syncthreads();
+    }
+  }
+  if constexpr (VEC) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the clamped tail loads
+
+  // epilogue: acc[r] -> row (r&3) + 8*(r>>2) + 4*half, col l31 of each 32x32 tile
   float* out = a.out + (size_t)z * a.slab_stride;
-  const int col = n0 + wn * 32 + l31;
-  if (col < a.N) {
+#pragma unroll
+  for (int ni = 0; ni < WN; ++ni) {
+    const int col = n0 + (wn * WN + ni) * 32 + l31;
+    if (col >= a.N) continue;
     const float bv = (a.bias != nullptr) ? a.bias[col] : 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (row < a.M) {
-        float* p = out + (size_t)row * a.ldo + col;
-        float v = acc[r] + bv;
-        if (a.accumulate) v += *p;
-        *p = v;
+    for (int mi = 0; mi < WM; ++mi) {
+      const int rbase = m0 + (wm * WM + mi) * 32 + 4 * half;
+      float old[16];
+      if (a.accumulate) {  // all 16 read-backs in flight together (clamped rows), one wait
+#pragma unroll
+        for (int r = 0; r < 16; ++r) old[r] = out[(size_t)min(rbase + (r & 3) + 8 * (r >> 2), a.M - 1) * a.ldo + col];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) old[r] = 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int row = rbase + (r & 3) + 8 * (r >> 2);
+        if (row < a.M) out[(size_t)row * a.ldo + col] = acc[mi][ni][r] + bv + old[r];
       }
     }
   }
@@ -289,20 +465,32 @@ int build_args(const ssc_gemm_desc* d, KArgs& k) {
     k.seg[i].K = s.K;
     k.seg[i].nsteps = ssc_cdiv(s.K, BK);
     k.steps_total += k.seg[i].nsteps;
-    k.seg[i].avec = (ssc_aligned16(s.A) && !(s.lda & 3)) ? 1 : 0;
-    k.seg[i].bvec = (ssc_aligned16(s.B) && !(s.ldb & 3)) ? 1 : 0;
+    k.seg[i].avec = (ssc_aligned16(s.A) && !(s.lda & 3) && !((d->a_kc ? s.K : d->M) & 3)) ? 1 : 0;
+    k.seg[i].bvec = (ssc_aligned16(s.B) && !(s.ldb & 3) && !((d->b_kc ? s.K : d->N) & 3)) ? 1 : 0;
   }
   return SSC_OK;
 }
 
+template <int WM, int WN, int PF, bool VEC>
+gemm_fn pick_layout(const ssc_gemm_desc* d) {
+  if (d->a_kc && d->b_kc) return gemm_kernel<true, true, WM, WN, PF, VEC>;
+  if (d->a_kc && !d->b_kc) return gemm_kernel<true, false, WM, WN, PF, VEC>;
+  if (!d->a_kc && !d->b_kc) return gemm_kernel<false, false, WM, WN, PF, VEC>;
+  return gemm_kernel<false, true, WM, WN, PF, VEC>;
+}
+
+// tile choice: 128x128 (2x2 MFMA tiles per wave) when both dimensions are large, else 64x64 with a deeper prefetch
+inline bool big_tile(int M, int N) { return M >= 512 && N >= 512; }
+
 int launch(const ssc_gemm_desc* d, KArgs& k, int splits, hipStream_t st) {
   k.steps_per_split = ssc_cdiv(k.steps_total, splits);
-  dim3 grid(ssc_cdiv(d->N, BN), ssc_cdiv(d->M, BM), splits);
-  gemm_fn fn;
-  if (d->a_kc && d->b_kc) fn = gemm_kernel<true, true>;
-  else if (d->a_kc && !d->b_kc) fn = gemm_kernel<true, false>;
-  else if (!d->a_kc && !d->b_kc) fn = gemm_kernel<false, false>;
-  else fn = gemm_kernel<false, true>;
+  const bool big = big_tile(d->M, d->N);
+  const int bm = big ? 128 : 64, bn = big ? 128 : 64;
+  dim3 grid(ssc_cdiv(d->N, bn), ssc_cdiv(d->M, bm), splits);
+  bool vec = true;  // every segment of both operands must allow 16 B/lane loads, else the 4 B/lane kernel runs
+  for (int i = 0; i < k.nseg; ++i) vec = vec && k.seg[i].avec && k.seg[i].bvec;
+  gemm_fn fn = big ? (vec ? pick_layout<2, 2, 1, true>(d) : pick_layout<2, 2, 1, false>(d))
+                   : (vec ? pick_layout<1, 1, 2, true>(d) : pick_layout<1, 1, 2, false>(d));
   ProfRec* rec = nullptr;
   if (g_prof_on && g_prof && g_prof_n < PROF_MAX) {
     rec = &g_prof[g_prof_n++];
@@ -321,9 +509,11 @@ int launch(const ssc_gemm_desc* d, KArgs& k, int splits, hipStream_t st) {
 }  // namespace
 
 extern "C" int ssc_gemm_auto_splits(int M, int N, int ksteps) {
-  long tiles = (long)ssc_cdiv(M, BM) * ssc_cdiv(N, BN);
-  if (tiles >= 384) return 1;
-  int s = (int)((640 + tiles - 1) / tiles);
+  const bool big = big_tile(M, N);
+  long tiles = big ? (long)ssc_cdiv(M, 128) * ssc_cdiv(N, 128) : (long)ssc_cdiv(M, BM) * ssc_cdiv(N, BN);
+  const long want = big ? 480 : 640;  // resident workgroup slots we try to fill (2 resp. 4 per CU) 
+  if (tiles >= (big ? 300 : 384)) return 1;
+  int s = (int)((want + tiles - 1) / tiles);
   int maxs = ksteps / 6;  // keep >= 6 k-steps (192 of K) per workgroup
   if (s > maxs) s = maxs;
   if (s > 32) s = 32;

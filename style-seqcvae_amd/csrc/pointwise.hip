@@ -288,27 +288,53 @@ __global__ void log_softmax_kernel(const float* __restrict__ logits, int ldl, in
 // ---------------------------------------------------------------------------------------------
 // column sums, tanh, fill
 // ---------------------------------------------------------------------------------------------
-__global__ void colsum_kernel(const float* __restrict__ X, int ldx, int rows, int N, const float* __restrict__ wrow,
-                              float* __restrict__ out, int out_stride, int accumulate) {
-  __shared__ float sh[8][33];
-  int tx = threadIdx.x, ty = threadIdx.y;
-  int n = blockIdx.x * 32 + tx;
+// column sums in two deterministic stages: stage 1 - workgroup (column slice of 256, row chunk) -> partials
+// [chunk][N] (thread per column: 1 KiB coalesced row reads); stage 2 - sum the chunks, write out (and out2).
+constexpr int COLSUM_CHUNKS = 16;
+__global__ __launch_bounds__(256) void colsum_stage1_kernel(const float* __restrict__ X, int ldx, int rows, int N,
+                                                            const float* __restrict__ wrow, float* __restrict__ part) {
+  int n = blockIdx.x * 256 + threadIdx.x;
+  int chunk = blockIdx.y;
+  int per = (rows + COLSUM_CHUNKS - 1) / COLSUM_CHUNKS;
+  int r0 = chunk * per, r1 = r0 + per < rows ? r0 + per : rows;
+  if (n >= N) return;
   float s = 0.f;
-  if (n < N) {
-    for (int r = ty; r < rows; r += 8) {
-      float x = X[(size_t)r * ldx + n];
-      s += wrow ? wrow[r] * x : x;
-    }
+  for (int r = r0; r < r1; ++r) {
+    float x = X[(size_t)r * ldx + n];
+    s += wrow ? wrow[r] * x : x;
   }
-  sh[ty][tx] = s;
-  __syncthreads();
-  if (ty == 0 && n < N) {
-    float t = 0.f;
+  part[(size_t)chunk * N + n] = s;
+}
+__global__ __launch_bounds__(256) void colsum_stage2_kernel(const float* __restrict__ part, int N, float* __restrict__ out,
+                                                            int out_stride, float* __restrict__ out2, int accumulate) {
+  int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  float t = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) t += sh[i][tx];
-    float* o = out + (size_t)n * out_stride;
-    *o = accumulate ? *o + t : t;
+  for (int c = 0; c < COLSUM_CHUNKS; ++c) t += part[(size_t)c * N + n];
+  float* o = out + (size_t)n * out_stride;
+  *o = accumulate ? *o + t : t;
+  if (out2) out2[n] = accumulate ? out2[n] + t : t;
+}
+
+// small-row fallback (rows < 64): one pass
+__global__ void colsum_kernel(const float* __restrict__ X, int ldx, int rows, int N, const float* __restrict__ wrow,
+                              float* __restrict__ out, int out_stride, float* __restrict__ out2, int accumulate) {
+  int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int r = 0; r < rows; ++r) {
+    float x = X[(size_t)r * ldx + n];
+    s += wrow ? wrow[r] * x : x;
   }
+  float* o = out + (size_t)n * out_stride;
+  *o = accumulate ? *o + s : s;
+  if (out2) out2[n] = accumulate ? out2[n] + s : s;
+}
+
+__global__ void copy_strided_kernel(const float* __restrict__ src, size_t stride, int n, float* __restrict__ dst) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[(size_t)i * stride];
 }
 
 __global__ void bias_tanh_kernel(float* __restrict__ x, int ldx, int N, const float* __restrict__ bias) {
@@ -485,11 +511,33 @@ extern "C" int ssc_log_softmax(const float* logits, int ldl, int rows, int V, fl
   return SSC_OK;
 }
 
+// scratch: COLSUM_CHUNKS*N floats when rows >= 64 (may be null for fewer rows); out2: optional second copy (N, stride 1)
+extern "C" int ssc_colsum2(const float* X, int ldx, int rows, int N, const float* wrow, float* out, int out_stride,
+                           float* out2, int accumulate, float* scratch, void* stream) {
+  if (!X || !out || rows <= 0 || N <= 0 || ldx < N || out_stride < 1) return SSC_EINVAL;
+  if (rows >= 64 && scratch) {
+    hipLaunchKernelGGL(colsum_stage1_kernel, dim3(ssc_cdiv(N, 256), COLSUM_CHUNKS), dim3(256), 0, S(stream), X, ldx, rows, N,
+                       wrow, scratch);
+    SSC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(colsum_stage2_kernel, dim3(ssc_cdiv(N, 256)), dim3(256), 0, S(stream), scratch, N, out, out_stride,
+                       out2, accumulate);
+    SSC_CHECK_LAUNCH();
+    return SSC_OK;
+  }
+  hipLaunchKernelGGL(colsum_kernel, dim3(ssc_cdiv(N, 256)), dim3(256), 0, S(stream), X, ldx, rows, N, wrow, out, out_stride,
+                     out2, accumulate);
+  SSC_CHECK_LAUNCH();
+  return SSC_OK;
+}
+
 extern "C" int ssc_colsum(const float* X, int ldx, int rows, int N, const float* wrow, float* out, int out_stride,
                           int accumulate, void* stream) {
-  if (!X || !out || rows <= 0 || N <= 0 || ldx < N || out_stride < 1) return SSC_EINVAL;
-  hipLaunchKernelGGL(colsum_kernel, dim3(ssc_cdiv(N, 32)), dim3(32, 8), 0, S(stream), X, ldx, rows, N, wrow, out,
-                     out_stride, accumulate);
+  return ssc_colsum2(X, ldx, rows, N, wrow, out, out_stride, nullptr, accumulate, nullptr, stream);
+}
+
+extern "C" int ssc_copy_strided(const float* src, size_t stride, int n, float* dst, void* stream) {
+  if (!src || !dst || n <= 0) return SSC_EINVAL;
+  hipLaunchKernelGGL(copy_strided_kernel, dim3(ssc_cdiv(n, 256)), dim3(256), 0, S(stream), src, stride, n, dst);
   SSC_CHECK_LAUNCH();
   return SSC_OK;
 }

@@ -25,7 +25,7 @@ struct Layout {
   int V, E, H, A, F, Z, S, tied;
   int Ep, Hp, Ap, Fp, Zp, Vp, H4, XW;  // padded leading dims ; XW = F + 2H
   size_t total = 0;                    // floats
-  size_t tok, w, nvalid, sent_all, mask, avg, pv, emb, ga_static, ga_avg;
+  size_t tok, w, nvalid, sent_all, wcol_e, wcol_d, mask, avg, pv, emb, ga_static, ga_avg;
   size_t h1, c1, he, ce, hd, cd, gates_a, gates_e, gates_d, q, attn_logits, alpha, att, mu, lv, z, mulv;
   size_t slabs, slab_floats, logits, lse, proj;
   // backward
@@ -49,6 +49,7 @@ Layout make_layout(const ssc_model_cfg* c, int B, int R, int L) {
   l.w = l.take(TB);
   l.nvalid = l.take(B);
   l.sent_all = l.take(TB);
+  l.wcol_e = l.take(l.H4); l.wcol_d = l.take(l.H4);
   l.mask = l.take((size_t)B * R);
   l.avg = l.take((size_t)B * l.Fp);
   l.pv = l.take((size_t)B * R * l.A);
@@ -220,6 +221,10 @@ extern "C" int ssc_train_fwd(const ssc_model_cfg* cfg, const ssc_params* p, cons
     SSC_TRY(ssc_fill(W + l.mu, (size_t)TB * l.Zp, 0.f, st));
     SSC_TRY(ssc_fill(W + l.lv, (size_t)TB * l.Zp, 0.f, st));
   }
+  if (S) {  // the rank-1 sentiment columns of W_ih^enc / W_ih^dec, made contiguous once per call
+    SSC_TRY(ssc_copy_strided(p->enc_w_ih + F + 2 * H, p->ld_enc_w_ih, H4, W + l.wcol_e, st));
+    SSC_TRY(ssc_copy_strided(p->dec_w_ih + F + 2 * H, p->ld_dec_w_ih, H4, W + l.wcol_d, st));
+  }
   const bool fc_adjacent = (p->fc_lv_w == p->fc_mean_w + (size_t)Z * p->ld_fc_mean_w) && p->ld_fc_lv_w == p->ld_fc_mean_w;
 
   // ---- time loop ----------------------------------------------------------------------------------
@@ -266,7 +271,7 @@ extern "C" int ssc_train_fwd(const ssc_model_cfg* cfg, const ssc_params* p, cons
       d.B = B; d.H = H;
       d.slabs = c.slabs; d.nslab = ns; d.slab_stride = (size_t)B * H4;
       d.b_ih = p->enc_b_ih; d.b_hh = p->enc_b_hh;
-      if (S) { d.sent = bt->sentiment; d.wcol = p->enc_w_ih + F + 2 * H; d.ldwcol = p->ld_enc_w_ih; }
+      if (S) { d.sent = bt->sentiment; d.wcol = W + l.wcol_e; d.ldwcol = 1; }
       d.c_prev = cep; d.ld_cprev = l.Hp;
       d.gates_out = W + l.gates_e + (size_t)t * B * H4;
       d.c_out = cen; d.ld_cout = l.Hp; d.h_out = hen; d.ld_hout = l.Hp;
@@ -304,7 +309,7 @@ extern "C" int ssc_train_fwd(const ssc_model_cfg* cfg, const ssc_params* p, cons
       d.B = B; d.H = H;
       d.slabs = c.slabs; d.nslab = ns; d.slab_stride = (size_t)B * H4;
       d.b_ih = p->dec_b_ih; d.b_hh = p->dec_b_hh;
-      if (S) { d.sent = bt->sentiment; d.wcol = p->dec_w_ih + F + 2 * H; d.ldwcol = p->ld_dec_w_ih; }
+      if (S) { d.sent = bt->sentiment; d.wcol = W + l.wcol_d; d.ldwcol = 1; }
       d.c_prev = cdp; d.ld_cprev = l.Hp;
       d.gates_out = W + l.gates_d + (size_t)t * B * H4;
       d.c_out = cdn; d.ld_cout = l.Hp; d.h_out = hdn; d.ld_hout = l.Hp;
@@ -349,11 +354,11 @@ extern "C" int ssc_train_bwd(const ssc_model_cfg* cfg, const ssc_params* p, cons
     SSC_TRY(ssc_tanh_bwd(dP, l.Ep, W + l.proj, l.Ep, TB, E, st));
     SSC_TRY(gemm(c, true, false, {{dP, l.Ep, p->proj_w, p->ld_proj_w, E}}, TB, H, W + l.dhdv, l.Hp));
     if (g->proj_w) SSC_TRY(gemm(c, false, false, {{dP, l.Ep, hd_all, l.Hp, TB}}, E, H, g->proj_w, g->ld_proj_w));
-    if (g->proj_b) SSC_TRY(ssc_colsum(dP, l.Ep, TB, E, nullptr, g->proj_b, 1, 0, st));
+    if (g->proj_b) SSC_TRY(ssc_colsum2(dP, l.Ep, TB, E, nullptr, g->proj_b, 1, nullptr, 0, c.slabs, st));
   } else {
     SSC_TRY(gemm(c, true, false, {{dlog, l.Vp, p->out_w, p->ld_out_w, V}}, TB, H, W + l.dhdv, l.Hp));
     if (g->out_w) SSC_TRY(gemm(c, false, false, {{dlog, l.Vp, hd_all, l.Hp, TB}}, V, H, g->out_w, g->ld_out_w));
-    if (g->out_b) SSC_TRY(ssc_colsum(dlog, l.Vp, TB, V, nullptr, g->out_b, 1, 0, st));
+    if (g->out_b) SSC_TRY(ssc_colsum2(dlog, l.Vp, TB, V, nullptr, g->out_b, 1, nullptr, 0, c.slabs, st));
   }
 
   // ---- carried gradients start at zero ----------------------------------------------------------------
@@ -468,8 +473,12 @@ extern "C" int ssc_train_bwd(const ssc_model_cfg* cfg, const ssc_params* p, cons
     SSC_TRY(gemm(c, false, false, {{dga, H4, hd_prev, l.Hp, TB}}, H4, H, gw + E + F + H, ld));
   }
   if (g->att_w_hh) SSC_TRY(gemm(c, false, false, {{dga, H4, h1_prev, l.Hp, TB}}, H4, H, g->att_w_hh, g->ld_att_w_hh));
-  if (g->att_b_ih) SSC_TRY(ssc_colsum(dga, H4, TB, H4, nullptr, g->att_b_ih, 1, 0, st));
-  if (g->att_b_hh) SSC_TRY(ssc_colsum(dga, H4, TB, H4, nullptr, g->att_b_hh, 1, 0, st));
+  if (g->att_b_ih && g->att_b_hh) {
+    SSC_TRY(ssc_colsum2(dga, H4, TB, H4, nullptr, g->att_b_ih, 1, g->att_b_hh, 0, c.slabs, st));
+  } else {
+    if (g->att_b_ih) SSC_TRY(ssc_colsum2(dga, H4, TB, H4, nullptr, g->att_b_ih, 1, nullptr, 0, c.slabs, st));
+    if (g->att_b_hh) SSC_TRY(ssc_colsum2(dga, H4, TB, H4, nullptr, g->att_b_hh, 1, nullptr, 0, c.slabs, st));
+  }
   if (g->emb && !cfg->tied) {
     SSC_TRY(gemm(c, true, false, {{dga, H4, p->att_w_ih, p->ld_att_w_ih, H4}}, TB, E, W + l.demb, l.Ep));
     // zero the table gradient, then scatter-add rows by token id (padding_idx row gets none)
@@ -487,28 +496,36 @@ extern "C" int ssc_train_bwd(const ssc_model_cfg* cfg, const ssc_params* p, cons
     SSC_TRY(gemm(c, false, false, {{dge, H4, att, l.Fp, TB}}, H4, F, gw, ld));
     SSC_TRY(gemm(c, false, false, {{dge, H4, h1_new, l.Hp, TB}}, H4, H, gw + F, ld));
     SSC_TRY(gemm(c, false, false, {{dge, H4, hd_prev, l.Hp, TB}}, H4, H, gw + F + H, ld));
-    if (S) SSC_TRY(ssc_colsum(dge, H4, TB, H4, W + l.sent_all, gw + F + 2 * H, ld, 0, st));
+    if (S) SSC_TRY(ssc_colsum2(dge, H4, TB, H4, W + l.sent_all, gw + F + 2 * H, ld, nullptr, 0, c.slabs, st));
   }
   if (g->enc_w_hh) SSC_TRY(gemm(c, false, false, {{dge, H4, he_prev, l.Hp, TB}}, H4, H, g->enc_w_hh, g->ld_enc_w_hh));
-  if (g->enc_b_ih) SSC_TRY(ssc_colsum(dge, H4, TB, H4, nullptr, g->enc_b_ih, 1, 0, st));
-  if (g->enc_b_hh) SSC_TRY(ssc_colsum(dge, H4, TB, H4, nullptr, g->enc_b_hh, 1, 0, st));
+  if (g->enc_b_ih && g->enc_b_hh) {
+    SSC_TRY(ssc_colsum2(dge, H4, TB, H4, nullptr, g->enc_b_ih, 1, g->enc_b_hh, 0, c.slabs, st));
+  } else {
+    if (g->enc_b_ih) SSC_TRY(ssc_colsum2(dge, H4, TB, H4, nullptr, g->enc_b_ih, 1, nullptr, 0, c.slabs, st));
+    if (g->enc_b_hh) SSC_TRY(ssc_colsum2(dge, H4, TB, H4, nullptr, g->enc_b_hh, 1, nullptr, 0, c.slabs, st));
+  }
   // latent heads
   const float* dmulv = W + l.dmulv;
   if (g->fc_mean_w) SSC_TRY(gemm(c, false, false, {{dmulv, 2 * Z, he_new, l.Hp, TB}}, Z, H, g->fc_mean_w, g->ld_fc_mean_w));
   if (g->fc_lv_w) SSC_TRY(gemm(c, false, false, {{dmulv + Z, 2 * Z, he_new, l.Hp, TB}}, Z, H, g->fc_lv_w, g->ld_fc_lv_w));
-  if (g->fc_mean_b) SSC_TRY(ssc_colsum(dmulv, 2 * Z, TB, Z, nullptr, g->fc_mean_b, 1, 0, st));
-  if (g->fc_lv_b) SSC_TRY(ssc_colsum(dmulv + Z, 2 * Z, TB, Z, nullptr, g->fc_lv_b, 1, 0, st));
+  if (g->fc_mean_b) SSC_TRY(ssc_colsum2(dmulv, 2 * Z, TB, Z, nullptr, g->fc_mean_b, 1, nullptr, 0, c.slabs, st));
+  if (g->fc_lv_b) SSC_TRY(ssc_colsum2(dmulv + Z, 2 * Z, TB, Z, nullptr, g->fc_lv_b, 1, nullptr, 0, c.slabs, st));
   // decoder LSTM (skipped while frozen: train.py:156-161)
   if (g->dec_w_ih) {
     float* gw = g->dec_w_ih; int ld = g->ld_dec_w_ih;
     SSC_TRY(gemm(c, false, false, {{dgd, H4, att, l.Fp, TB}}, H4, F, gw, ld));
     SSC_TRY(gemm(c, false, false, {{dgd, H4, h1_new, l.Hp, TB}}, H4, H, gw + F, ld));
     SSC_TRY(gemm(c, false, false, {{dgd, H4, hd_prev, l.Hp, TB}}, H4, H, gw + F + H, ld));
-    if (S) SSC_TRY(ssc_colsum(dgd, H4, TB, H4, W + l.sent_all, gw + F + 2 * H, ld, 0, st));
+    if (S) SSC_TRY(ssc_colsum2(dgd, H4, TB, H4, W + l.sent_all, gw + F + 2 * H, ld, nullptr, 0, c.slabs, st));
     SSC_TRY(gemm(c, false, false, {{dgd, H4, W + l.z, l.Zp, TB}}, H4, Z, gw + zcol, ld));
   }
   if (g->dec_w_hh) SSC_TRY(gemm(c, false, false, {{dgd, H4, hd_prev, l.Hp, TB}}, H4, H, g->dec_w_hh, g->ld_dec_w_hh));
-  if (g->dec_b_ih) SSC_TRY(ssc_colsum(dgd, H4, TB, H4, nullptr, g->dec_b_ih, 1, 0, st));
-  if (g->dec_b_hh) SSC_TRY(ssc_colsum(dgd, H4, TB, H4, nullptr, g->dec_b_hh, 1, 0, st));
+  if (g->dec_b_ih && g->dec_b_hh) {
+    SSC_TRY(ssc_colsum2(dgd, H4, TB, H4, nullptr, g->dec_b_ih, 1, g->dec_b_hh, 0, c.slabs, st));
+  } else {
+    if (g->dec_b_ih) SSC_TRY(ssc_colsum2(dgd, H4, TB, H4, nullptr, g->dec_b_ih, 1, nullptr, 0, c.slabs, st));
+    if (g->dec_b_hh) SSC_TRY(ssc_colsum2(dgd, H4, TB, H4, nullptr, g->dec_b_hh, 1, nullptr, 0, c.slabs, st));
+  }
   return SSC_OK;
 }

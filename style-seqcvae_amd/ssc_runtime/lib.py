@@ -120,6 +120,8 @@ SYMBOLS = {
     "ssc_ce_bwd": (_i, [vp, _i, vp, vp, vp, vp, vp, _i, _i, _i, vp]),
     "ssc_log_softmax": (_i, [vp, _i, _i, _i, vp, _i, vp]),
     "ssc_colsum": (_i, [vp, _i, _i, _i, vp, vp, _i, _i, vp]),
+    "ssc_colsum2": (_i, [vp, _i, _i, _i, vp, vp, _i, vp, _i, vp, vp]),
+    "ssc_copy_strided": (_i, [vp, _sz, _i, vp, vp]),
     "ssc_bias_tanh": (_i, [vp, _i, _i, _i, vp, vp]),
     "ssc_tanh_bwd": (_i, [vp, _i, vp, _i, _i, _i, vp]),
     "ssc_fill": (_i, [vp, _sz, _f, vp]),

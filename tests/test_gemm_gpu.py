@@ -19,7 +19,8 @@ def ref(As, Bs, a_kc, b_kc):
 
 @pytest.mark.parametrize("a_kc,b_kc", [(1, 1), (1, 0), (0, 0)])
 @pytest.mark.parametrize("M,N,Ks", [(64, 128, [96]), (64, 4800, [2048, 1200, 1200]), (1, 7, [5]), (70, 33, [37, 1, 64]),
-                                    (130, 257, [100, 31]), (1344, 200, [300])])
+                                    (130, 257, [100, 31]), (1344, 200, [300]), (600, 530, [100, 31, 64]),
+                                    (1344, 1200, [333])])
 @pytest.mark.parametrize("splits", [0, 1, 3])
 def test_gemm_layouts(a_kc, b_kc, M, N, Ks, splits):
     g = torch.Generator().manual_seed(M * 7 + N)
