@@ -85,6 +85,62 @@ def cpu_baseline(c, seconds_budget=25.0):
                       f"median {med:.2f} s/step, torch {torch.__version__} CPU, os.cpu_count()={os.cpu_count()}"}
 
 
+def bench_decode(args, model, eng, c, rank, world, device):
+    """BASELINE.json configs[3] (C4): beam 5 (per-node 2) x 20 latent samples per image, 36x2048 features, max 20
+    steps, trivial one-state FSM, images sharded over ranks (no collective).  A "step" = one chunk of images."""
+    import torch.distributed as dist
+    from ssc_runtime.inference import count_tokens, diverse_decode
+
+    model.eval()
+    dec = model._dec
+    chunk = 50                       # images per beam-search call: 50 x 20 samples x 5 beams = 5000 rows
+    per_rank = args.images // world
+    n_chunks = max(1, per_rank // chunk)
+    g = torch.Generator().manual_seed(4321 + rank)
+    feats = [torch.randn(chunk, c["R"], c["F"], generator=g).to(device) for _ in range(min(n_chunks, 4))]
+    senti = torch.ones(chunk, device=device)
+    results = {}
+    for early in (True, False):
+        for i in range(args.warmup if early else 1):
+            diverse_decode(dec, feats[i % len(feats)], senti, 20, 5, c["L"], 1, early_stop=early)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tokens = rows_steps = 0
+        for i in range(n_chunks):
+            pred, calls = diverse_decode(dec, feats[i % len(feats)], senti, 20, 5, c["L"], 1, early_stop=early)
+            tokens += count_tokens(pred, 1)
+            rows_steps += chunk * 20 * (1 + 5 * (calls - 1))
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el, tokens, rows_steps], device=device, dtype=torch.float64)
+            tmax = t.clone()
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            el, tokens, rows_steps = float(tmax[0]), float(t[1]), float(t[2])
+        results[early] = (el, tokens, rows_steps)
+    if rank == 0:
+        el, tokens, rows_steps = results[True]
+        el2, tokens2, rows_steps2 = results[False]
+        print(json.dumps({
+            "metric": "decode tokens/sec (beam 5 x 20 latent samples per image)", "value": tokens / el, "unit": "tokens/s",
+            "n_gpus": world, "steps": n_chunks, "warmup": args.warmup, "ms_per_step": el / n_chunks * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C4 diverse decode: %d images, 36x2048 feats, beam 5 (per-node 2), N_Z=20, max 20 steps, "
+                                   "trivial FSM, random-init weights" % (n_chunks * chunk * world),
+                       "images_per_call": chunk, "rows_per_call": chunk * 100},
+            "captions_per_s": n_chunks * chunk * world * 20 / el, "row_steps_per_s": rows_steps / el,
+            "early_stop_disabled": {"tokens_per_s": tokens2 / el2, "row_steps_per_s": rows_steps2 / el2,
+                                    "captions_per_s": n_chunks * chunk * world * 20 / el2}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -92,6 +148,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", type=int, default=C2["B"])
+    ap.add_argument("--mode", default="train", choices=["train", "decode"],
+                    help="train: headline captions/sec (default); decode: C4 diverse-decode tokens/sec")
+    ap.add_argument("--images", type=int, default=1000, help="decode mode: synthetic images in total")
     ap.add_argument("--dump-gemm", default="", help="write the per-shape GEMM timing table (roofline leg) to this file")
     args = ap.parse_args()
 
@@ -122,6 +181,8 @@ def main():
                             z_space=c["Z"], prior_std=1.0, simple_vae=False, latent_embedding="glove", sentiment_vae=1,
                             senti_prior_multip=0.5, device=device).to(device)
     eng = model._engine()  # flat parameter / gradient store + fused kernels; the module's parameters are views of it
+    if args.mode == "decode":
+        return bench_decode(args, model, eng, c, rank, world, device)
     batches = [synth_batch(1234 + rank + 100 * i, c["B"], c["R"], c["F"], c["L"], c["V"], c["Z"], device) for i in range(4)]
     total_iters = 70000
 

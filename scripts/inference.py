@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Diverse captioning inference on MI355X - counterpart of the reference's var_updown/scripts/inference.py:19-191: same
+flags and JSON output ([{"image_id", "caption"}...], N_Z_SAMPLES captions per image), but images x latent samples are
+decoded as ONE batched beam search per chunk instead of a per-image Python loop of N_Z_SAMPLES model calls."""
+import argparse
+import json
+import os
+import random
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "style-seqcvae_amd"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from ssc_runtime.config import Config  # noqa: E402
+from ssc_runtime.data import SyntheticCaptionData, TensorFileData  # noqa: E402
+from ssc_runtime.inference import diverse_decode  # noqa: E402
+from ssc_runtime.vocab import Vocabulary  # noqa: E402
+from var_updown.models import UpDownCaptioner  # noqa: E402
+
+parser = argparse.ArgumentParser("Run diverse-decoding inference with a trained Style-SeqCVAE captioner (MI355X).")
+parser.add_argument("--config", required=True)
+parser.add_argument("--config-override", default=[], nargs="*")
+parser.add_argument("--gpu-ids", required=True, nargs="+", type=int)
+parser.add_argument("--cpu-workers", type=int, default=0)
+parser.add_argument("--in-memory", action="store_true")
+parser.add_argument("--checkpoint-path", default="", help="checkpoint with a 'model' state_dict; empty: random init")
+parser.add_argument("--output-path", default="predictions.json")
+parser.add_argument("--evalai-submit", action="store_true", help="accepted for flag parity; EvalAI is a network service")
+parser.add_argument("--infer-tensors", default="")
+parser.add_argument("--synthetic", type=int, default=0)
+parser.add_argument("--vocab-size", type=int, default=10000)
+parser.add_argument("--num-boxes", type=int, default=36)
+parser.add_argument("--images-per-call", type=int, default=50)
+parser.add_argument("--sentiment", type=float, default=None, help="override the per-image sentiment (-1, 0, 1)")
+
+
+class _LocalGlove(UpDownCaptioner):
+    """Frozen embedding table comes from the checkpoint; no GloVe download at construction time."""
+
+    def _initialize_glove(self):
+        return torch.zeros(self._vocabulary.get_vocab_size(), self.embedding_size)
+
+
+def main():
+    _A = parser.parse_args()
+    _C = Config(_A.config, _A.config_override)
+    random.seed(_C.RANDOM_SEED)
+    np.random.seed(_C.RANDOM_SEED)
+    torch.manual_seed(_C.RANDOM_SEED)
+    device = torch.device("cuda", _A.gpu_ids[0])
+    torch.cuda.set_device(device)
+    if _A.synthetic:
+        vocabulary = Vocabulary.synthetic(_A.vocab_size)
+        data = SyntheticCaptionData(_A.synthetic, _A.num_boxes, _C.MODEL.IMAGE_FEATURE_SIZE, _C.DATA.MAX_CAPTION_LENGTH,
+                                    _A.vocab_size, seed=4321)
+    else:
+        vocabulary = Vocabulary.from_files(_C.DATA.VOCABULARY)
+        if not _A.infer_tensors:
+            raise SystemExit("pass --infer-tensors file.pt or --synthetic N (h5 readers are out of scope)")
+        data = TensorFileData(_A.infer_tensors)
+    cls = _LocalGlove if (_C.MODEL.EMBEDDING_SIZE in (300, 600) and _A.checkpoint_path) else UpDownCaptioner
+    model = cls.from_config(_C, vocabulary=vocabulary, device=device).to(device)
+    if _A.checkpoint_path:
+        model.load_state_dict(torch.load(_A.checkpoint_path, map_location=device, weights_only=True)["model"])
+    model.eval()
+    model._engine()
+    n_z = max(1, _C.MODEL.N_Z_SAMPLES)
+    beam = _C.MODEL.BEAM_SIZE
+    boundary = vocabulary.get_token_index("@@BOUNDARY@@")
+    predictions = []
+    with torch.no_grad():
+        for lo in range(0, len(data), _A.images_per_call):
+            feats = data.feats[lo: lo + _A.images_per_call].to(device)
+            senti = data.senti[lo: lo + _A.images_per_call, 0].to(device)
+            if _A.sentiment is not None:
+                senti = torch.full_like(senti, _A.sentiment)
+            pred, _ = diverse_decode(model._dec, feats, senti, n_z, beam, _C.DATA.MAX_CAPTION_LENGTH, boundary)
+            pred = pred.cpu()
+            for i in range(pred.size(0)):
+                for k in range(n_z):
+                    words = [vocabulary.get_token_from_index(int(t)) for t in pred[i, k]]
+                    if "@@BOUNDARY@@" in words:                      # inference.py:180-182
+                        words = words[: words.index("@@BOUNDARY@@")]
+                    predictions.append({"image_id": int(data.image_id[lo + i]), "caption": " ".join(words)})
+    json.dump(predictions, open(_A.output_path, "w", encoding="utf-8"))
+    print(f"wrote {len(predictions)} captions to {_A.output_path}")
+
+
+if __name__ == "__main__":
+    main()

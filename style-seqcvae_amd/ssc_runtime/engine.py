@@ -104,7 +104,7 @@ class FlatStore:
         for name, shp in shapes.items():
             n = shp[0] * _r4(shp[1]) if len(shp) == 2 and shp[0] > 1 else _r4(shp[-1])
             self.offsets[name] = (off, n)
-            off += (n + 63) // 64 * 64
+            off += n  # n is a multiple of 4 floats: every tensor starts 16-B aligned, neighbours stay adjacent
         self.numel = off
         self.flat = torch.zeros(off, dtype=torch.float32, device=device) if zero else torch.empty(
             off, dtype=torch.float32, device=device)
@@ -120,7 +120,7 @@ class FlatStore:
     def range_of(self, names: Sequence[str]) -> Tuple[int, int]:
         """[lo, hi) flat range covering `names` (must be laid out consecutively)."""
         lo = min(self.offsets[n][0] for n in names)
-        hi = max(self.offsets[n][0] + (self.offsets[n][1] + 63) // 64 * 64 for n in names)
+        hi = max(self.offsets[n][0] + self.offsets[n][1] for n in names)
         return lo, hi
 
     def c_struct(self, only: Optional[Sequence[str]] = None) -> _lib.Params:
@@ -173,6 +173,7 @@ class TrainEngine:
         self.frozen_names = ["_embedding_layer.weight"] if dims.tied else []
         self.steps_done = 0
         self.fwd_version = 0
+        self.dp_buckets = 1
 
     def adopt(self, named: "Dict[str, torch.nn.Parameter]"):
         """Re-home nn.Parameters into the flat store (copy once, then `param.data` IS the view).  Cheap when they
@@ -302,12 +303,9 @@ class TrainEngine:
     # ---- data parallel -----------------------------------------------------------------------------------
     def allreduce_grads(self, group=None):
         """One RCCL all-reduce (sum) over the flat gradient buffer; the 1/world_size is folded into the SGD kernel."""
-        import torch.distributed as dist
+        from . import dp
 
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-            dist.all_reduce(self.grads.flat, op=dist.ReduceOp.SUM, group=group)
-            return dist.get_world_size(group)
-        return 1
+        return dp.allreduce_flat(self.grads.flat, group=group, n_buckets=self.dp_buckets)
 
     def train_step(self, feats, caps, sentiment, eps, lr, kld_weight=750.0, momentum=0.9, weight_decay=0.001,
                    max_norm=12.5, decoder_frozen=False, group=None):

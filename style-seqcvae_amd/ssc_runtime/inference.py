@@ -1,0 +1,61 @@
+"""Diverse decoding: N_Z stochastic beam-search decodes per image, batched over images x samples on one GPU.
+
+Reference: var_updown/scripts/inference.py:117-189 runs, per image (batch forced to 1, :95), a Python loop of
+N_Z_SAMPLES calls of model(...) - 20 x <=20 steps x G=beam rows: launch-bound.  Here the (image, sample) pairs are
+the batch entries of ONE constrained beam search (rows ordered image, sample, fsm state, beam), per-image terms are
+computed once per image and shared by its N_Z * beam rows; the result per (image, sample) equals the reference's
+per-call result given the same per-row noise.
+"""
+from typing import List, Optional
+
+import torch
+
+from .decode import DecodeEngine, cbs_search
+from .decoding import select_best_beam_with_constraints
+
+
+def diverse_decode(dec: DecodeEngine, feats: torch.Tensor, sentiment: Optional[torch.Tensor], n_samples: int, beam: int,
+                   max_steps: int, boundary_index: int, fsm: Optional[torch.Tensor] = None,
+                   num_constraints: Optional[torch.Tensor] = None, min_constraints_to_satisfy: int = 0,
+                   eps_steps: Optional[List[torch.Tensor]] = None, early_stop: bool = True, per_node: Optional[int] = None):
+    """feats (nimg,R,F), sentiment (nimg,) or None -> predictions (nimg, n_samples, steps) int64 on device.
+    fsm: (nimg*n_samples, S, S, V) uint8 or None (trivial one-state machine, what MAX_GIVEN_CONSTRAINTS: 0 produces).
+    eps_steps: optional explicit noise per step call [(rows_k, Z)]; default: device RNG."""
+    dev = feats.device
+    nimg = feats.size(0)
+    d = dec.dims
+    B = nimg * n_samples
+    ctx = dec.prepare(feats)
+    if fsm is None:
+        fsm = torch.ones(B, 1, 1, d.V, dtype=torch.uint8, device=dev)
+        num_constraints = torch.zeros(B, dtype=torch.long)
+    sent_b = sentiment.reshape(nimg, 1).expand(nimg, n_samples).reshape(B) if sentiment is not None else None
+    calls = {"k": 0}
+
+    def step(tokens, state):
+        G = tokens.numel()
+        sent_rows = sent_b.view(B, 1).expand(B, G // B).reshape(G) if sent_b is not None else None
+        if eps_steps is not None:
+            eps = eps_steps[calls["k"]]
+        else:
+            eps = torch.randn(G, d.Z, device=dev)
+        calls["k"] += 1
+        lp, st, alpha = dec.step(ctx, tokens, state, sent_rows, eps)
+        return lp, st
+
+    start = torch.full((B,), boundary_index, dtype=torch.long, device=dev)
+    beams, lps = cbs_search(start, None, step, fsm, boundary_index, max_steps, beam, per_node or (beam // 2) or beam,
+                            early_stop=early_stop)
+    if fsm.size(1) == 1:
+        best = beams[:, 0, 0, :]
+    else:
+        best, _ = select_best_beam_with_constraints(beams, lps, num_constraints, None, None, min_constraints_to_satisfy, True)
+    return best.view(nimg, n_samples, -1), calls["k"]
+
+
+def count_tokens(pred: torch.Tensor, boundary_index: int) -> int:
+    """Tokens emitted before the first @@BOUNDARY@@ of every caption (inference.py:180-182)."""
+    is_end = (pred == boundary_index)
+    steps = pred.size(-1)
+    first = torch.where(is_end.any(-1), is_end.float().argmax(-1), torch.full(pred.shape[:-1], steps, device=pred.device))
+    return int(first.sum().item())

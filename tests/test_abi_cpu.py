@@ -1,0 +1,62 @@
+"""CPU: libssc_hip.so loads without a GPU and exports every symbol include/ssc.h declares (no compute calls);
+the ctypes table mirrors the header; argument validation fails loudly instead of touching memory."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from ssc_runtime import lib as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "ssc.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ssc_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = L.load()
+    names = header_symbols()
+    assert len(names) >= 35
+    cdll = C.CDLL(L.LIB_PATH)
+    for n in names:
+        assert hasattr(cdll, n), f"{n} declared in include/ssc.h but not exported"
+        assert n in L.SYMBOLS, f"{n} missing from the ctypes table"
+    assert sorted(L.SYMBOLS) == names
+    assert lib.ssc_version() == 1 and lib.ssc_arch() == b"gfx950"
+
+
+def test_struct_layouts_match_header_field_order():
+    text = open(os.path.join(ROOT, "include", "ssc.h")).read()
+    body = text[text.index("typedef struct {\n  float* emb;"):text.index("} ssc_params;")]
+    fields = re.findall(r"(?:float\*|int)\s+(\w+);", body)
+    assert fields == [f for f, _ in L.Params._fields_]
+    body = text[text.index("typedef struct {\n  int V, E, H, A, F, Z;"):text.index("} ssc_model_cfg;")]
+    names = [n.strip() for line in re.findall(r"(?:int|float)\s+([\w, ]+);", body) for n in line.split(",")]
+    assert names == [f for f, _ in L.ModelCfg._fields_]
+
+
+def test_bad_arguments_are_rejected_without_a_gpu():
+    lib = L.load()
+    with pytest.raises(L.SscError, match="SSC_EINVAL"):
+        lib.ssc_gemm(None, None)
+    d = L.GemmDesc()
+    d.nseg = 9
+    with pytest.raises(L.SscError, match="SSC_EINVAL"):
+        lib.ssc_gemm(C.byref(d), None)
+    with pytest.raises(L.SscError, match="SSC_EINVAL"):
+        lib.ssc_feat_prep(None, 1, 1, 1, None, None, None)
+    cfg = L.ModelCfg(10, 4, 4, 4, 4, 4, 0, 0, 0, 0.0, 1.0, 0, 1)
+    assert lib.ssc_train_workspace_bytes(C.byref(cfg), 2, 3, 4) > 0
+    assert lib.ssc_train_workspace_bytes(C.byref(cfg), 0, 3, 4) == 0
+    assert lib.ssc_gemm_auto_splits(64, 4800, 180) >= 1
+
+
+def test_missing_extension_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(L, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        L.load()
