@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 outputs into the small files committed under profiles/.
+
+  python profiles/summarize.py pmc  <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>
+  python profiles/summarize.py stats <kernel_stats.csv> <out.csv>
+
+PMC correction (MI355X_MICROARCH.md §HBM): FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports exactly
+half the bytes of a wide (16 B/lane) coalesced streaming read, so the read side is doubled for the GEMM / streaming
+kernels (all of ours read 16 B/lane); WRITE_SIZE is exact for 16-B-per-lane stores and is used as is.
+"""
+import collections
+import csv
+import json
+import re
+import sys
+
+
+def short(name):
+    m = re.search(r"gemm_kernel<(\w+), (\w+), (\d), (\d), (\d), (\w+)>", name)
+    if m:
+        a, b, wm, wn, pf, vec = m.groups()
+        kind = {("true", "true"): "NT", ("true", "false"): "NN", ("false", "false"): "TN", ("false", "true"): "TT"}[(a, b)]
+        return f"gemm_kernel<{kind},{64 * int(wm)}x{64 * int(wn)},{'vec' if vec == 'true' else 'scalar'}>"
+    m = re.search(r"(?:\(anonymous namespace\)::)?(\w+)\(", name)
+    return m.group(1) if m else name[:50]
+
+
+def pmc(fetch_csv, write_csv, out):
+    acc = collections.defaultdict(lambda: {"launches": 0, "fetch_kib": 0.0, "write_kib": 0.0})
+    for path, key in ((fetch_csv, "fetch_kib"), (write_csv, "write_kib")):
+        n = collections.Counter()
+        for r in csv.DictReader(open(path)):
+            k = short(r["Kernel_Name"])
+            acc[k][key] += float(r["Counter_Value"])
+            n[k] += 1
+        for k, c in n.items():
+            acc[k]["launches"] = max(acc[k]["launches"], c)
+    res = {}
+    for k, v in acc.items():
+        L = max(v["launches"], 1)
+        res[k] = {"launches": L, "hbm_read_bytes_per_launch": 2.0 * v["fetch_kib"] * 1024 / L,
+                  "hbm_write_bytes_per_launch": v["write_kib"] * 1024 / L,
+                  "hbm_bytes_per_launch": (2.0 * v["fetch_kib"] + v["write_kib"]) * 1024 / L}
+    json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `bench.py --steps 2 --warmup 1 "
+                       "--no-cpu-baseline`; read side x2 (gfx950 FETCH_SIZE half-count of 16 B/lane streams)",
+               "kernels": dict(sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"]))},
+              open(out, "w"), indent=1)
+
+
+def stats(stats_csv, out):
+    rows = list(csv.DictReader(open(stats_csv)))
+    with open(out, "w") as f:
+        f.write("kernel,calls,total_ms,avg_us,percent\n")
+        for r in rows:
+            f.write(f"{short(r['Name'])},{r['Calls']},{float(r['TotalDurationNs']) / 1e6:.3f},"
+                    f"{float(r['AverageNs']) / 1e3:.2f},{r['Percentage']}\n")
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "pmc":
+        pmc(*sys.argv[2:5])
+    else:
+        stats(*sys.argv[2:4])
