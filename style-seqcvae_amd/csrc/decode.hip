@@ -52,7 +52,7 @@ StepLayout step_layout(const ssc_model_cfg* c, int G, int R) {
   l.proj = o; o += r64(c->tied ? (size_t)G * l.Ep : 0);
   l.wcol = o; o += r64((size_t)4 * c->H);
   size_t skinny = (size_t)33 * G * 4 * c->H;
-  size_t full = (size_t)1100 * 4096;
+  size_t full = (size_t)16 * 1024 * 1024;  // 64 MB: split-K slabs of the large GEMMs
   l.slab_floats = skinny > full ? skinny : full;
   l.slabs = o; o += r64(l.slab_floats);
   l.total = o;
@@ -87,14 +87,7 @@ int gemm_nt(hipStream_t st, float* ws, size_t ws_floats, std::initializer_list<S
 int gemm_slabs(hipStream_t st, float* ws, size_t ws_floats, std::initializer_list<Seg> segs, int M, int N, int* nslab) {
   ssc_gemm_desc d;
   fill_desc(d, segs, M, N);
-  int ksteps = 0;
-  for (int i = 0; i < d.nseg; ++i) ksteps += ssc_cdiv(d.seg[i].K, 32);
-  int splits = ssc_gemm_auto_splits(M, N, ksteps);
-  while (splits > 1 && (size_t)splits * M * N > ws_floats) --splits;
-  int per = ssc_cdiv(ksteps, splits);
-  splits = ssc_cdiv(ksteps, per);
-  *nslab = splits;
-  return ssc_gemm_slabs(&d, splits, ws, st);
+  return ssc_gemm_slabs_auto(&d, ws, ws_floats, nslab, st);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -19,6 +19,8 @@
 // and leading dimension allow it, else 4 B/lane (still coalesced along the contiguous axis).
 // Split-K: grid.z workgroups per tile write partial slabs that a second kernel (or the fused LSTM /
 // latent epilogue kernels) sums in a fixed order -> deterministic, no float atomics.
+#include <stdlib.h>
+
 #include "ssc_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -45,6 +47,8 @@ struct KArgs {
   const float* bias;
   int accumulate;
   int steps_total, steps_per_split;
+  int dbg;  // timing-only ablation switches (SSC_GEMM_DBG env; results are wrong when set): 1 = no global loads in
+            // the loop, 2 = no LDS stores, 4 = no barriers
 };
 
 // ---- global -> register staging of one ROWS x 32 operand tile (ROWS/8 floats per thread) --------------
@@ -301,7 +305,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(const KArgs a) {
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int half = lane >> 5, l31 = lane & 31;
-  const int n0 = blockIdx.x * RB, m0 = blockIdx.y * RA, z = blockIdx.z;
+  // XCD-aware tile order (cdna_hip_programming.md T1): workgroups are dealt round-robin over the 8 XCDs, so give
+  // each XCD a contiguous run of row-major tile ids - tiles that share an A panel (same M-tile) then share an L2.
+  // Speed only; the map is a bijection for any grid size.
+  int bx = blockIdx.x, by = blockIdx.y;
+  {
+    const int gx = gridDim.x, total = gridDim.x * gridDim.y;
+    const int lin = by * gx + bx;
+    const int q = total >> 3, rem = total & 7;          // XCD x owns q (+1 if x < rem) tiles
+    const int xcd = lin & 7, slot = lin >> 3;
+    const int nl = xcd * q + (xcd < rem ? xcd : rem) + slot;
+    by = nl / gx;
+    bx = nl - by * gx;
+  }
+  const int n0 = bx * RB, m0 = by * RA, z = blockIdx.z;
 
   const int s_lo = z * a.steps_per_split;
   int s_hi = s_lo + a.steps_per_split;
@@ -317,28 +334,25 @@ __global__ __launch_bounds__(256) void gemm_kernel(const KArgs a) {
 
   typedef Stage<A_KC, B_KC, RA, RB, VEC> StageT;
   constexpr int NL = StageT::NLOADS;
-  StageT st0, st1;
+  StageT st[PF];
   const int s_last = s_hi - 1;
-  // prologue: tile s_lo -> LDS[0]; tiles s_lo+1 (and s_lo+2 when PF == 2) stay in flight in registers.  Loads are
-  // unconditional - a step index past the end is clamped and re-reads the last tile, which is never stored.
+  // prologue: tile s_lo -> LDS[0]; tiles s_lo+1 .. s_lo+PF stay in flight in registers (stage j holds tile s+1+j).
+  // Loads are unconditional - a step index past the end is clamped and re-reads the last tile, which is never stored.
   Cursor cur;
   int s_ld = s_lo;  // step the cursor points at (the newest tile requested)
   if (s_lo < s_hi) {
     cur.init(a, s_lo);
-    st0.load(a, cur, m0, n0, tid);
-    st0.template wait<0>();
-    st0.store(As, Bs, tid);
-    cur.advance(a, s_ld >= s_last); s_ld = min(s_ld + 1, s_last);
-    st0.load(a, cur, m0, n0, tid);
-    if constexpr (PF == 2) {
+    st[0].load(a, cur, m0, n0, tid);
+    st[0].template wait<0>();
+    st[0].store(As, Bs, tid);
+#pragma unroll
+    for (int j = 0; j < PF; ++j) {
       cur.advance(a, s_ld >= s_last); s_ld = min(s_ld + 1, s_last);
-      st1.load(a, cur, m0, n0, tid);
+      st[j].load(a, cur, m0, n0, tid);
     }
   }
   __syncthreads();
 
-  // All fragment reads of a k-step are issued up front when registers allow (one exposed LDS latency per step
-  // instead of one per 8-wide chunk); the 2x2 wave tile reads chunk by chunk to stay inside the register budget.
   auto compute = [&](int buf) {
     const float* as = As + buf * TA;
     const float* bs = Bs + buf * TB;
@@ -365,30 +379,21 @@ __global__ __launch_bounds__(256) void gemm_kernel(const KArgs a) {
     }
   };
 
-  // steady state: tile s is in LDS[cur]; tile s+1 sits in stage X (older loads), tile s+2 in stage Y (younger, PF == 2)
-  for (int s = s_lo; s < s_hi; s += 2) {
-    {  // even: X = st0, Y = st1
-      compute(0);
-      st0.template wait<(PF == 2) ? NL : 0>();
-      if (s + 1 < s_hi) st0.store(As + TA, Bs + TB, tid);
-      cur.advance(a, s_ld >= s_last); s_ld = min(s_ld + 1, s_last);
-      st0.load(a, cur, m0, n0, tid);
-      __syncthreads();
-    }
-    if (s + 1 < s_hi) {  // odd: X = st1 (PF == 2) or st0 (PF == 1)
-      compute(1);
-      if constexpr (PF == 2) {
-        st1.template wait<NL>();
-        if (s + 2 < s_hi) st1.store(As, Bs, tid);
+  // steady state, unrolled so that stage and LDS-buffer indices are static: in sub-iteration j tile s+j is in
+  // LDS[j&1], stage j%PF holds tile s+j+1 (the OLDEST loads in flight; the other PF-1 stages are younger).
+  constexpr int U = PF > 2 ? PF : 2;
+  for (int s = s_lo; s < s_hi; s += U) {
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      if (s + j < s_hi) {
+        StageT& x = st[j % PF];
+        compute(j & 1);
+        x.template wait<(PF - 1) * NL>();
+        if (s + j + 1 < s_hi && !(a.dbg & 2)) x.store(As + ((j + 1) & 1) * TA, Bs + ((j + 1) & 1) * TB, tid);
         cur.advance(a, s_ld >= s_last); s_ld = min(s_ld + 1, s_last);
-        st1.load(a, cur, m0, n0, tid);
-      } else {
-        st0.template wait<0>();
-        if (s + 2 < s_hi) st0.store(As, Bs, tid);
-        cur.advance(a, s_ld >= s_last); s_ld = min(s_ld + 1, s_last);
-        st0.load(a, cur, m0, n0, tid);
+        if (!(a.dbg & 1)) x.load(a, cur, m0, n0, tid);
+        if (!(a.dbg & 4)) __syncthreads();
       }
-      __syncthreads();
     }
   }
   if constexpr (VEC) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the clamped tail loads
@@ -427,7 +432,13 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int nslab, 
   if (i >= total) return;
   int row = (int)(i / N), col = (int)(i % N);
   float v = 0.f;
-  for (int s = 0; s < nslab; ++s) v += slabs[(size_t)s * slab_stride + i];
+  for (int s0 = 0; s0 < nslab; s0 += 8) {  // fixed summation order, 8 loads in flight
+    float t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = slabs[(size_t)min(s0 + u, nslab - 1) * slab_stride + i];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v += (s0 + u < nslab) ? t[u] : 0.f;
+  }
   if (bias) v += bias[col];
   float* p = C + (size_t)row * ldc + col;
   if (accumulate) v += *p;
@@ -484,13 +495,17 @@ inline bool big_tile(int M, int N) { return M >= 512 && N >= 512; }
 
 int launch(const ssc_gemm_desc* d, KArgs& k, int splits, hipStream_t st) {
   k.steps_per_split = ssc_cdiv(k.steps_total, splits);
+  {
+    static const int dbg = getenv("SSC_GEMM_DBG") ? atoi(getenv("SSC_GEMM_DBG")) : 0;
+    k.dbg = dbg;
+  }
   const bool big = big_tile(d->M, d->N);
   const int bm = big ? 128 : 64, bn = big ? 128 : 64;
   dim3 grid(ssc_cdiv(d->N, bn), ssc_cdiv(d->M, bm), splits);
   bool vec = true;  // every segment of both operands must allow 16 B/lane loads, else the 4 B/lane kernel runs
   for (int i = 0; i < k.nseg; ++i) vec = vec && k.seg[i].avec && k.seg[i].bvec;
   gemm_fn fn = big ? (vec ? pick_layout<2, 2, 1, true>(d) : pick_layout<2, 2, 1, false>(d))
-                   : (vec ? pick_layout<1, 1, 2, true>(d) : pick_layout<1, 1, 2, false>(d));
+                   : (vec ? pick_layout<1, 1, 4, true>(d) : pick_layout<1, 1, 2, false>(d));
   ProfRec* rec = nullptr;
   if (g_prof_on && g_prof && g_prof_n < PROF_MAX) {
     rec = &g_prof[g_prof_n++];
@@ -508,20 +523,31 @@ int launch(const ssc_gemm_desc* d, KArgs& k, int splits, hipStream_t st) {
 
 }  // namespace
 
+// Split-K choice by a small cost model fitted to rocprof timings (profiles/r01_c_gemm_shapes.csv, tools/gemm_probe.py):
+// time ~ (workgroups on the busiest CU) x (k-steps per workgroup + fixed per-workgroup cost) / efficiency(occupancy)
+//        + per-slab cost.  One wave per SIMD leaves the MFMA pipe ~45 % busy, three or four ~85-90 %.
 extern "C" int ssc_gemm_auto_splits(int M, int N, int ksteps) {
   const bool big = big_tile(M, N);
-  long tiles = big ? (long)ssc_cdiv(M, 128) * ssc_cdiv(N, 128) : (long)ssc_cdiv(M, BM) * ssc_cdiv(N, BN);
-  const long want = big ? 480 : 640;  // resident workgroup slots we try to fill (2 resp. 4 per CU) 
-  if (tiles >= (big ? 300 : 384)) return 1;
-  int s = (int)((want + tiles - 1) / tiles);
-  int maxs = ksteps / 6;  // keep >= 6 k-steps (192 of K) per workgroup
-  if (s > maxs) s = maxs;
-  if (s > 32) s = 32;
-  if (s < 1) s = 1;
-  // no empty trailing split
-  int per = ssc_cdiv(ksteps, s);
-  s = ssc_cdiv(ksteps, per);
-  return s;
+  const long tiles = big ? (long)ssc_cdiv(M, 128) * ssc_cdiv(N, 128) : (long)ssc_cdiv(M, BM) * ssc_cdiv(N, BN);
+  const int occ = big ? 2 : 4;                         // resident workgroups per CU
+  static const float eff_small[5] = {0.f, 0.45f, 0.70f, 0.85f, 0.90f};
+  static const float eff_big[3] = {0.f, 0.55f, 0.85f};
+  const float fixed = big ? 3.f : 6.f;                 // prologue/epilogue per workgroup, in k-steps
+  const float slab = big ? 2.5f : 0.4f;                // write + re-read of one partial slab, in k-steps
+  int best = 1;
+  float best_cost = 1e30f;
+  const int smax = ksteps / (big ? 8 : 4) < 1 ? 1 : ksteps / (big ? 8 : 4);
+  for (int s = 1; s <= 40 && s <= smax; ++s) {
+    const int per = ssc_cdiv(ksteps, s);
+    if (ssc_cdiv(ksteps, per) != s) continue;          // would leave an empty trailing split
+    const long wgs = tiles * s;
+    const int c = (int)((wgs + 255) / 256);            // workgroups on the busiest CU
+    const int resident = c < occ ? c : occ;
+    const float eff = big ? eff_big[resident] : eff_small[resident];
+    float cost = (float)c * ((float)per + fixed) / eff + (s > 1 ? slab * s : 0.f);
+    if (cost < best_cost) { best_cost = cost; best = s; }
+  }
+  return best;
 }
 
 // partial slabs only: slabs[z] is (M,N) with ld N.  Used by the fused epilogue kernels.
@@ -539,6 +565,40 @@ int ssc_gemm_slabs(const ssc_gemm_desc* d, int splits, float* slabs, hipStream_t
   return launch(d, k, splits, st);
 }
 
+// Skinny GEMM for a fused epilogue: leaves its split-K slabs (M x N, ld N) in `slabs`.  Segments that allow
+// 16 B/lane loads and segments that do not (e.g. the z-block of W_ih^dec, which starts at an odd column when the
+// sentiment column is present) go to separate launches, so one misaligned segment does not push the whole product
+// onto the 4 B/lane kernel.  *nslab = total number of slabs written.
+int ssc_gemm_slabs_auto(const ssc_gemm_desc* d, float* slabs, size_t cap_floats, int* nslab, hipStream_t st) {
+  KArgs k;
+  SSC_TRY(build_args(d, k));
+  ssc_gemm_desc part[2];
+  int np[2] = {0, 0};
+  for (int g = 0; g < 2; ++g) { part[g] = *d; part[g].nseg = 0; }
+  for (int i = 0; i < k.nseg; ++i) {
+    int g = (k.seg[i].avec && k.seg[i].bvec) ? 0 : 1;
+    part[g].seg[np[g]++] = d->seg[i];
+  }
+  if (np[0] == 0 || np[1] == 0) { np[0] = d->nseg; np[1] = 0; part[0] = *d; }
+  const size_t mn = (size_t)d->M * d->N;
+  int total = 0;
+  for (int g = 0; g < 2; ++g) {
+    if (!np[g]) continue;
+    part[g].nseg = np[g];
+    int ksteps = 0;
+    for (int i = 0; i < np[g]; ++i) ksteps += ssc_cdiv(part[g].seg[i].K, BK);
+    int splits = ssc_gemm_auto_splits(d->M, d->N, ksteps);
+    while (splits > 1 && (size_t)(total + splits) * mn > cap_floats) --splits;
+    if ((size_t)(total + splits) * mn > cap_floats) return SSC_EWORKSPACE;
+    int per = ssc_cdiv(ksteps, splits);
+    splits = ssc_cdiv(ksteps, per);
+    SSC_TRY(ssc_gemm_slabs(&part[g], splits, slabs + (size_t)total * mn, st));
+    total += splits;
+  }
+  *nslab = total;
+  return SSC_OK;
+}
+
 extern "C" int ssc_gemm(const ssc_gemm_desc* d, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   KArgs k;
@@ -553,7 +613,11 @@ extern "C" int ssc_gemm(const ssc_gemm_desc* d, void* stream) {
   }
   if (splits > 1 && (!d->workspace || d->workspace_floats < (size_t)splits * d->M * d->N)) {
     if (d->splits > 1) return SSC_EWORKSPACE;
-    splits = 1;  // auto mode without (enough) workspace: fall back to one pass
+    // auto mode with a small workspace: the largest split count that fits (1 = single pass)
+    splits = d->workspace ? (int)(d->workspace_floats / ((size_t)d->M * d->N)) : 1;
+    if (splits < 1) splits = 1;
+    int per = ssc_cdiv(k.steps_total, splits);
+    splits = ssc_cdiv(k.steps_total, per);
   }
   if (splits == 1) {
     k.out = d->C;

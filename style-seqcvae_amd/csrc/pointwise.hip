@@ -92,7 +92,18 @@ __global__ void lstm_fwd_kernel(const ssc_lstm_fwd_desc d) {
   for (int g = 0; g < 4; ++g) {
     int n = g * H + j;
     float v = 0.f;
-    for (int s = 0; s < d.nslab; ++s) v += d.slabs[(size_t)s * d.slab_stride + (size_t)b * H4 + n];
+    // slabs are summed in index order, 8 independent loads in flight at a time (a plain `v += load` loop with a
+    // dynamic trip count serialises the load latencies)
+    for (int s0 = 0; s0 < d.nslab; s0 += 8) {
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        int sc = min(s0 + u, d.nslab - 1);
+        t[u] = d.slabs[(size_t)sc * d.slab_stride + (size_t)b * H4 + n];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v += (s0 + u < d.nslab) ? t[u] : 0.f;
+    }
     if (d.add0) v += d.add0[(size_t)b * d.ld_add0 + n];
     if (d.add1) v += d.add1[(size_t)(b / d.rows_per_add1) * d.ld_add1 + n];
     if (d.b_ih) v += d.b_ih[n];

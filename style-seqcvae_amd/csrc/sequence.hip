@@ -68,7 +68,7 @@ Layout make_layout(const ssc_model_cfg* c, int B, int R, int L) {
   l.mulv = l.take((size_t)B * 2 * l.Z);
   // slab workspace: skinny GEMMs use up to 32 splits of (B x 4H); full GEMMs never exceed ~1024 tiles * 4096
   size_t skinny = (size_t)33 * B * l.H4;
-  size_t full = (size_t)1100 * 4096;
+  size_t full = (size_t)16 * 1024 * 1024;  // 64 MB: split-K slabs of the large GEMMs
   l.slab_floats = skinny > full ? skinny : full;
   l.slabs = l.take(l.slab_floats);
   l.logits = l.take(TB * l.Vp);
@@ -133,16 +133,7 @@ int gemm(const Ctx& c, bool a_kc, bool b_kc, std::initializer_list<Seg> segs, in
 int gemm_to_slabs(const Ctx& c, std::initializer_list<Seg> segs, int M, int N, int* nslab) {
   ssc_gemm_desc d;
   fill_desc(d, true, true, segs, M, N);
-  int ksteps = 0;
-  for (int i = 0; i < d.nseg; ++i) ksteps += ssc_cdiv(d.seg[i].K, 32);
-  int splits = ssc_gemm_auto_splits(M, N, ksteps);
-  while (splits > 1 && (size_t)splits * M * N > c.slab_floats) --splits;
-  {
-    int per = ssc_cdiv(ksteps, splits);
-    splits = ssc_cdiv(ksteps, per);
-  }
-  *nslab = splits;
-  return ssc_gemm_slabs(&d, splits, c.slabs, c.st);
+  return ssc_gemm_slabs_auto(&d, c.slabs, c.slab_floats, nslab, c.st);
 }
 
 int check_cfg(const ssc_model_cfg* c, const ssc_params* p, const ssc_batch* b) {

@@ -44,3 +44,4 @@ __device__ __forceinline__ float ssc_sigmoid(float x) { return 1.0f / (1.0f + ex
 
 // internal cross-TU entry points (not part of the C ABI)
 int ssc_gemm_slabs(const ssc_gemm_desc* d, int splits, float* slabs, hipStream_t st);  // partial slabs only
+int ssc_gemm_slabs_auto(const ssc_gemm_desc* d, float* slabs, size_t cap_floats, int* nslab, hipStream_t st);
