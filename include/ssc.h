@@ -69,6 +69,14 @@ typedef struct {
 
 int ssc_gemm(const ssc_gemm_desc* d, void* stream);
 
+/* Numerics of NT products (a_kc = b_kc = 1, 16-B aligned operands): mode 1 (default) splits every fp32 operand exactly
+ * into three bf16 pieces and sums the six partial products of order <= 2 on v_mfma_f32_32x32x16_bf16 with fp32
+ * accumulation (error ~ one fp32 rounding per product); mode 0 uses the exact-fp32 MFMA v_mfma_f32_32x32x2_f32.
+ * Process-wide; returns the previous mode.  Environment default: SSC_GEMM_MODE=x3|f32. */
+int ssc_set_gemm_mode(int mode);
+/* tuning hook: minimum N at which M<=64 products use the 64x128 block tile; returns the previous value */
+int ssc_set_gemm_wide_min_n(int n);
+
 /* In-situ GEMM profiling for bench.py's roofline leg (process-global switch, not thread-safe, off by default):
  * while enabled every GEMM launch is bracketed by a hipEvent pair on its stream.  ssc_prof_collect synchronises the
  * device and writes up to max_records x 6 floats {kind (0 NT,1 NN,3 TN), M, N, sum K, splits, milliseconds}. */

@@ -263,6 +263,8 @@ struct Stage<A_KC, B_KC, RA, RB, true> {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER) : "memory");
     if constexpr (NVA == 2 && NVB == 2) {
       asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1])::"memory");
+    } else if constexpr (NVA == 2 && NVB == 4) {
+      asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3])::"memory");
     } else {
       static_assert(NVA == 4 && NVB == 4, "unsupported tile");
       asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3])::"memory");
@@ -425,6 +427,176 @@ __global__ __launch_bounds__(256) void gemm_kernel(const KArgs a) {
   }
 }
 
+// =====================================================================================================
+// "3xBF16" NT kernel: fp32-accurate GEMM on the bf16 matrix cores.
+//
+// Every fp32 operand is split EXACTLY into three bf16 pieces x = hi + mid + lo (8 significant bits each, by
+// truncation: hi = x & 0xffff0000, mid = (x-hi) & 0xffff0000, lo = x-hi-mid, which has <= 8 significant bits left and
+// is itself a bf16).  a*b is then the sum of the six partial products of order <= 2 (hi*hi, hi*mid, mid*hi, hi*lo,
+// lo*hi, mid*mid), each exact in fp32 (8+8 significand bits), accumulated in fp32 by
+// v_mfma_f32_32x32x16_bf16; the dropped terms (mid*lo, lo*mid, lo*lo) are <= 2^-23 |a*b|, i.e. the size of one
+// fp32 rounding.  Six bf16 MFMAs (32 cycles, K=16) replace sixteen fp32 MFMAs (64 cycles, K=2) per K=32:
+// 384 vs 1024 matrix-pipe cycles, which moves the skinny (M = minibatch) gate GEMMs from fp32-MFMA-bound to
+// HBM-bound - the regime BASELINE.json's roofline target is quoted in.  Operands stay fp32 in HBM (4 B/weight
+// streamed once); the split happens in registers on the way into LDS.  tests/test_gemm_gpu.py bounds the error
+// against float64 next to the exact-fp32 MFMA path.
+//
+// Layout: 64x64 block tile, 2x2 waves of 32x32; BK = 32; per operand three LDS planes [row][32 bf16 + 8 pad]
+// (80-B rows: the 16-lane ds_read_b128 groups hit 16 distinct 16-B slots); A/B fragments of
+// v_mfma_f32_32x32x16_bf16 are 8 consecutive k of one row = one ds_read_b128 per plane.
+// =====================================================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int PL_ROW_B = 80;               // bytes per LDS plane row (32 bf16 + 16 B pad)
+constexpr int PL_BYTES = 64 * PL_ROW_B;    // one plane of a 64-row operand tile
+constexpr int X3_STAGE_B = 6 * PL_BYTES;   // A(hi,mid,lo) + B(hi,mid,lo)
+
+// split 4 consecutive fp32 (one float4 of k) into the three bf16 planes, packed two bf16 per dword
+__device__ __forceinline__ void split4(const f32x4& v, u32x2& hi, u32x2& mid, u32x2& lo) {
+  unsigned u[4], m[4], l[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float x = v[i];
+    const unsigned xu = __float_as_uint(x);
+    u[i] = xu & 0xffff0000u;
+    const float r1 = x - __uint_as_float(u[i]);
+    m[i] = __float_as_uint(r1) & 0xffff0000u;
+    const float r2 = r1 - __uint_as_float(m[i]);
+    l[i] = __float_as_uint(r2);  // <= 8 significant bits: exact as bf16 (low 16 bits are zero)
+  }
+  hi[0] = (u[0] >> 16) | u[1];  hi[1] = (u[2] >> 16) | u[3];
+  mid[0] = (m[0] >> 16) | m[1]; mid[1] = (m[2] >> 16) | m[3];
+  lo[0] = (l[0] >> 16) | (l[1] & 0xffff0000u); lo[1] = (l[2] >> 16) | (l[3] & 0xffff0000u);
+}
+
+template <int PF>
+__global__ __launch_bounds__(256) void gemm_x3_kernel(const KArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * X3_STAGE_B];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int half = lane >> 5, l31 = lane & 31;
+  int bx = blockIdx.x, by = blockIdx.y;
+  {
+    const int gx = gridDim.x, total = gridDim.x * gridDim.y;
+    const int lin = by * gx + bx;
+    const int q = total >> 3, rem = total & 7;
+    const int xcd = lin & 7, slot = lin >> 3;
+    const int nl = xcd * q + (xcd < rem ? xcd : rem) + slot;
+    by = nl / gx;
+    bx = nl - by * gx;
+  }
+  const int n0 = bx * 64, m0 = by * 64, z = blockIdx.z;
+  const int s_lo = z * a.steps_per_split;
+  int s_hi = s_lo + a.steps_per_split;
+  if (s_hi > a.steps_total) s_hi = a.steps_total;
+
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+  typedef Stage<true, true, 64, 64, true> StageT;
+  constexpr int NL = StageT::NLOADS;
+  StageT st[PF];
+  const int s_last = s_hi - 1;
+
+  // registers -> three bf16 planes per operand (k-range select applied here, as in the fp32 kernel)
+  auto put_planes = [&](unsigned char* base, const StageT& x) {
+#pragma unroll
+    for (int op = 0; op < 2; ++op) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int idx = tid + 256 * u;
+        const int row = idx >> 3, kq = idx & 7;
+        const bool ok = ((op == 0 ? x.oka : x.okb) >> u) & 1u;
+        f32x4 v = op == 0 ? x.a[u] : x.b[u];
+        if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        u32x2 hi, mid, lo;
+        split4(v, hi, mid, lo);
+        unsigned char* p = base + op * 3 * PL_BYTES + row * PL_ROW_B + kq * 8;
+        *reinterpret_cast<u32x2*>(p) = hi;
+        *reinterpret_cast<u32x2*>(p + PL_BYTES) = mid;
+        *reinterpret_cast<u32x2*>(p + 2 * PL_BYTES) = lo;
+      }
+    }
+  };
+
+  Cursor cur;
+  int s_ld = s_lo;
+  if (s_lo < s_hi) {
+    cur.init(a, s_lo);
+    st[0].load(a, cur, m0, n0, tid);
+    st[0].template wait<0>();
+    put_planes(lds, st[0]);
+#pragma unroll
+    for (int j = 0; j < PF; ++j) {
+      cur.advance(a, s_ld >= s_last); s_ld = min(s_ld + 1, s_last);
+      st[j].load(a, cur, m0, n0, tid);
+    }
+  }
+  __syncthreads();
+
+  auto compute = [&](int buf) {
+    const unsigned char* pa = lds + buf * X3_STAGE_B + (wm * 32 + l31) * PL_ROW_B + half * 16;
+    const unsigned char* pb = lds + buf * X3_STAGE_B + 3 * PL_BYTES + (wn * 32 + l31) * PL_ROW_B + half * 16;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(pa + kk * 32));
+      bf16x8 am = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(pa + PL_BYTES + kk * 32));
+      bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(pa + 2 * PL_BYTES + kk * 32));
+      bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(pb + kk * 32));
+      bf16x8 bm = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(pb + PL_BYTES + kk * 32));
+      bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(pb + 2 * PL_BYTES + kk * 32));
+      // smallest partial products first
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+    }
+  };
+
+  constexpr int U = PF > 2 ? PF : 2;
+  for (int s = s_lo; s < s_hi; s += U) {
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      if (s + j < s_hi) {
+        StageT& x = st[j % PF];
+        compute(j & 1);
+        x.template wait<(PF - 1) * NL>();
+        if (s + j + 1 < s_hi) put_planes(lds + ((j + 1) & 1) * X3_STAGE_B, x);
+        cur.advance(a, s_ld >= s_last); s_ld = min(s_ld + 1, s_last);
+        x.load(a, cur, m0, n0, tid);
+        __syncthreads();
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  float* out = a.out + (size_t)z * a.slab_stride;
+  const int col = n0 + wn * 32 + l31;
+  if (col < a.N) {
+    const float bv = (a.bias != nullptr) ? a.bias[col] : 0.f;
+    const int rbase = m0 + wm * 32 + 4 * half;
+    float old[16];
+    if (a.accumulate) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) old[r] = out[(size_t)min(rbase + (r & 3) + 8 * (r >> 2), a.M - 1) * a.ldo + col];
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) old[r] = 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int row = rbase + (r & 3) + 8 * (r >> 2);
+      if (row < a.M) out[(size_t)row * a.ldo + col] = acc[r] + bv + old[r];
+    }
+  }
+}
+
 __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int nslab, size_t slab_stride, int M, int N,
                                     float* __restrict__ C, int ldc, const float* __restrict__ bias, int accumulate) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -491,7 +663,23 @@ gemm_fn pick_layout(const ssc_gemm_desc* d) {
 }
 
 // tile choice: 128x128 (2x2 MFMA tiles per wave) when both dimensions are large, else 64x64 with a deeper prefetch
+// SSC_GEMM_MODE: "x3" (default) = 3xBF16 split kernel for NT products with 16 B/lane operands, "f32" = exact fp32 MFMA
+int g_gemm_mode = -1;  // -1: take the default from the environment on first use
+inline int gemm_mode() {
+  if (g_gemm_mode < 0) {
+    const char* e = getenv("SSC_GEMM_MODE");
+    g_gemm_mode = (e && e[0] == 'f') ? 0 : 1;
+  }
+  return g_gemm_mode;
+}
+inline bool use_x3(const ssc_gemm_desc* d, bool vec) { return gemm_mode() == 1 && d->a_kc && d->b_kc && vec; }
 inline bool big_tile(int M, int N) { return M >= 512 && N >= 512; }
+// M <= 64 with a wide N: 64x128 block tile (wave tile 32x64).  Every workgroup re-reads the whole A operand
+// (the minibatch activations, from L2) for its K-range, and the CU-side load path (~24 GB/s per CU) is what these
+// products run into first (rocprof r01: loads per CU saturate with A+B at BN=64), so halving the A re-reads per
+// streamed weight byte matters more than occupancy.
+int g_wide_min_n = 1024;
+inline bool wide_tile(int M, int N) { return M <= 64 && N >= g_wide_min_n; }
 
 int launch(const ssc_gemm_desc* d, KArgs& k, int splits, hipStream_t st) {
   k.steps_per_split = ssc_cdiv(k.steps_total, splits);
@@ -499,13 +687,29 @@ int launch(const ssc_gemm_desc* d, KArgs& k, int splits, hipStream_t st) {
     static const int dbg = getenv("SSC_GEMM_DBG") ? atoi(getenv("SSC_GEMM_DBG")) : 0;
     k.dbg = dbg;
   }
-  const bool big = big_tile(d->M, d->N);
-  const int bm = big ? 128 : 64, bn = big ? 128 : 64;
-  dim3 grid(ssc_cdiv(d->N, bn), ssc_cdiv(d->M, bm), splits);
   bool vec = true;  // every segment of both operands must allow 16 B/lane loads, else the 4 B/lane kernel runs
   for (int i = 0; i < k.nseg; ++i) vec = vec && k.seg[i].avec && k.seg[i].bvec;
+  if (use_x3(d, vec)) {
+    dim3 grid(ssc_cdiv(d->N, 64), ssc_cdiv(d->M, 64), splits);
+    ProfRec* rec = nullptr;
+    if (g_prof_on && g_prof && g_prof_n < PROF_MAX) {
+      rec = &g_prof[g_prof_n++];
+      rec->kind = 0; rec->M = d->M; rec->N = d->N; rec->splits = splits; rec->K = 0;
+      for (int i = 0; i < d->nseg; ++i) rec->K += d->seg[i].K;
+      (void)hipEventRecord(rec->e0, st);
+    }
+    hipLaunchKernelGGL(gemm_x3_kernel<2>, grid, dim3(256), 0, st, k);
+    if (rec) (void)hipEventRecord(rec->e1, st);
+    SSC_CHECK_LAUNCH();
+    return SSC_OK;
+  }
+  const bool big = big_tile(d->M, d->N);
+  const bool wide = !big && vec && wide_tile(d->M, d->N);
+  const int bm = big ? 128 : 64, bn = (big || wide) ? 128 : 64;
+  dim3 grid(ssc_cdiv(d->N, bn), ssc_cdiv(d->M, bm), splits);
   gemm_fn fn = big ? (vec ? pick_layout<2, 2, 1, true>(d) : pick_layout<2, 2, 1, false>(d))
-                   : (vec ? pick_layout<1, 1, 4, true>(d) : pick_layout<1, 1, 2, false>(d));
+                   : wide ? pick_layout<1, 2, 2, true>(d)
+                          : (vec ? pick_layout<1, 1, 4, true>(d) : pick_layout<1, 1, 2, false>(d));
   ProfRec* rec = nullptr;
   if (g_prof_on && g_prof && g_prof_n < PROF_MAX) {
     rec = &g_prof[g_prof_n++];
@@ -528,8 +732,10 @@ int launch(const ssc_gemm_desc* d, KArgs& k, int splits, hipStream_t st) {
 //        + per-slab cost.  One wave per SIMD leaves the MFMA pipe ~45 % busy, three or four ~85-90 %.
 extern "C" int ssc_gemm_auto_splits(int M, int N, int ksteps) {
   const bool big = big_tile(M, N);
-  const long tiles = big ? (long)ssc_cdiv(M, 128) * ssc_cdiv(N, 128) : (long)ssc_cdiv(M, BM) * ssc_cdiv(N, BN);
-  const int occ = big ? 2 : 4;                         // resident workgroups per CU
+  const bool wide = !big && wide_tile(M, N);
+  const long tiles = big ? (long)ssc_cdiv(M, 128) * ssc_cdiv(N, 128)
+                         : (long)ssc_cdiv(M, BM) * ssc_cdiv(N, wide ? 128 : BN);
+  const int occ = (big || wide) ? 2 : 4;               // resident workgroups per CU
   static const float eff_small[5] = {0.f, 0.45f, 0.70f, 0.85f, 0.90f};
   static const float eff_big[3] = {0.f, 0.55f, 0.85f};
   const float fixed = big ? 3.f : 6.f;                 // prologue/epilogue per workgroup, in k-steps
@@ -543,7 +749,7 @@ extern "C" int ssc_gemm_auto_splits(int M, int N, int ksteps) {
     const long wgs = tiles * s;
     const int c = (int)((wgs + 255) / 256);            // workgroups on the busiest CU
     const int resident = c < occ ? c : occ;
-    const float eff = big ? eff_big[resident] : eff_small[resident];
+    const float eff = (big || wide) ? eff_big[resident] : eff_small[resident];
     float cost = (float)c * ((float)per + fixed) / eff + (s > 1 ? slab * s : 0.f);
     if (cost < best_cost) { best_cost = cost; best = s; }
   }
@@ -667,4 +873,19 @@ extern "C" int ssc_prof_collect(float* out, int max_records) {
   }
   g_prof_n = 0;
   return n;
+}
+
+// Process-wide numerics switch for NT products: 1 = 3xBF16 split on the bf16 matrix cores (default, fp32-accurate),
+// 0 = exact-fp32 MFMA (v_mfma_f32_32x32x2_f32).  Returns the previous mode.  Default from SSC_GEMM_MODE=f32|x3.
+extern "C" int ssc_set_gemm_mode(int mode) {
+  int prev = gemm_mode();
+  if (mode == 0 || mode == 1) g_gemm_mode = mode;
+  return prev;
+}
+
+// tuning hook (tools/gemm_probe.py): minimum N for the 64x128 skinny tile; returns the previous value
+extern "C" int ssc_set_gemm_wide_min_n(int n) {
+  int prev = g_wide_min_n;
+  if (n > 0) g_wide_min_n = n;
+  return prev;
 }

@@ -102,6 +102,8 @@ SYMBOLS = {
     "ssc_arch": (C.c_char_p, []),
     "ssc_gemm": (_i, [C.POINTER(GemmDesc), vp]),
     "ssc_gemm_auto_splits": (_i, [_i, _i, _i]),
+    "ssc_set_gemm_mode": (_i, [_i]),
+    "ssc_set_gemm_wide_min_n": (_i, [_i]),
     "ssc_prof_enable": (_i, [_i]),
     "ssc_prof_collect": (_i, [vp, _i]),
     "ssc_feat_prep": (_i, [vp, _i, _i, _i, vp, vp, vp]),
@@ -157,7 +159,7 @@ class _Lib:
         raw = self.__dict__.get("_raw_" + name)
         if raw is None:
             raise AttributeError(name)
-        if raw.restype is not C.c_int or name in ("ssc_version", "ssc_last_hip_error", "ssc_gemm_auto_splits", "ssc_prof_collect"):
+        if raw.restype is not C.c_int or name in ("ssc_version", "ssc_last_hip_error", "ssc_gemm_auto_splits", "ssc_prof_collect", "ssc_set_gemm_mode", "ssc_set_gemm_wide_min_n"):
             return raw
 
         def checked(*a):

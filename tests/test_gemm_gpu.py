@@ -68,3 +68,42 @@ def test_gemm_exact_small_integers():
     Bt = torch.randint(-3, 4, (M, N), generator=g).float()
     gemm([(dev(A), K, dev(Bt), N, M)], K, N, 0, 0, out2)
     assert torch.equal(out2.cpu(), A.t() @ Bt)
+
+
+@pytest.mark.parametrize("M,N,Ks", [(64, 4800, [2048, 1200, 1200, 1200]), (64, 768, [1200]), (1344, 1000, [1200]),
+                                    (70, 130, [100, 36])])
+def test_nt_split_bf16_is_fp32_accurate(M, N, Ks):
+    """The 3xBF16 split kernel (default for NT) against float64, next to the exact-fp32 MFMA kernel: its error must
+    stay within 2x the fp32 kernel's and within 2e-6 relative to sum|a||b| (data with a wide dynamic range)."""
+    from ssc_runtime import lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(M + N)
+    As = [torch.randn(M, K, generator=g) * torch.exp(2 * torch.randn(M, K, generator=g)) for K in Ks]
+    Bs = [torch.randn(N, K, generator=g) * torch.exp(2 * torch.randn(N, K, generator=g)) / 50 for K in Ks]
+    want = ref(As, Bs, 1, 1)
+    scale = sum(a.double().abs() @ b.double().abs().t() for a, b in zip(As, Bs))
+    dA, dB = [dev(a) for a in As], [dev(b) for b in Bs]
+    segs = [(a, a.stride(0), b, b.stride(0), K) for a, b, K in zip(dA, dB, Ks)]
+    ws = torch.empty(40 * M * N + 64, device="cuda")
+    errs = {}
+    prev = lib.ssc_set_gemm_mode(1)
+    try:
+        for mode in (1, 0):
+            lib.ssc_set_gemm_mode(mode)
+            out = torch.full((M, N), float("nan"), device="cuda")
+            gemm(segs, M, N, 1, 1, out, ws=ws)
+            errs[mode] = ((out.cpu().double() - want).abs() / scale).max().item()
+    finally:
+        lib.ssc_set_gemm_mode(prev)
+    assert errs[1] < 2e-6, errs
+    assert errs[1] <= 2.0 * errs[0] + 1e-8, errs
+
+
+def test_nt_split_bf16_exact_on_small_integers():
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 96, 160, 72
+    A = torch.randint(-200, 201, (M, K), generator=g).float()   # needs hi+mid pieces
+    B = torch.randint(-200, 201, (N, K), generator=g).float()
+    out = torch.empty(M, N, device="cuda")
+    gemm([(dev(A), K, dev(B), K, K)], M, N, 1, 1, out)
+    assert torch.equal(out.cpu(), A @ B.t())
