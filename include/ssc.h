@@ -140,6 +140,10 @@ typedef struct {
   float* dG;                   /* (B,4H) ld 4H */
   float* dc_prev; int ld_dcprev;
   float* dgsum;                /* optional (B,4H) running sum over time */
+  /* optional extra addends of dh given as split-K partial slabs ((B,H), ld H each) of the GEMMs that produce them:
+   * dh += sum_s slabsA[s] + sum_s slabsB[s]  (fixed summation order) */
+  const float* slabsA; int nA; size_t strideA;
+  const float* slabsB; int nB; size_t strideB;
 } ssc_lstm_bwd_desc;
 int ssc_lstm_bwd(const ssc_lstm_bwd_desc* d, void* stream);
 
@@ -195,6 +199,7 @@ typedef struct {
   int kld_mode; const float* sent; float pm_scale; float prior_var;
   const float* w; const float* gk; /* (B) step weights, (B) upstream grad of kld_b */
   float* dmulv; int lddmulv;
+  int nslab; size_t slab_stride; /* nslab > 1: dz is the first of nslab split-K slabs ((B, lddz) each) to be summed */
 } ssc_latent_bwd_desc;
 int ssc_latent_bwd(const ssc_latent_bwd_desc* d, void* stream);
 

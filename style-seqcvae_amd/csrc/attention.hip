@@ -14,7 +14,11 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void attn_logits_kernel(const float* __restrict__ q, int ldq,
+// q may arrive as `nslab` split-K partial slabs of the q-projection GEMM ((G,A), ld A each): every wave sums the slabs
+// for the a-range it needs (fixed order) and the r == 0 wave of each row writes the reduced q for the backward pass -
+// this replaces a separate reduce launch per timestep.
+__global__ __launch_bounds__(256) void attn_logits_kernel(const float* __restrict__ q, int ldq, int nslab, size_t slab_stride,
+                                                          float* __restrict__ q_out, int ldqo,
                                                           const float* __restrict__ pv, const float* __restrict__ wa,
                                                           int G, int R, int A, int rows_per_image,
                                                           float* __restrict__ logits) {
@@ -26,15 +30,26 @@ __global__ __launch_bounds__(256) void attn_logits_kernel(const float* __restric
   const float* qp = q + (size_t)g * ldq;
   const float* pp = pv + ((size_t)img * R + r) * A;
   float s = 0.f;
-  if (((A & 3) == 0) && ((ldq & 3) == 0) && ssc_aligned16_dev(qp) && ssc_aligned16_dev(pp) && ssc_aligned16_dev(wa)) {
+  if (((A & 3) == 0) && ((ldq & 3) == 0) && ((ldqo & 3) == 0) && ((slab_stride & 3) == 0) && ssc_aligned16_dev(qp) &&
+      ssc_aligned16_dev(pp) && ssc_aligned16_dev(wa) && ssc_aligned16_dev(q_out)) {
     for (int a = lane * 4; a < A; a += 256) {
       float4 qv = *reinterpret_cast<const float4*>(qp + a);
+      for (int sl = 1; sl < nslab; ++sl) {
+        float4 t = *reinterpret_cast<const float4*>(qp + sl * slab_stride + a);
+        qv.x += t.x; qv.y += t.y; qv.z += t.z; qv.w += t.w;
+      }
+      if (q_out && r == 0) *reinterpret_cast<float4*>(q_out + (size_t)g * ldqo + a) = qv;
       float4 p4 = *reinterpret_cast<const float4*>(pp + a);
       float4 w4 = *reinterpret_cast<const float4*>(wa + a);
       s += w4.x * tanhf(qv.x + p4.x) + w4.y * tanhf(qv.y + p4.y) + w4.z * tanhf(qv.z + p4.z) + w4.w * tanhf(qv.w + p4.w);
     }
   } else {
-    for (int a = lane; a < A; a += 64) s += wa[a] * tanhf(qp[a] + pp[a]);
+    for (int a = lane; a < A; a += 64) {
+      float qv = qp[a];
+      for (int sl = 1; sl < nslab; ++sl) qv += qp[sl * slab_stride + a];
+      if (q_out && r == 0) q_out[(size_t)g * ldqo + a] = qv;
+      s += wa[a] * tanhf(qv + pp[a]);
+    }
   }
   s = ssc_wave_sum(s);
   if (lane == 0) logits[wid] = s;
@@ -236,8 +251,8 @@ __global__ __launch_bounds__(256) void attn_bwd_apply_kernel(const float* __rest
 extern "C" int ssc_attn_logits(const float* q, int ldq, const float* pv, const float* wa, int G, int R, int A,
                                int rows_per_image, float* logits, void* stream) {
   if (!q || !pv || !wa || !logits || G <= 0 || R <= 0 || A <= 0 || rows_per_image <= 0 || ldq < A) return SSC_EINVAL;
-  hipLaunchKernelGGL(attn_logits_kernel, dim3(ssc_cdiv(G * R, 4)), dim3(256), 0, (hipStream_t)stream, q, ldq, pv, wa, G, R,
-                     A, rows_per_image, logits);
+  hipLaunchKernelGGL(attn_logits_kernel, dim3(ssc_cdiv(G * R, 4)), dim3(256), 0, (hipStream_t)stream, q, ldq, 1, (size_t)0,
+                     (float*)nullptr, 0, pv, wa, G, R, A, rows_per_image, logits);
   SSC_CHECK_LAUNCH();
   return SSC_OK;
 }
@@ -250,6 +265,21 @@ extern "C" int ssc_attn_fwd(const float* q, int ldq, const float* pv, const floa
   SSC_TRY(ssc_attn_logits(q, ldq, pv, wa, G, R, A, rows_per_image, logits, stream));
   hipLaunchKernelGGL(attn_apply_kernel, dim3(ssc_cdiv(F, 256), G), dim3(64), 0, (hipStream_t)stream, logits, mask, feats,
                      G, R, F, rows_per_image, alpha, att, ldatt);
+  SSC_CHECK_LAUNCH();
+  return SSC_OK;
+}
+
+// internal: attention forward with q given as split-K slabs ((G,A) each, ld A); writes the reduced q to q_out (ld ldqo)
+int ssc_attn_fwd_qslabs(const float* qslabs, int nslab, size_t slab_stride, float* q_out, int ldqo, const float* pv,
+                        const float* wa, const float* mask, const float* feats, int G, int R, int A, int F,
+                        int rows_per_image, float* logits, float* alpha, float* att, int ldatt, hipStream_t st) {
+  if (!qslabs || nslab < 1 || !q_out || !pv || !wa || !mask || !feats || !alpha || !att || !logits) return SSC_EINVAL;
+  if (G <= 0 || R <= 0 || A <= 0 || F <= 0 || ldatt < F || ldqo < A || R > 64 * MAXR_LANE) return SSC_EINVAL;
+  hipLaunchKernelGGL(attn_logits_kernel, dim3(ssc_cdiv(G * R, 4)), dim3(256), 0, st, qslabs, A, nslab, slab_stride, q_out,
+                     ldqo, pv, wa, G, R, A, rows_per_image, logits);
+  SSC_CHECK_LAUNCH();
+  hipLaunchKernelGGL(attn_apply_kernel, dim3(ssc_cdiv(F, 256), G), dim3(64), 0, st, logits, mask, feats, G, R, F,
+                     rows_per_image, alpha, att, ldatt);
   SSC_CHECK_LAUNCH();
   return SSC_OK;
 }

@@ -130,6 +130,20 @@ __global__ void lstm_bwd_kernel(const ssc_lstm_bwd_desc d) {
   const int H = d.H, H4 = 4 * d.H;
   float dh = d.dh ? d.dh[(size_t)b * d.ld_dh + j] : 0.f;
   if (d.dh2) dh += d.dh2[(size_t)b * d.ld_dh2 + j];
+  for (int s0 = 0; s0 < d.nA; s0 += 8) {  // split-K slabs of the producing GEMMs, fixed order, 8 loads in flight
+    float t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = d.slabsA[(size_t)min(s0 + u, d.nA - 1) * d.strideA + (size_t)b * H + j];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) dh += (s0 + u < d.nA) ? t[u] : 0.f;
+  }
+  for (int s0 = 0; s0 < d.nB; s0 += 8) {
+    float t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = d.slabsB[(size_t)min(s0 + u, d.nB - 1) * d.strideB + (size_t)b * H + j];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) dh += (s0 + u < d.nB) ? t[u] : 0.f;
+  }
   float dcin = d.dc_in ? d.dc_in[(size_t)b * d.ld_dcin + j] : 0.f;
   const float* g = d.gates + (size_t)b * H4 + j;
   float ig = g[0], fg = g[H], gg = g[2 * H], og = g[3 * H];
@@ -203,6 +217,7 @@ __global__ void latent_bwd_kernel(const ssc_latent_bwd_desc d) {
   float k = d.gk[b] * d.w[b];
   float m = d.mu[(size_t)b * d.ldz + z], l = d.lv[(size_t)b * d.ldz + z];
   float dz = d.dz[(size_t)b * d.lddz + z];
+  for (int sl = 1; sl < d.nslab; ++sl) dz += d.dz[(size_t)sl * d.slab_stride + (size_t)b * d.lddz + z];
   float e = d.eps[(size_t)b * d.ldeps + z];
   float var = expf(l);
   float dmu, dlv;
@@ -464,6 +479,7 @@ extern "C" int ssc_lstm_fwd(const ssc_lstm_fwd_desc* d, void* stream) {
 
 extern "C" int ssc_lstm_bwd(const ssc_lstm_bwd_desc* d, void* stream) {
   if (!d || d->B <= 0 || d->H <= 0 || !d->gates || !d->c_prev || !d->c_new || !d->dG || !d->dc_prev) return SSC_EINVAL;
+  if ((d->nA > 0 && !d->slabsA) || (d->nB > 0 && !d->slabsB) || d->nA < 0 || d->nB < 0) return SSC_EINVAL;
   hipLaunchKernelGGL(lstm_bwd_kernel, dim3(ssc_cdiv(d->H, 128), d->B), dim3(128), 0, S(stream), *d);
   SSC_CHECK_LAUNCH();
   return SSC_OK;

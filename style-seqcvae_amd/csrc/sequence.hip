@@ -28,6 +28,7 @@ struct Layout {
   size_t tok, w, nvalid, sent_all, wcol_e, wcol_d, mask, avg, pv, emb, ga_static, ga_avg;
   size_t h1, c1, he, ce, hd, cd, gates_a, gates_e, gates_d, q, attn_logits, alpha, att, mu, lv, z, mulv;
   size_t slabs, slab_floats, logits, lse, proj;
+  size_t sl_q, sl_mulv, sl_gh1, sl_ghd, sl_ghe, sl_dqw, sl_dhe, sl_dz, small_floats, wsum_att, wsum_dec, wz;
   // backward
   size_t dhdv, dga, dge, dgd, dga_sum, g_h1, g_c1, g_he, g_ce, g_cd, dz, dmulv, dx, dalpha, dq, dpv, dwa, demb, dproj;
 
@@ -71,6 +72,18 @@ Layout make_layout(const ssc_model_cfg* c, int B, int R, int L) {
   size_t full = (size_t)16 * 1024 * 1024;  // 64 MB: split-K slabs of the large GEMMs
   l.slab_floats = skinny > full ? skinny : full;
   l.slabs = l.take(l.slab_floats);
+  // per-consumer slab regions of the small per-step GEMMs whose split-K reduction is fused into their consumer
+  {
+    size_t w = (size_t)(l.Hp > l.Ap ? l.Hp : l.Ap);
+    if ((size_t)2 * l.Z > w) w = (size_t)2 * l.Z;
+    l.small_floats = (size_t)40 * B * w;
+    l.sl_q = l.take(l.small_floats); l.sl_mulv = l.take(l.small_floats);
+    l.sl_gh1 = l.take(l.small_floats); l.sl_ghd = l.take(l.small_floats); l.sl_ghe = l.take(l.small_floats);
+    l.sl_dqw = l.take(l.small_floats); l.sl_dhe = l.take(l.small_floats); l.sl_dz = l.take(l.small_floats);
+  }
+  l.wsum_att = l.take((size_t)l.H4 * l.Hp);   // W_ih^att[:, h1-block] + W_hh^att  (both multiply h1')
+  l.wsum_dec = l.take((size_t)l.H4 * l.Hp);   // W_ih^dec[:, hd-block] + W_hh^dec  (both multiply hd')
+  l.wz = l.take((size_t)l.H4 * l.Zp);         // 16-B aligned copy of the z-block of W_ih^dec
   l.logits = l.take(TB * l.Vp);
   l.lse = l.take(2 * TB);
   l.proj = l.take(l.tied ? TB * l.Ep : 0);
@@ -129,11 +142,37 @@ int gemm(const Ctx& c, bool a_kc, bool b_kc, std::initializer_list<Seg> segs, in
   return ssc_gemm(&d, c.st);
 }
 
-// skinny GEMM that leaves its split-K slabs (M x N, ld N) in the slab workspace for a fused epilogue
-int gemm_to_slabs(const Ctx& c, std::initializer_list<Seg> segs, int M, int N, int* nslab) {
+// GEMM that leaves its split-K slabs (M x N, ld N) in `region` for a fused epilogue / consumer
+int gemm_to_slabs(const Ctx& c, float* region, size_t cap, bool a_kc, bool b_kc, std::initializer_list<Seg> segs, int M,
+                  int N, int* nslab) {
   ssc_gemm_desc d;
-  fill_desc(d, true, true, segs, M, N);
-  return ssc_gemm_slabs_auto(&d, c.slabs, c.slab_floats, nslab, c.st);
+  fill_desc(d, a_kc, b_kc, segs, M, N);
+  return ssc_gemm_slabs_auto(&d, region, cap, nslab, c.st);
+}
+int gemm_to_slabs(const Ctx& c, std::initializer_list<Seg> segs, int M, int N, int* nslab) {
+  return gemm_to_slabs(c, c.slabs, c.slab_floats, true, true, segs, M, N, nslab);
+}
+
+__global__ void add2d_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb, int cols,
+                             float* __restrict__ o, int ldo) {
+  int r = blockIdx.y, x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x < cols) o[(size_t)r * ldo + x] = a[(size_t)r * lda + x] + b[(size_t)r * ldb + x];
+}
+int add2d(const float* a, int lda, const float* b, int ldb, int rows, int cols, float* o, int ldo, hipStream_t st) {
+  hipLaunchKernelGGL(add2d_kernel, dim3(ssc_cdiv(cols, 256), rows), dim3(256), 0, st, a, lda, b, ldb, cols, o, ldo);
+  SSC_CHECK_LAUNCH();
+  return SSC_OK;
+}
+// once per call: pre-summed recurrent blocks and the aligned z-block copy
+int prepare_weight_views(const Layout& l, const ssc_params* p, float* W, hipStream_t st) {
+  const int E = l.E, F = l.F, H = l.H, Z = l.Z, S = l.S, H4 = l.H4;
+  SSC_TRY(add2d(p->att_w_ih + E + F, p->ld_att_w_ih, p->att_w_hh, p->ld_att_w_hh, H4, H, W + l.wsum_att, l.Hp, st));
+  SSC_TRY(add2d(p->dec_w_ih + F + H, p->ld_dec_w_ih, p->dec_w_hh, p->ld_dec_w_hh, H4, H, W + l.wsum_dec, l.Hp, st));
+  if (hipMemcpy2DAsync(W + l.wz, (size_t)l.Zp * sizeof(float), p->dec_w_ih + F + 2 * H + S,
+                       (size_t)p->ld_dec_w_ih * sizeof(float), (size_t)Z * sizeof(float), H4, hipMemcpyDeviceToDevice,
+                       st) != hipSuccess)
+    return SSC_EHIP;
+  return SSC_OK;
 }
 
 int check_cfg(const ssc_model_cfg* c, const ssc_params* p, const ssc_batch* b) {
@@ -216,6 +255,7 @@ extern "C" int ssc_train_fwd(const ssc_model_cfg* cfg, const ssc_params* p, cons
     SSC_TRY(ssc_copy_strided(p->enc_w_ih + F + 2 * H, p->ld_enc_w_ih, H4, W + l.wcol_e, st));
     SSC_TRY(ssc_copy_strided(p->dec_w_ih + F + 2 * H, p->ld_dec_w_ih, H4, W + l.wcol_d, st));
   }
+  SSC_TRY(prepare_weight_views(l, p, W, st));
   const bool fc_adjacent = (p->fc_lv_w == p->fc_mean_w + (size_t)Z * p->ld_fc_mean_w) && p->ld_fc_lv_w == p->ld_fc_mean_w;
 
   // ---- time loop ----------------------------------------------------------------------------------
@@ -235,10 +275,9 @@ extern "C" int ssc_train_fwd(const ssc_model_cfg* cfg, const ssc_params* p, cons
     {
       ssc_lstm_fwd_desc d{};
       d.B = B; d.H = H;
-      if (t > 0) {  // all recurrent inputs are zero at t = 0
+      if (t > 0) {  // all recurrent inputs are zero at t = 0; h1' meets the pre-summed W_ih[:,h1]+W_hh block
         const float* wr = p->att_w_ih + E + F;
-        SSC_TRY(gemm_to_slabs(c, {{h1p, l.Hp, wr, p->ld_att_w_ih, H}, {hdp, l.Hp, wr + H, p->ld_att_w_ih, H},
-                                  {h1p, l.Hp, p->att_w_hh, p->ld_att_w_hh, H}}, B, H4, &ns));
+        SSC_TRY(gemm_to_slabs(c, {{h1p, l.Hp, W + l.wsum_att, l.Hp, H}, {hdp, l.Hp, wr + H, p->ld_att_w_ih, H}}, B, H4, &ns));
         d.slabs = c.slabs; d.nslab = ns; d.slab_stride = (size_t)B * H4;
       }
       d.add0 = W + l.ga_static + (size_t)t * B * H4; d.ld_add0 = H4;
@@ -249,10 +288,11 @@ extern "C" int ssc_train_fwd(const ssc_model_cfg* cfg, const ssc_params* p, cons
       d.c_out = c1n; d.ld_cout = l.Hp; d.h_out = h1n; d.ld_hout = l.Hp;
       SSC_TRY(ssc_lstm_fwd(&d, st));
     }
-    // (ii)+(iii) attention (attention.py:69-95, updown_cell.py:151-158)
-    SSC_TRY(gemm(c, true, true, {{h1n, l.Hp, p->wq, p->ld_wq, H}}, B, A, qt, l.Ap));
-    SSC_TRY(ssc_attn_fwd(qt, l.Ap, W + l.pv, p->wa, W + l.mask, bt->feats, B, R, A, F, 1, W + l.attn_logits,
-                         W + l.alpha + (size_t)t * B * R, att, l.Fp, st));
+    // (ii)+(iii) attention (attention.py:69-95, updown_cell.py:151-158); the q-projection's split-K slabs are summed
+    // inside the logits kernel, which also stores q for the backward pass
+    SSC_TRY(gemm_to_slabs(c, W + l.sl_q, l.small_floats, true, true, {{h1n, l.Hp, p->wq, p->ld_wq, H}}, B, A, &ns));
+    SSC_TRY(ssc_attn_fwd_qslabs(W + l.sl_q, ns, (size_t)B * A, qt, l.Ap, W + l.pv, p->wa, W + l.mask, bt->feats, B, R, A, F, 1,
+                                W + l.attn_logits, W + l.alpha + (size_t)t * B * R, att, l.Fp, st));
     // (iv) encoder LSTM: x_e = [att, h1, hd', (s)] (updown_cell.py:176-194)
     {
       SSC_TRY(gemm_to_slabs(c, {{att, l.Fp, p->enc_w_ih, p->ld_enc_w_ih, F}, {h1n, l.Hp, p->enc_w_ih + F, p->ld_enc_w_ih, H},
@@ -271,15 +311,17 @@ extern "C" int ssc_train_fwd(const ssc_model_cfg* cfg, const ssc_params* p, cons
     // latent head: mean / log_var / z / KL (updown_cell.py:196-208, updown_captioner.py:295-303)
     {
       float* mulv = W + l.mulv;
-      if (fc_adjacent) {
-        SSC_TRY(gemm(c, true, true, {{hen, l.Hp, p->fc_mean_w, p->ld_fc_mean_w, H}}, B, 2 * Z, mulv, 2 * Z));
+      ssc_latent_fwd_desc d{};
+      d.B = B; d.Z = Z;
+      if (fc_adjacent) {  // one (2Z x H) operand; the slabs go straight to the latent epilogue
+        SSC_TRY(gemm_to_slabs(c, W + l.sl_mulv, l.small_floats, true, true, {{hen, l.Hp, p->fc_mean_w, p->ld_fc_mean_w, H}}, B,
+                              2 * Z, &ns));
+        d.mulv = W + l.sl_mulv; d.ldmulv = 2 * Z; d.nslab = ns; d.slab_stride = (size_t)B * 2 * Z;
       } else {
         SSC_TRY(gemm(c, true, true, {{hen, l.Hp, p->fc_mean_w, p->ld_fc_mean_w, H}}, B, Z, mulv, 2 * Z));
         SSC_TRY(gemm(c, true, true, {{hen, l.Hp, p->fc_lv_w, p->ld_fc_lv_w, H}}, B, Z, mulv + Z, 2 * Z));
+        d.mulv = mulv; d.ldmulv = 2 * Z; d.nslab = 1; d.slab_stride = 0;
       }
-      ssc_latent_fwd_desc d{};
-      d.B = B; d.Z = Z;
-      d.mulv = mulv; d.ldmulv = 2 * Z; d.nslab = 1; d.slab_stride = 0;
       d.bmu = p->fc_mean_b; d.blv = p->fc_lv_b;
       d.eps = bt->eps + (size_t)t * B * Z; d.ldeps = Z;
       d.kld_mode = cfg->kld_mode; d.sent = cfg->pm_scale != 0.f ? bt->sentiment : nullptr;
@@ -291,11 +333,9 @@ extern "C" int ssc_train_fwd(const ssc_model_cfg* cfg, const ssc_params* p, cons
     }
     // (vi) decoder LSTM: x_d = [att, h1, hd', (s), z] (updown_cell.py:211-229)
     {
-      const float* wz = p->dec_w_ih + F + 2 * H + S;
+      // hd' meets the pre-summed W_ih[:,hd]+W_hh block; z meets the aligned copy of its weight block
       SSC_TRY(gemm_to_slabs(c, {{att, l.Fp, p->dec_w_ih, p->ld_dec_w_ih, F}, {h1n, l.Hp, p->dec_w_ih + F, p->ld_dec_w_ih, H},
-                                {hdp, l.Hp, p->dec_w_ih + F + H, p->ld_dec_w_ih, t > 0 ? H : 0},
-                                {zt, l.Zp, wz, p->ld_dec_w_ih, Z},
-                                {hdp, l.Hp, p->dec_w_hh, p->ld_dec_w_hh, t > 0 ? H : 0}}, B, H4, &ns));
+                                {hdp, l.Hp, W + l.wsum_dec, l.Hp, t > 0 ? H : 0}, {zt, l.Zp, W + l.wz, l.Zp, Z}}, B, H4, &ns));
       ssc_lstm_fwd_desc d{};
       d.B = B; d.H = H;
       d.slabs = c.slabs; d.nslab = ns; d.slab_stride = (size_t)B * H4;
@@ -353,14 +393,18 @@ extern "C" int ssc_train_bwd(const ssc_model_cfg* cfg, const ssc_params* p, cons
   }
 
   // ---- carried gradients start at zero ----------------------------------------------------------------
-  for (size_t off : {l.g_h1, l.g_c1, l.g_he, l.g_ce, l.g_cd}) SSC_TRY(ssc_fill(W + off, sH, 0.f, st));
+  // g_c1 / g_ce / g_cd are plain (B,H) buffers.  The carried hidden-state gradients are NOT reduced into buffers: the
+  // split-K slabs of the GEMMs that produce them (g_h1', g_hd', g_he', dq Wq, dmu Wmu + dlv Wlv) stay in per-consumer
+  // slab regions and are summed, in a fixed order, inside the LSTM backward kernel that consumes them.
+  for (size_t off : {l.g_c1, l.g_ce, l.g_cd}) SSC_TRY(ssc_fill(W + off, sH, 0.f, st));
   SSC_TRY(ssc_fill(W + l.dx, (size_t)B * XW, 0.f, st));
   SSC_TRY(ssc_fill(W + l.dpv, (size_t)B * R * A, 0.f, st));
   SSC_TRY(ssc_fill(W + l.dwa, (size_t)B * A, 0.f, st));
   SSC_TRY(ssc_fill(W + l.dga_sum, (size_t)B * H4, 0.f, st));
-  float* dx = W + l.dx;            // [datt (F) | dh1 (H) | dhd' (H)] ; the dhd' block doubles as carried g_hd
-  float* g_hd = dx + F + H;        // ld XW
-  const int zcol = F + 2 * H + S;
+  SSC_TRY(prepare_weight_views(l, p, W, st));
+  float* dx = W + l.dx;            // [datt (F) | dh1 (H) | dhd' (H)], ld XW
+  int n_gh1 = 0, n_ghd = 0, n_ghe = 0;  // slab counts carried from step t+1 (none at t = T-1)
+  const size_t sBH = (size_t)B * H;
 
   for (int t = T - 1; t >= 0; --t) {
     float* dgd = W + l.dgd + (size_t)t * B * H4;
@@ -368,12 +412,14 @@ extern "C" int ssc_train_bwd(const ssc_model_cfg* cfg, const ssc_params* p, cons
     float* dga = W + l.dga + (size_t)t * B * H4;
     float* dmulv = W + l.dmulv + (size_t)t * B * 2 * Z;
     float* dq = W + l.dq + (size_t)t * B * l.Ap;
-    // 1. decoder LSTM
+    int ns = 0;
+    // 1. decoder LSTM: dh = dx[hd' block] (step t+1's dGd W_ih^dec[hd] + dGe W_ih^enc[hd]) + g_hd' slabs + vocabulary path
     {
       ssc_lstm_bwd_desc d{};
       d.B = B; d.H = H;
-      d.dh = g_hd; d.ld_dh = XW;
+      d.dh = dx + F + H; d.ld_dh = XW;
       d.dh2 = W + l.dhdv + (size_t)t * B * l.Hp; d.ld_dh2 = l.Hp;
+      d.slabsA = W + l.sl_ghd; d.nA = n_ghd; d.strideA = sBH;
       d.dc_in = W + l.g_cd; d.ld_dcin = l.Hp;
       d.gates = W + l.gates_d + (size_t)t * B * H4;
       d.c_prev = W + l.cd + t * sH; d.ld_cprev = l.Hp;
@@ -381,12 +427,12 @@ extern "C" int ssc_train_bwd(const ssc_model_cfg* cfg, const ssc_params* p, cons
       d.dG = dgd; d.dc_prev = W + l.g_cd; d.ld_dcprev = l.Hp;
       SSC_TRY(ssc_lstm_bwd(&d, st));
     }
-    // 2-3. dz and the latent head
-    SSC_TRY(gemm(c, true, false, {{dgd, H4, p->dec_w_ih + zcol, p->ld_dec_w_ih, H4}}, B, Z, W + l.dz, l.Zp));
+    // 2-3. dz = dGd W_ih^dec[:, z-block] (aligned copy), summed inside the latent backward
+    SSC_TRY(gemm_to_slabs(c, W + l.sl_dz, l.small_floats, true, false, {{dgd, H4, W + l.wz, l.Zp, H4}}, B, Z, &ns));
     {
       ssc_latent_bwd_desc d{};
       d.B = B; d.Z = Z;
-      d.dz = W + l.dz; d.lddz = l.Zp;
+      d.dz = W + l.sl_dz; d.lddz = Z; d.nslab = ns; d.slab_stride = (size_t)B * Z;
       d.eps = bt->eps + (size_t)t * B * Z; d.ldeps = Z;
       d.mu = W + l.mu + (size_t)t * B * l.Zp; d.lv = W + l.lv + (size_t)t * B * l.Zp; d.ldz = l.Zp;
       d.kld_mode = cfg->kld_mode; d.sent = cfg->pm_scale != 0.f ? bt->sentiment : nullptr;
@@ -395,14 +441,15 @@ extern "C" int ssc_train_bwd(const ssc_model_cfg* cfg, const ssc_params* p, cons
       d.dmulv = dmulv; d.lddmulv = 2 * Z;
       SSC_TRY(ssc_latent_bwd(&d, st));
     }
-    // 4. dhe = g_he + dmu Wmu + dlv Wlv
-    SSC_TRY(gemm(c, true, false, {{dmulv, 2 * Z, p->fc_mean_w, p->ld_fc_mean_w, Z}, {dmulv + Z, 2 * Z, p->fc_lv_w, p->ld_fc_lv_w, Z}},
-                 B, H, W + l.g_he, l.Hp, nullptr, 1));
-    // 5. encoder LSTM
+    // 4-5. encoder LSTM: dhe = g_he' slabs + (dmu Wmu + dlv Wlv) slabs
+    SSC_TRY(gemm_to_slabs(c, W + l.sl_dhe, l.small_floats, true, false,
+                          {{dmulv, 2 * Z, p->fc_mean_w, p->ld_fc_mean_w, Z}, {dmulv + Z, 2 * Z, p->fc_lv_w, p->ld_fc_lv_w, Z}}, B, H,
+                          &ns));
     {
       ssc_lstm_bwd_desc d{};
       d.B = B; d.H = H;
-      d.dh = W + l.g_he; d.ld_dh = l.Hp;
+      d.slabsA = W + l.sl_ghe; d.nA = n_ghe; d.strideA = sBH;
+      d.slabsB = W + l.sl_dhe; d.nB = ns; d.strideB = sBH;
       d.dc_in = W + l.g_ce; d.ld_dcin = l.Hp;
       d.gates = W + l.gates_e + (size_t)t * B * H4;
       d.c_prev = W + l.ce + t * sH; d.ld_cprev = l.Hp;
@@ -416,14 +463,14 @@ extern "C" int ssc_train_bwd(const ssc_model_cfg* cfg, const ssc_params* p, cons
     // 7. attention backward
     SSC_TRY(ssc_attn_bwd(dx, XW, W + l.q + (size_t)t * B * l.Ap, l.Ap, W + l.pv, p->wa, W + l.alpha + (size_t)t * B * R,
                          bt->feats, B, R, A, F, dq, l.Ap, W + l.dpv, W + l.dwa, W + l.dalpha, st));
-    // 8. dh1 = g_h1 + dx[h1] + dq Wq
-    SSC_TRY(gemm(c, true, false, {{dq, l.Ap, p->wq, p->ld_wq, A}}, B, H, W + l.g_h1, l.Hp, nullptr, 1));
-    // 9. attention LSTM
+    // 8-9. attention LSTM: dh1 = dx[h1 block] + g_h1' slabs + (dq Wq) slabs
+    SSC_TRY(gemm_to_slabs(c, W + l.sl_dqw, l.small_floats, true, false, {{dq, l.Ap, p->wq, p->ld_wq, A}}, B, H, &ns));
     {
       ssc_lstm_bwd_desc d{};
       d.B = B; d.H = H;
-      d.dh = W + l.g_h1; d.ld_dh = l.Hp;
-      d.dh2 = dx + F; d.ld_dh2 = XW;
+      d.dh = dx + F; d.ld_dh = XW;
+      d.slabsA = W + l.sl_gh1; d.nA = n_gh1; d.strideA = sBH;
+      d.slabsB = W + l.sl_dqw; d.nB = ns; d.strideB = sBH;
       d.dc_in = W + l.g_c1; d.ld_dcin = l.Hp;
       d.gates = W + l.gates_a + (size_t)t * B * H4;
       d.c_prev = W + l.c1 + t * sH; d.ld_cprev = l.Hp;
@@ -432,17 +479,18 @@ extern "C" int ssc_train_bwd(const ssc_model_cfg* cfg, const ssc_params* p, cons
       d.dgsum = W + l.dga_sum;
       SSC_TRY(ssc_lstm_bwd(&d, st));
     }
-    // 10. gradients carried to step t-1
+    // 10. gradients carried to step t-1 (left as slabs for their consumers)
     if (t > 0) {
       const float* wr = p->att_w_ih + E + F;
-      SSC_TRY(gemm(c, true, false, {{dga, H4, wr, p->ld_att_w_ih, H4}, {dga, H4, p->att_w_hh, p->ld_att_w_hh, H4}}, B, H,
-                   W + l.g_h1, l.Hp));
-      SSC_TRY(gemm(c, true, false, {{dga, H4, wr + H, p->ld_att_w_ih, H4}, {dgd, H4, p->dec_w_hh, p->ld_dec_w_hh, H4}}, B, H,
-                   g_hd, XW, nullptr, 1));
-      SSC_TRY(gemm(c, true, false, {{dge, H4, p->enc_w_hh, p->ld_enc_w_hh, H4}}, B, H, W + l.g_he, l.Hp));
+      SSC_TRY(gemm_to_slabs(c, W + l.sl_gh1, l.small_floats, true, false, {{dga, H4, W + l.wsum_att, l.Hp, H4}}, B, H, &n_gh1));
+      SSC_TRY(gemm_to_slabs(c, W + l.sl_ghd, l.small_floats, true, false,
+                            {{dga, H4, wr + H, p->ld_att_w_ih, H4}, {dgd, H4, p->dec_w_hh, p->ld_dec_w_hh, H4}}, B, H, &n_ghd));
+      SSC_TRY(gemm_to_slabs(c, W + l.sl_ghe, l.small_floats, true, false, {{dge, H4, p->enc_w_hh, p->ld_enc_w_hh, H4}}, B, H,
+                            &n_ghe));
     }
   }
 
+  const int zcol = F + 2 * H + S;
   // ---- weight gradients: one K = T*B GEMM per block ----------------------------------------------------
   const float* dga = W + l.dga; const float* dge = W + l.dge; const float* dgd = W + l.dgd;
   const float* h1_prev = W + l.h1; const float* h1_new = W + l.h1 + sH;

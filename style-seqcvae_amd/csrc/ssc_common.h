@@ -44,4 +44,7 @@ __device__ __forceinline__ float ssc_sigmoid(float x) { return 1.0f / (1.0f + ex
 
 // internal cross-TU entry points (not part of the C ABI)
 int ssc_gemm_slabs(const ssc_gemm_desc* d, int splits, float* slabs, hipStream_t st);  // partial slabs only
+int ssc_attn_fwd_qslabs(const float* qslabs, int nslab, size_t slab_stride, float* q_out, int ldqo, const float* pv,
+                        const float* wa, const float* mask, const float* feats, int G, int R, int A, int F,
+                        int rows_per_image, float* logits, float* alpha, float* att, int ldatt, hipStream_t st);
 int ssc_gemm_slabs_auto(const ssc_gemm_desc* d, float* slabs, size_t cap_floats, int* nslab, hipStream_t st);

@@ -40,7 +40,9 @@ class LstmFwdDesc(C.Structure):
 class LstmBwdDesc(C.Structure):
     _fields_ = [("B", C.c_int), ("H", C.c_int), ("dh", vp), ("ld_dh", C.c_int), ("dh2", vp), ("ld_dh2", C.c_int),
                 ("dc_in", vp), ("ld_dcin", C.c_int), ("gates", vp), ("c_prev", vp), ("ld_cprev", C.c_int),
-                ("c_new", vp), ("ld_cnew", C.c_int), ("dG", vp), ("dc_prev", vp), ("ld_dcprev", C.c_int), ("dgsum", vp)]
+                ("c_new", vp), ("ld_cnew", C.c_int), ("dG", vp), ("dc_prev", vp), ("ld_dcprev", C.c_int), ("dgsum", vp),
+                ("slabsA", vp), ("nA", C.c_int), ("strideA", C.c_size_t), ("slabsB", vp), ("nB", C.c_int),
+                ("strideB", C.c_size_t)]
 
 
 class LatentFwdDesc(C.Structure):
@@ -53,7 +55,8 @@ class LatentFwdDesc(C.Structure):
 class LatentBwdDesc(C.Structure):
     _fields_ = [("B", C.c_int), ("Z", C.c_int), ("dz", vp), ("lddz", C.c_int), ("eps", vp), ("ldeps", C.c_int),
                 ("mu", vp), ("lv", vp), ("ldz", C.c_int), ("kld_mode", C.c_int), ("sent", vp), ("pm_scale", C.c_float),
-                ("prior_var", C.c_float), ("w", vp), ("gk", vp), ("dmulv", vp), ("lddmulv", C.c_int)]
+                ("prior_var", C.c_float), ("w", vp), ("gk", vp), ("dmulv", vp), ("lddmulv", C.c_int),
+                ("nslab", C.c_int), ("slab_stride", C.c_size_t)]
 
 
 class ModelCfg(C.Structure):
