@@ -33,10 +33,14 @@ __global__ __launch_bounds__(256) void attn_logits_kernel(const float* __restric
   if (((A & 3) == 0) && ((ldq & 3) == 0) && ((ldqo & 3) == 0) && ((slab_stride & 3) == 0) && ssc_aligned16_dev(qp) &&
       ssc_aligned16_dev(pp) && ssc_aligned16_dev(wa) && ssc_aligned16_dev(q_out)) {
     for (int a = lane * 4; a < A; a += 256) {
-      float4 qv = *reinterpret_cast<const float4*>(qp + a);
-      for (int sl = 1; sl < nslab; ++sl) {
-        float4 t = *reinterpret_cast<const float4*>(qp + sl * slab_stride + a);
-        qv.x += t.x; qv.y += t.y; qv.z += t.z; qv.w += t.w;
+      float4 qv = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int s0 = 0; s0 < nslab; s0 += 8) {  // fixed order, 8 slab loads in flight
+        float4 t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const float4*>(qp + (size_t)min(s0 + u, nslab - 1) * slab_stride + a);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (s0 + u < nslab) { qv.x += t[u].x; qv.y += t[u].y; qv.z += t[u].z; qv.w += t[u].w; }
       }
       if (q_out && r == 0) *reinterpret_cast<float4*>(q_out + (size_t)g * ldqo + a) = qv;
       float4 p4 = *reinterpret_cast<const float4*>(pp + a);

@@ -87,23 +87,26 @@ __global__ void lstm_fwd_kernel(const ssc_lstm_fwd_desc d) {
   int b = blockIdx.y;
   if (j >= d.H) return;
   const int H = d.H, H4 = 4 * d.H;
-  float pre[4];
+  float pre[4] = {0.f, 0.f, 0.f, 0.f};
+  // split-K slabs: summed in index order per gate; the loads of all four gates x 8 slabs (32) are in flight together
+  // (a `v += load` loop with a dynamic trip count serialises one memory latency per slab)
+  for (int s0 = 0; s0 < d.nslab; s0 += 8) {
+    float t[4][8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float* sp = d.slabs + (size_t)min(s0 + u, d.nslab - 1) * d.slab_stride + (size_t)b * H4 + j;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) t[g][u] = sp[g * H];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) pre[g] += (s0 + u < d.nslab) ? t[g][u] : 0.f;
+  }
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     int n = g * H + j;
-    float v = 0.f;
-    // slabs are summed in index order, 8 independent loads in flight at a time (a plain `v += load` loop with a
-    // dynamic trip count serialises the load latencies)
-    for (int s0 = 0; s0 < d.nslab; s0 += 8) {
-      float t[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        int sc = min(s0 + u, d.nslab - 1);
-        t[u] = d.slabs[(size_t)sc * d.slab_stride + (size_t)b * H4 + n];
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v += (s0 + u < d.nslab) ? t[u] : 0.f;
-    }
+    float v = pre[g];
     if (d.add0) v += d.add0[(size_t)b * d.ld_add0 + n];
     if (d.add1) v += d.add1[(size_t)(b / d.rows_per_add1) * d.ld_add1 + n];
     if (d.b_ih) v += d.b_ih[n];
@@ -178,10 +181,19 @@ __global__ void latent_fwd_kernel(const ssc_latent_fwd_desc d) {
   float acc = 0.f;
   for (int z = lane; z < Z; z += 64) {
     float m = 0.f, l = 0.f;
-    for (int s = 0; s < d.nslab; ++s) {
-      const float* row = d.mulv + (size_t)s * d.slab_stride + (size_t)b * d.ldmulv;
-      m += row[z];
-      l += row[Z + z];
+    for (int s0 = 0; s0 < d.nslab; s0 += 8) {
+      float tm[8], tl[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float* row = d.mulv + (size_t)min(s0 + u, d.nslab - 1) * d.slab_stride + (size_t)b * d.ldmulv;
+        tm[u] = row[z];
+        tl[u] = row[Z + z];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        m += (s0 + u < d.nslab) ? tm[u] : 0.f;
+        l += (s0 + u < d.nslab) ? tl[u] : 0.f;
+      }
     }
     m += d.bmu[z];
     l += d.blv[z];
@@ -216,8 +228,17 @@ __global__ void latent_bwd_kernel(const ssc_latent_bwd_desc d) {
   if (z >= d.Z) return;
   float k = d.gk[b] * d.w[b];
   float m = d.mu[(size_t)b * d.ldz + z], l = d.lv[(size_t)b * d.ldz + z];
-  float dz = d.dz[(size_t)b * d.lddz + z];
-  for (int sl = 1; sl < d.nslab; ++sl) dz += d.dz[(size_t)sl * d.slab_stride + (size_t)b * d.lddz + z];
+  float dz = 0.f;
+  {
+    const int ns = d.nslab > 1 ? d.nslab : 1;
+    for (int s0 = 0; s0 < ns; s0 += 8) {
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = d.dz[(size_t)min(s0 + u, ns - 1) * d.slab_stride + (size_t)b * d.lddz + z];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) dz += (s0 + u < ns) ? t[u] : 0.f;
+    }
+  }
   float e = d.eps[(size_t)b * d.ldeps + z];
   float var = expf(l);
   float dmu, dlv;
@@ -393,9 +414,19 @@ __global__ void sq_norm_partial_kernel(const float* __restrict__ g, size_t n, fl
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   size_t stride = (size_t)gridDim.x * blockDim.x;
   float s = 0.f;
-  for (; i < n; i += stride) {
-    float v = g[i];
-    s += v * v;
+  if (ssc_aligned16_dev(g)) {  // 16 B/lane stream over the bulk, scalar tail
+    const size_t n4 = n >> 2;
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    for (size_t k = i; k < n4; k += stride) {
+      float4 v = g4[k];
+      s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    for (size_t k = (n4 << 2) + i; k < n; k += stride) s += g[k] * g[k];
+  } else {
+    for (; i < n; i += stride) {
+      float v = g[i];
+      s += v * v;
+    }
   }
   s = block_reduce(s, sh, false);
   if (threadIdx.x == 0) scratch[blockIdx.x] = s;
