@@ -161,13 +161,20 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # SSC_BENCH_ONE_DEVICE=1 (rehearsal on a one-GPU box only): every rank uses cuda:0 and gloo carries the
+    # collectives; the real multi-GPU run is one rank per GPU over RCCL ("nccl" backend on ROCm).
+    rehearsal = os.environ.get("SSC_BENCH_ONE_DEVICE") == "1"
+    dev_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     import torch.distributed as dist
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from ssc_runtime import lib as L
     from ssc_runtime.vocab import Vocabulary

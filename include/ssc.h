@@ -302,6 +302,14 @@ int ssc_train_fwd(const ssc_model_cfg* cfg, const ssc_params* p, const ssc_batch
 int ssc_train_bwd(const ssc_model_cfg* cfg, const ssc_params* p, const ssc_batch* batch, void* workspace,
                   size_t workspace_bytes, const float* gl, const float* gk, const ssc_params* g, void* stream);
 
+/* The same backward in up to four stream-ordered phases (bit mask, ascending order): 1 = vocabulary head + BPTT time
+ * loop (output-head gradients final), 2 = embedding / attention-LSTM / attention-projection gradients, 4 = encoder-LSTM
+ * and latent-head gradients, 8 = decoder-LSTM gradients.  Lets the caller overlap the RCCL all-reduce of a finished
+ * gradient range with the next phase's GEMMs. */
+int ssc_train_bwd_phases(const ssc_model_cfg* cfg, const ssc_params* p, const ssc_batch* batch, void* workspace,
+                         size_t workspace_bytes, const float* gl, const float* gk, const ssc_params* g, unsigned phases,
+                         void* stream);
+
 /* read-back of saved per-step activations for tests: which = 0:h1 1:c1 2:h_enc 3:c_enc 4:h_dec 5:c_dec
  * (each (T+1,B,H), index 0 = initial zeros), 6: alpha (T,B,R), 7: mu (T,B,Zp), 8: lv (T,B,Zp), 9: logits (T*B,V),
  * 10: tokens (L+2,B) int64, 11: att (T,B,F).  Returns pointer into the workspace (and its ld) or 0. */

@@ -450,8 +450,6 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int PL_ROW_B = 80;               // bytes per LDS plane row (32 bf16 + 16 B pad)
-constexpr int PL_BYTES = 64 * PL_ROW_B;    // one plane of a 64-row operand tile
-constexpr int X3_STAGE_B = 6 * PL_BYTES;   // A(hi,mid,lo) + B(hi,mid,lo)
 
 // split 4 consecutive fp32 (one float4 of k) into the three bf16 planes, packed two bf16 per dword
 __device__ __forceinline__ void split4(const f32x4& v, u32x2& hi, u32x2& mid, u32x2& lo) {
@@ -471,9 +469,17 @@ __device__ __forceinline__ void split4(const f32x4& v, u32x2& hi, u32x2& mid, u3
   lo[0] = (l[0] >> 16) | (l[1] & 0xffff0000u); lo[1] = (l[2] >> 16) | (l[3] & 0xffff0000u);
 }
 
-template <int PF>
+// WN = 32x32 MFMA tiles per wave along N: block tile 64 x (64*WN).  WN = 2 halves the A re-reads per streamed weight
+// byte (the CU-side load path, ~24 GB/s per CU, is what the skinny products saturate) at one workgroup per CU.
+// NBUF = LDS stages: 2 = one barrier per k-step (61 KB: two workgroups per CU); 1 = two barriers per k-step but half the
+// LDS (31 KB: four workgroups per CU) - each wave's in-order stream (loads, split, LDS stores, MFMAs) is what a single
+// workgroup is bound by, so more resident waves per SIMD matter more than the extra barrier.
+template <int PF, int WN, int NBUF>
 __global__ __launch_bounds__(256) void gemm_x3_kernel(const KArgs a) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * X3_STAGE_B];
+  constexpr int RB = 64 * WN;
+  constexpr int PLA = 64 * PL_ROW_B, PLB = RB * PL_ROW_B;   // bytes per plane
+  constexpr int STAGE_B = 3 * PLA + 3 * PLB;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[NBUF * STAGE_B];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -488,16 +494,18 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const KArgs a) {
     by = nl / gx;
     bx = nl - by * gx;
   }
-  const int n0 = bx * 64, m0 = by * 64, z = blockIdx.z;
+  const int n0 = bx * RB, m0 = by * 64, z = blockIdx.z;
   const int s_lo = z * a.steps_per_split;
   int s_hi = s_lo + a.steps_per_split;
   if (s_hi > a.steps_total) s_hi = a.steps_total;
 
-  f32x16 acc;
+  f32x16 acc[WN];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  for (int ni = 0; ni < WN; ++ni)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[ni][i] = 0.f;
 
-  typedef Stage<true, true, 64, 64, true> StageT;
+  typedef Stage<true, true, 64, RB, true> StageT;
   constexpr int NL = StageT::NLOADS;
   StageT st[PF];
   const int s_last = s_hi - 1;
@@ -505,21 +513,30 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const KArgs a) {
   // registers -> three bf16 planes per operand (k-range select applied here, as in the fp32 kernel)
   auto put_planes = [&](unsigned char* base, const StageT& x) {
 #pragma unroll
-    for (int op = 0; op < 2; ++op) {
+    for (int u = 0; u < StageT::NVA; ++u) {
+      const int idx = tid + 256 * u;
+      const int row = idx >> 3, kq = idx & 7;
+      f32x4 v = x.a[u];
+      if (!((x.oka >> u) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      u32x2 hi, mid, lo;
+      split4(v, hi, mid, lo);
+      unsigned char* p = base + row * PL_ROW_B + kq * 8;
+      *reinterpret_cast<u32x2*>(p) = hi;
+      *reinterpret_cast<u32x2*>(p + PLA) = mid;
+      *reinterpret_cast<u32x2*>(p + 2 * PLA) = lo;
+    }
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int idx = tid + 256 * u;
-        const int row = idx >> 3, kq = idx & 7;
-        const bool ok = ((op == 0 ? x.oka : x.okb) >> u) & 1u;
-        f32x4 v = op == 0 ? x.a[u] : x.b[u];
-        if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
-        u32x2 hi, mid, lo;
-        split4(v, hi, mid, lo);
-        unsigned char* p = base + op * 3 * PL_BYTES + row * PL_ROW_B + kq * 8;
-        *reinterpret_cast<u32x2*>(p) = hi;
-        *reinterpret_cast<u32x2*>(p + PL_BYTES) = mid;
-        *reinterpret_cast<u32x2*>(p + 2 * PL_BYTES) = lo;
-      }
+    for (int u = 0; u < StageT::NVB; ++u) {
+      const int idx = tid + 256 * u;
+      const int row = idx >> 3, kq = idx & 7;
+      f32x4 v = x.b[u];
+      if (!((x.okb >> u) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      u32x2 hi, mid, lo;
+      split4(v, hi, mid, lo);
+      unsigned char* p = base + 3 * PLA + row * PL_ROW_B + kq * 8;
+      *reinterpret_cast<u32x2*>(p) = hi;
+      *reinterpret_cast<u32x2*>(p + PLB) = mid;
+      *reinterpret_cast<u32x2*>(p + 2 * PLB) = lo;
     }
   };
 
@@ -539,23 +556,27 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const KArgs a) {
   __syncthreads();
 
   auto compute = [&](int buf) {
-    const unsigned char* pa = lds + buf * X3_STAGE_B + (wm * 32 + l31) * PL_ROW_B + half * 16;
-    const unsigned char* pb = lds + buf * X3_STAGE_B + 3 * PL_BYTES + (wn * 32 + l31) * PL_ROW_B + half * 16;
+    const unsigned char* pa = lds + buf * STAGE_B + (wm * 32 + l31) * PL_ROW_B + half * 16;
+    const unsigned char* pb = lds + buf * STAGE_B + 3 * PLA + (wn * 32 * WN + l31) * PL_ROW_B + half * 16;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(pa + kk * 32));
-      bf16x8 am = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(pa + PL_BYTES + kk * 32));
-      bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(pa + 2 * PL_BYTES + kk * 32));
-      bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(pb + kk * 32));
-      bf16x8 bm = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(pb + PL_BYTES + kk * 32));
-      bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(pb + 2 * PL_BYTES + kk * 32));
-      // smallest partial products first
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+      bf16x8 am = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(pa + PLA + kk * 32));
+      bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(pa + 2 * PLA + kk * 32));
+#pragma unroll
+      for (int ni = 0; ni < WN; ++ni) {
+        const unsigned char* pbn = pb + ni * 32 * PL_ROW_B;
+        bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(pbn + kk * 32));
+        bf16x8 bm = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(pbn + PLB + kk * 32));
+        bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(pbn + 2 * PLB + kk * 32));
+        // smallest partial products first
+        acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[ni], 0, 0, 0);
+        acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[ni], 0, 0, 0);
+        acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[ni], 0, 0, 0);
+        acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[ni], 0, 0, 0);
+        acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[ni], 0, 0, 0);
+        acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[ni], 0, 0, 0);
+      }
     }
   };
 
@@ -565,9 +586,10 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const KArgs a) {
     for (int j = 0; j < U; ++j) {
       if (s + j < s_hi) {
         StageT& x = st[j % PF];
-        compute(j & 1);
+        compute(NBUF == 2 ? (j & 1) : 0);
         x.template wait<(PF - 1) * NL>();
-        if (s + j + 1 < s_hi) put_planes(lds + ((j + 1) & 1) * X3_STAGE_B, x);
+        if constexpr (NBUF == 1) __syncthreads();  // every wave is done reading the single stage
+        if (s + j + 1 < s_hi) put_planes(lds + (NBUF == 2 ? ((j + 1) & 1) : 0) * STAGE_B, x);
         cur.advance(a, s_ld >= s_last); s_ld = min(s_ld + 1, s_last);
         x.load(a, cur, m0, n0, tid);
         __syncthreads();
@@ -577,8 +599,10 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const KArgs a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   float* out = a.out + (size_t)z * a.slab_stride;
-  const int col = n0 + wn * 32 + l31;
-  if (col < a.N) {
+#pragma unroll
+  for (int ni = 0; ni < WN; ++ni) {
+    const int col = n0 + (wn * WN + ni) * 32 + l31;
+    if (col >= a.N) continue;
     const float bv = (a.bias != nullptr) ? a.bias[col] : 0.f;
     const int rbase = m0 + wm * 32 + 4 * half;
     float old[16];
@@ -592,7 +616,7 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const KArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       int row = rbase + (r & 3) + 8 * (r >> 2);
-      if (row < a.M) out[(size_t)row * a.ldo + col] = acc[r] + bv + old[r];
+      if (row < a.M) out[(size_t)row * a.ldo + col] = acc[ni][r] + bv + old[r];
     }
   }
 }
@@ -673,6 +697,9 @@ inline int gemm_mode() {
   return g_gemm_mode;
 }
 inline bool use_x3(const ssc_gemm_desc* d, bool vec) { return gemm_mode() == 1 && d->a_kc && d->b_kc && vec; }
+int g_x3_nbuf = 2;
+int g_x3_wide = 0;  // tuning hook: 1 = 64x128 block tile for skinny (M <= 64, N >= 1024) 3xBF16 products
+inline bool x3_wide(int M, int N) { return g_x3_wide && M <= 64 && N >= 1024; }
 inline bool big_tile(int M, int N) { return M >= 512 && N >= 512; }
 // M <= 64 with a wide N: 64x128 block tile (wave tile 32x64).  Every workgroup re-reads the whole A operand
 // (the minibatch activations, from L2) for its K-range, and the CU-side load path (~24 GB/s per CU) is what these
@@ -690,7 +717,8 @@ int launch(const ssc_gemm_desc* d, KArgs& k, int splits, hipStream_t st) {
   bool vec = true;  // every segment of both operands must allow 16 B/lane loads, else the 4 B/lane kernel runs
   for (int i = 0; i < k.nseg; ++i) vec = vec && k.seg[i].avec && k.seg[i].bvec;
   if (use_x3(d, vec)) {
-    dim3 grid(ssc_cdiv(d->N, 64), ssc_cdiv(d->M, 64), splits);
+    const bool wide = x3_wide(d->M, d->N);
+    dim3 grid(ssc_cdiv(d->N, wide ? 128 : 64), ssc_cdiv(d->M, 64), splits);
     ProfRec* rec = nullptr;
     if (g_prof_on && g_prof && g_prof_n < PROF_MAX) {
       rec = &g_prof[g_prof_n++];
@@ -698,7 +726,9 @@ int launch(const ssc_gemm_desc* d, KArgs& k, int splits, hipStream_t st) {
       for (int i = 0; i < d->nseg; ++i) rec->K += d->seg[i].K;
       (void)hipEventRecord(rec->e0, st);
     }
-    hipLaunchKernelGGL(gemm_x3_kernel<2>, grid, dim3(256), 0, st, k);
+    if (wide) hipLaunchKernelGGL((gemm_x3_kernel<2, 2, 2>), grid, dim3(256), 0, st, k);
+    else if (g_x3_nbuf == 1) hipLaunchKernelGGL((gemm_x3_kernel<2, 1, 1>), grid, dim3(256), 0, st, k);
+    else hipLaunchKernelGGL((gemm_x3_kernel<2, 1, 2>), grid, dim3(256), 0, st, k);
     if (rec) (void)hipEventRecord(rec->e1, st);
     SSC_CHECK_LAUNCH();
     return SSC_OK;
@@ -887,5 +917,9 @@ extern "C" int ssc_set_gemm_mode(int mode) {
 extern "C" int ssc_set_gemm_wide_min_n(int n) {
   int prev = g_wide_min_n;
   if (n > 0) g_wide_min_n = n;
+  if (n == -1) g_x3_wide = 1;   // probe hooks: -1 / -2 switch the 3xBF16 wide tile on / off
+  if (n == -2) g_x3_wide = 0;
+  if (n == -3) g_x3_nbuf = 1;
+  if (n == -4) g_x3_nbuf = 2;
   return prev;
 }

@@ -361,8 +361,20 @@ extern "C" int ssc_train_fwd(const ssc_model_cfg* cfg, const ssc_params* p, cons
   return SSC_OK;
 }
 
-extern "C" int ssc_train_bwd(const ssc_model_cfg* cfg, const ssc_params* p, const ssc_batch* bt, void* workspace,
-                             size_t workspace_bytes, const float* gl, const float* gk, const ssc_params* g, void* stream) {
+namespace {
+__global__ void repeat_kernel(const float* __restrict__ src, int n, int reps, float* __restrict__ dst) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n * reps) dst[i] = src[i % n];
+}
+}  // namespace
+
+// phases (bit mask): 1 = vocabulary head + BPTT time loop (output-head gradients are final after it), 2 = embedding,
+// attention-LSTM and attention-projection gradients, 4 = encoder-LSTM and latent-head gradients, 8 = decoder-LSTM
+// gradients.  Phases must run in this order on one stream; splitting them lets the caller start the all-reduce of a
+// finished gradient range while the next phase computes (ssc_runtime/engine.py).
+static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const ssc_batch* bt, void* workspace,
+                          size_t workspace_bytes, const float* gl, const float* gk, const ssc_params* g, void* stream,
+                          unsigned phases) {
   SSC_TRY(check_cfg(cfg, p, bt));
   if (!workspace || !gl || !gk || !g) return SSC_EINVAL;
   const Layout l = make_layout(cfg, bt->B, bt->R, bt->L);
@@ -376,6 +388,7 @@ extern "C" int ssc_train_bwd(const ssc_model_cfg* cfg, const ssc_params* p, cons
   const size_t sH = (size_t)B * l.Hp;
   const float* hd_all = W + l.hd + sH;
 
+  if (phases & 1u) {
   // ---- vocabulary head ------------------------------------------------------------------------------
   SSC_TRY(ssc_ce_bwd(W + l.logits, l.Vp, tok + B, W + l.w, W + l.nvalid, W + l.lse, gl, T, B, V, st));
   const float* dlog = W + l.logits;
@@ -490,19 +503,19 @@ extern "C" int ssc_train_bwd(const ssc_model_cfg* cfg, const ssc_params* p, cons
     }
   }
 
+  if (S) {  // sentiment replicated over time (row = t*B+b) for the rank-1 column gradients
+    hipLaunchKernelGGL(repeat_kernel, dim3(ssc_cdiv(TB, 256)), dim3(256), 0, st, bt->sentiment, B, T, W + l.sent_all);
+    SSC_CHECK_LAUNCH();
+  }
+  }  // phase 1
+
   const int zcol = F + 2 * H + S;
   // ---- weight gradients: one K = T*B GEMM per block ----------------------------------------------------
   const float* dga = W + l.dga; const float* dge = W + l.dge; const float* dgd = W + l.dgd;
   const float* h1_prev = W + l.h1; const float* h1_new = W + l.h1 + sH;
   const float* hd_prev = W + l.hd; const float* he_prev = W + l.he; const float* he_new = W + l.he + sH;
   const float* att = W + l.att;
-  // sentiment replicated over time (row = t*B+b) for the rank-1 column gradients
-  if (S) {
-    for (int t = 0; t < T; ++t)
-      if (hipMemcpyAsync(W + l.sent_all + (size_t)t * B, bt->sentiment, B * sizeof(float), hipMemcpyDeviceToDevice, st) !=
-          hipSuccess)
-        return SSC_EHIP;
-  }
+  if (phases & 2u) {
   // attention LSTM
   if (g->att_w_ih) {
     float* gw = g->att_w_ih; int ld = g->ld_att_w_ih;
@@ -529,6 +542,8 @@ extern "C" int ssc_train_bwd(const ssc_model_cfg* cfg, const ssc_params* p, cons
   if (g->wq) SSC_TRY(gemm(c, false, false, {{W + l.dq, l.Ap, h1_new, l.Hp, TB}}, A, H, g->wq, g->ld_wq));
   if (g->wv) SSC_TRY(gemm(c, false, false, {{W + l.dpv, A, bt->feats, F, B * R}}, A, F, g->wv, g->ld_wv));
   if (g->wa) SSC_TRY(ssc_colsum(W + l.dwa, A, B, A, nullptr, g->wa, 1, 0, st));
+  }  // phase 2
+  if (phases & 4u) {
   // encoder LSTM
   if (g->enc_w_ih) {
     float* gw = g->enc_w_ih; int ld = g->ld_enc_w_ih;
@@ -550,6 +565,8 @@ extern "C" int ssc_train_bwd(const ssc_model_cfg* cfg, const ssc_params* p, cons
   if (g->fc_lv_w) SSC_TRY(gemm(c, false, false, {{dmulv + Z, 2 * Z, he_new, l.Hp, TB}}, Z, H, g->fc_lv_w, g->ld_fc_lv_w));
   if (g->fc_mean_b) SSC_TRY(ssc_colsum2(dmulv, 2 * Z, TB, Z, nullptr, g->fc_mean_b, 1, nullptr, 0, c.slabs, st));
   if (g->fc_lv_b) SSC_TRY(ssc_colsum2(dmulv + Z, 2 * Z, TB, Z, nullptr, g->fc_lv_b, 1, nullptr, 0, c.slabs, st));
+  }  // phase 4
+  if (phases & 8u) {
   // decoder LSTM (skipped while frozen: train.py:156-161)
   if (g->dec_w_ih) {
     float* gw = g->dec_w_ih; int ld = g->ld_dec_w_ih;
@@ -566,5 +583,18 @@ extern "C" int ssc_train_bwd(const ssc_model_cfg* cfg, const ssc_params* p, cons
     if (g->dec_b_ih) SSC_TRY(ssc_colsum2(dgd, H4, TB, H4, nullptr, g->dec_b_ih, 1, nullptr, 0, c.slabs, st));
     if (g->dec_b_hh) SSC_TRY(ssc_colsum2(dgd, H4, TB, H4, nullptr, g->dec_b_hh, 1, nullptr, 0, c.slabs, st));
   }
+  }  // phase 8
   return SSC_OK;
+}
+
+extern "C" int ssc_train_bwd(const ssc_model_cfg* cfg, const ssc_params* p, const ssc_batch* bt, void* workspace,
+                             size_t workspace_bytes, const float* gl, const float* gk, const ssc_params* g, void* stream) {
+  return train_bwd_impl(cfg, p, bt, workspace, workspace_bytes, gl, gk, g, stream, 15u);
+}
+
+extern "C" int ssc_train_bwd_phases(const ssc_model_cfg* cfg, const ssc_params* p, const ssc_batch* bt, void* workspace,
+                                    size_t workspace_bytes, const float* gl, const float* gk, const ssc_params* g,
+                                    unsigned phases, void* stream) {
+  if (phases == 0 || phases > 15u) return SSC_EINVAL;
+  return train_bwd_impl(cfg, p, bt, workspace, workspace_bytes, gl, gk, g, stream, phases);
 }

@@ -174,6 +174,7 @@ class TrainEngine:
         self.steps_done = 0
         self.fwd_version = 0
         self.dp_buckets = 1
+        self.dp_overlap = True
 
     def adopt(self, named: "Dict[str, torch.nn.Parameter]"):
         """Re-home nn.Parameters into the flat store (copy once, then `param.data` IS the view).  Cheap when they
@@ -237,6 +238,40 @@ class TrainEngine:
         self._keep = (bt, feats, caps, sent, eps)
         self.fwd_version += 1
         return loss, kld
+
+    # gradient ranges that are final after each backward phase (flat layout order: emb | att LSTM | attention |
+    # enc LSTM | fc | output head | dec LSTM)
+    def phase_ranges(self):
+        names = list(self.grads.views)
+        head = [n for n in names if n.startswith("_output_")]
+        dec = self.decoder_names
+        first = [n for n in names if n.startswith("_embedding") or n.startswith(P_ATT) or n.startswith(P_BUTD)]
+        mid = [n for n in names if n.startswith(P_ENC) or n.startswith(P_CELL + "fc_")]
+        return [(1, self.grads.range_of(head)), (2, self.grads.range_of(first)), (4, self.grads.range_of(mid)),
+                (8, self.grads.range_of(dec))]
+
+    def backward_overlapped(self, gl, gk, skip: Sequence[str] = (), group=None):
+        """Backward in four phases; the sum all-reduce of each finished gradient range is issued asynchronously
+        (RCCL runs it on its own stream) while the next phase's GEMMs run.  Returns the world size."""
+        import torch.distributed as dist
+
+        bt = self._keep[0]
+        ws = self._workspace(bt.B, bt.R, bt.L)
+        skipset = set(skip) | set(self.frozen_names)
+        only = [n for n in self.grads.views if n not in skipset]
+        p = self.params.c_struct()
+        g = self.grads.c_struct(only=only)
+        gl = gl.to(torch.float32).contiguous()
+        gk = gk.to(torch.float32).contiguous()
+        world = dist.get_world_size(group)
+        works = []
+        for mask, (lo, hi) in self.phase_ranges():
+            self.lib.ssc_train_bwd_phases(C.byref(self._cfg), C.byref(p), C.byref(bt), _lib.ptr(ws), ws.numel() * 4,
+                                          _lib.ptr(gl), _lib.ptr(gk), C.byref(g), mask, _lib.stream_ptr())
+            works.append(dist.all_reduce(self.grads.flat[lo:hi], op=dist.ReduceOp.SUM, group=group, async_op=True))
+        for w in works:
+            w.wait()
+        return world
 
     def backward(self, gl, gk, skip: Sequence[str] = ()):
         """Writes d(sum_b gl_b loss_b + gk_b kld_b)/dparam into self.grads for every parameter not in `skip`
@@ -314,7 +349,13 @@ class TrainEngine:
         B = loss.numel()
         gl = torch.full((B,), 1.0 / B, dtype=torch.float32, device=self.device)
         gk = torch.full((B,), 1.0 / (B * kld_weight), dtype=torch.float32, device=self.device)
-        self.backward(gl, gk, skip=self.decoder_names if decoder_frozen else ())
-        world = self.allreduce_grads(group)
+        import torch.distributed as dist
+
+        skip = self.decoder_names if decoder_frozen else ()
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1 and self.dp_overlap:
+            world = self.backward_overlapped(gl, gk, skip=skip, group=group)
+        else:
+            self.backward(gl, gk, skip=skip)
+            world = self.allreduce_grads(group)
         self.clip_sgd_step(lr, momentum, weight_decay, max_norm, decoder_frozen, gscale=1.0 / world)
         return loss, kld

@@ -135,6 +135,8 @@ SYMBOLS = {
     "ssc_train_workspace_bytes": (_sz, [C.POINTER(ModelCfg), _i, _i, _i]),
     "ssc_train_fwd": (_i, [C.POINTER(ModelCfg), C.POINTER(Params), C.POINTER(Batch), vp, _sz, vp, vp, vp]),
     "ssc_train_bwd": (_i, [C.POINTER(ModelCfg), C.POINTER(Params), C.POINTER(Batch), vp, _sz, vp, vp, C.POINTER(Params), vp]),
+    "ssc_train_bwd_phases": (_i, [C.POINTER(ModelCfg), C.POINTER(Params), C.POINTER(Batch), vp, _sz, vp, vp, C.POINTER(Params),
+                                  C.c_uint, vp]),
     "ssc_train_workspace_view": (vp, [C.POINTER(ModelCfg), _i, _i, _i, vp, _i, C.POINTER(C.c_int)]),
     "ssc_decode_image_bytes": (_sz, [C.POINTER(ModelCfg), _i, _i]),
     "ssc_decode_prepare": (_i, [C.POINTER(ModelCfg), C.POINTER(Params), vp, _i, _i, vp, _sz, vp]),

@@ -17,6 +17,12 @@ DEFAULT = ["NT:64:4800:2048+1200+1200+1200", "NN:64:4448:4800+4800", "NN:64:1200
 
 
 def main():
+    import os as _os
+    from ssc_runtime import lib as _L
+    if _os.environ.get("SSC_X3_WIDE"):
+        _L.load().ssc_set_gemm_wide_min_n(-1)
+    if _os.environ.get("SSC_X3_NBUF") == "1":
+        _L.load().ssc_set_gemm_wide_min_n(-3)
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     shapes = sys.argv[2:] or DEFAULT
     for sh in shapes:
