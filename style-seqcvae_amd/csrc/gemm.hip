@@ -726,7 +726,8 @@ int launch(const ssc_gemm_desc* d, KArgs& k, int splits, hipStream_t st) {
       for (int i = 0; i < d->nseg; ++i) rec->K += d->seg[i].K;
       (void)hipEventRecord(rec->e0, st);
     }
-    if (wide) hipLaunchKernelGGL((gemm_x3_kernel<2, 2, 2>), grid, dim3(256), 0, st, k);
+    if (wide && g_x3_nbuf == 1) hipLaunchKernelGGL((gemm_x3_kernel<2, 2, 1>), grid, dim3(256), 0, st, k);
+    else if (wide) hipLaunchKernelGGL((gemm_x3_kernel<2, 2, 2>), grid, dim3(256), 0, st, k);
     else if (g_x3_nbuf == 1) hipLaunchKernelGGL((gemm_x3_kernel<2, 1, 1>), grid, dim3(256), 0, st, k);
     else hipLaunchKernelGGL((gemm_x3_kernel<2, 1, 2>), grid, dim3(256), 0, st, k);
     if (rec) (void)hipEventRecord(rec->e1, st);

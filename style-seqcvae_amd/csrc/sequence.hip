@@ -414,7 +414,7 @@ static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const s
   SSC_TRY(ssc_fill(W + l.dpv, (size_t)B * R * A, 0.f, st));
   SSC_TRY(ssc_fill(W + l.dwa, (size_t)B * A, 0.f, st));
   SSC_TRY(ssc_fill(W + l.dga_sum, (size_t)B * H4, 0.f, st));
-  SSC_TRY(prepare_weight_views(l, p, W, st));
+  // wsum_att / wz were prepared by ssc_train_fwd of the same minibatch (parameters are unchanged until the update)
   float* dx = W + l.dx;            // [datt (F) | dh1 (H) | dhd' (H)], ld XW
   int n_gh1 = 0, n_ghd = 0, n_ghe = 0;  // slab counts carried from step t+1 (none at t = T-1)
   const size_t sBH = (size_t)B * H;
