@@ -85,6 +85,54 @@ def cpu_baseline(c, seconds_budget=25.0):
                       f"median {med:.2f} s/step, torch {torch.__version__} CPU, os.cpu_count()={os.cpu_count()}"}
 
 
+def attention_roofline(device):
+    """HBM-roofline fraction of the fused attention step (logits + masked softmax + weighted sum; SURVEY §8(d) 'Attention
+    kernel') at the C2 and C5 shapes: algorithmic bytes 4*(B*R*A + B*R*F + B*A + B*R + B*F) over the hipEvent-timed
+    average of 50 back-to-back calls (two kernels per call)."""
+    from ssc_runtime import lib as L
+    lib = L.load()
+    out = {}
+    for name, (B, R, A, F) in {"C2": (64, 36, 768, 2048), "C5": (128, 100, 768, 2048)}.items():
+        g = torch.Generator().manual_seed(1)
+        q = torch.randn(B, A, generator=g).to(device)
+        pv = torch.randn(B, R, A, generator=g).to(device)
+        wa = torch.randn(A, generator=g).to(device)
+        feats = torch.randn(B, R, F, generator=g).to(device)
+        mask = torch.ones(B, R, device=device)
+        logits = torch.empty(B, R, device=device)
+        alpha = torch.empty(B, R, device=device)
+        att = torch.empty(B, F, device=device)
+        # rotate over several copies so that the 26-146 MB working set is not served from the 256 MB Infinity Cache
+        n_copies = 12 if name == "C2" else 3
+        pvs = [pv.clone() for _ in range(n_copies)]
+        fts = [feats.clone() for _ in range(n_copies)]
+
+        def call(i):
+            lib.ssc_attn_fwd(L.ptr(q), A, L.ptr(pvs[i % n_copies]), L.ptr(wa), L.ptr(mask), L.ptr(fts[i % n_copies]), B, R, A, F, 1,
+                             L.ptr(logits), L.ptr(alpha), L.ptr(att), F, L.stream_ptr())
+
+        for i in range(5):
+            call(i)
+        torch.cuda.synchronize()
+        # the 50 calls are captured into one hipGraph so that the measurement is device time, not ctypes launch overhead
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for i in range(50):
+                call(i)
+        graph.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        graph.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / 50 * 1e3
+        nbytes = 4 * (B * R * A + B * R * F + B * A + B * R + B * F)
+        out[name] = {"us": us, "algorithmic_bytes": nbytes, "achieved_GBps": nbytes / us / 1e3,
+                     "frac_of_8TBps": nbytes / us / 1e3 / HBM_PEAK_GBS}
+    return out
+
+
 def bench_decode(args, model, eng, c, rank, world, device):
     """BASELINE.json configs[3] (C4): beam 5 (per-node 2) x 20 latent samples per image, 36x2048 features, max 20
     steps, trivial one-state FSM, images sharded over ranks (no collective).  A "step" = one chunk of images."""
@@ -267,8 +315,16 @@ def main():
         gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9
         # the recurrent (per-timestep) gate GEMMs of the fused attention+LSTM step: NT launches with M == B, N == 4H
         step_recs = [r for r in rec.tolist() if int(r[0]) == 0 and int(r[1]) == c["B"] and int(r[2]) == 4 * c["H"]]
+        traffic = None
+        try:  # HBM-side bytes per launch of this kernel family from the committed rocprofv3 PMC passes (profiles/)
+            pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")))["kernels"]
+            fam = {0: ("gemm_x3", "gemm_kernel<NT"), 1: ("gemm_kernel<NN",), 3: ("gemm_kernel<TN",)}[dom]
+            sel = [v for k, v in pm.items() if any(k.startswith(f) for f in fam)]
+            traffic = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in sel) / max(1, sum(v["launches"] for v in sel))
+        except Exception:
+            traffic = None
         roofline = {"bound": "mfma", "kernel": names[dom], "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                    "frac": tf / MFMA_F32_PEAK_TF, "traffic": None, "launches_per_step": d["n"] / nprof,
+                    "frac": tf / MFMA_F32_PEAK_TF, "traffic": traffic, "launches_per_step": d["n"] / nprof,
                     "avg_launch_us": d["ms"] / d["n"] * 1e3, "algorithmic_GBps": gbs,
                     "hbm_frac_of_8TBps": gbs / HBM_PEAK_GBS,
                     "share_of_gemm_time": d["ms"] / sum(a["ms"] for a in agg.values())}
@@ -288,6 +344,7 @@ def main():
                              "global_batch": world * c["B"], "parallelism": f"dp{world}", "loss_probe": loss_probe},
                   "roofline": roofline, "roofline_step": roofline_step,
                   "gemm_time_ms_per_step": {names[k]: agg[k]["ms"] / nprof for k in agg}}
+        result["attention_roofline"] = attention_roofline(device)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(c)
         print(json.dumps(result), flush=True)

@@ -21,6 +21,9 @@ def short(name):
         a, b, wm, wn, pf, vec = m.groups()
         kind = {("true", "true"): "NT", ("true", "false"): "NN", ("false", "false"): "TN", ("false", "true"): "TT"}[(a, b)]
         return f"gemm_kernel<{kind},{64 * int(wm)}x{64 * int(wn)},{'vec' if vec == 'true' else 'scalar'}>"
+    m = re.search(r"gemm_x3_kernel<(\d), (\d), (\d)>", name)
+    if m:
+        return f"gemm_x3_kernel<NT,64x{64 * int(m.group(2))},lds{m.group(3)}>"
     m = re.search(r"(?:\(anonymous namespace\)::)?(\w+)\(", name)
     return m.group(1) if m else name[:50]
 
