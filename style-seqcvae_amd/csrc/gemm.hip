@@ -254,8 +254,9 @@ struct Stage<A_KC, B_KC, RA, RB, true> {
   }
 
   __device__ __forceinline__ void load(const KArgs& g, const Cursor& c, int m0, int n0, int tid) {
-    oka = issue<A_KC, RA, NVA>(a, c.A, c.lda, g.M, c.K, m0, c.k0, tid);
-    okb = issue<B_KC, RB, NVB>(b, c.B, c.ldb, g.N, c.K, n0, c.k0, tid);
+    // timing-only ablations (SSC_GEMM_DBG): 16 / 32 make every A / B load hit one cached line (no memory traffic)
+    oka = issue<A_KC, RA, NVA>(a, c.A, (g.dbg & 16) ? 0 : c.lda, g.M, c.K, (g.dbg & 16) ? 0 : m0, (g.dbg & 16) ? 0 : c.k0, tid);
+    okb = issue<B_KC, RB, NVB>(b, c.B, (g.dbg & 32) ? 0 : c.ldb, g.N, c.K, (g.dbg & 32) ? 0 : n0, (g.dbg & 32) ? 0 : c.k0, tid);
   }
 
   template <int YOUNGER>
@@ -393,8 +394,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const KArgs a) {
         x.template wait<(PF - 1) * NL>();
         if (s + j + 1 < s_hi && !(a.dbg & 2)) x.store(As + ((j + 1) & 1) * TA, Bs + ((j + 1) & 1) * TB, tid);
         cur.advance(a, s_ld >= s_last); s_ld = min(s_ld + 1, s_last);
-        if (!(a.dbg & 1)) x.load(a, cur, m0, n0, tid);
-        if (!(a.dbg & 4)) __syncthreads();
+        x.load(a, cur, m0, n0, tid);
+        __syncthreads();
       }
     }
   }
@@ -586,10 +587,24 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const KArgs a) {
     for (int j = 0; j < U; ++j) {
       if (s + j < s_hi) {
         StageT& x = st[j % PF];
-        compute(NBUF == 2 ? (j & 1) : 0);
+        // One basic block: this step's MFMA chain and the NEXT tile's fp32 -> 3xbf16 split (VALU) + plane stores.  A wave
+        // issues in order and a dependent MFMA blocks everything behind it, so the split must sit BETWEEN the MFMAs to
+        // run in their shadow (sched_group_barrier below); the store is unconditional (past the end it re-stores the
+        // clamped last tile into the stage nobody reads again).
         x.template wait<(PF - 1) * NL>();
-        if constexpr (NBUF == 1) __syncthreads();  // every wave is done reading the single stage
-        if (s + j + 1 < s_hi) put_planes(lds + (NBUF == 2 ? ((j + 1) & 1) : 0) * STAGE_B, x);
+        if constexpr (NBUF == 2) {
+          compute(j & 1);
+          put_planes(lds + ((j + 1) & 1) * STAGE_B, x);
+#pragma unroll
+          for (int q = 0; q < 12 * WN; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);  // up to 7 VALU in its shadow
+          }
+        } else {
+          compute(0);
+          __syncthreads();  // every wave is done reading the single stage
+          put_planes(lds, x);
+        }
         cur.advance(a, s_ld >= s_last); s_ld = min(s_ld + 1, s_last);
         x.load(a, cur, m0, n0, tid);
         __syncthreads();
@@ -697,7 +712,7 @@ inline int gemm_mode() {
   return g_gemm_mode;
 }
 inline bool use_x3(const ssc_gemm_desc* d, bool vec) { return gemm_mode() == 1 && d->a_kc && d->b_kc && vec; }
-int g_x3_nbuf = 2;
+int g_x3_nbuf = 1;  // single LDS stage: 31 KB per workgroup -> four resident workgroups per CU (rocprof r01: 37 vs 43 us)
 int g_x3_wide = 0;  // tuning hook: 1 = 64x128 block tile for skinny (M <= 64, N >= 1024) 3xBF16 products
 inline bool x3_wide(int M, int N) { return g_x3_wide && M <= 64 && N >= 1024; }
 inline bool big_tile(int M, int N) { return M >= 512 && N >= 512; }
@@ -923,4 +938,18 @@ extern "C" int ssc_set_gemm_wide_min_n(int n) {
   if (n == -3) g_x3_nbuf = 1;
   if (n == -4) g_x3_nbuf = 2;
   return prev;
+}
+
+// diagnostic: resident workgroups per CU the runtime reports for the GEMM kernels (tools/, not used by the product path)
+extern "C" int ssc_debug_gemm_occupancy(int* out4) {
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_x3_kernel<2, 1, 2>, 256, 0) != hipSuccess) return SSC_EHIP;
+  out4[0] = n;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_x3_kernel<2, 1, 1>, 256, 0) != hipSuccess) return SSC_EHIP;
+  out4[1] = n;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_kernel<true, true, 1, 1, 4, true>, 256, 0) != hipSuccess) return SSC_EHIP;
+  out4[2] = n;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_kernel<true, false, 1, 2, 2, true>, 256, 0) != hipSuccess) return SSC_EHIP;
+  out4[3] = n;
+  return SSC_OK;
 }
