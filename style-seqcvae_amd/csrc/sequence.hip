@@ -524,7 +524,17 @@ static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const s
     SSC_TRY(gemm(c, false, false, {{dga, H4, h1_prev, l.Hp, TB}}, H4, H, gw + E + F, ld));
     SSC_TRY(gemm(c, false, false, {{dga, H4, hd_prev, l.Hp, TB}}, H4, H, gw + E + F + H, ld));
   }
-  if (g->att_w_hh) SSC_TRY(gemm(c, false, false, {{dga, H4, h1_prev, l.Hp, TB}}, H4, H, g->att_w_hh, g->ld_att_w_hh));
+  if (g->att_w_hh) {
+    // dW_hh^att = dGa^T H1_prev is the same product as the h1' block of dW_ih^att (both multiply h1'): copy, do not recompute
+    if (g->att_w_ih) {
+      if (hipMemcpy2DAsync(g->att_w_hh, (size_t)g->ld_att_w_hh * sizeof(float), g->att_w_ih + E + F,
+                           (size_t)g->ld_att_w_ih * sizeof(float), (size_t)H * sizeof(float), H4, hipMemcpyDeviceToDevice,
+                           st) != hipSuccess)
+        return SSC_EHIP;
+    } else {
+      SSC_TRY(gemm(c, false, false, {{dga, H4, h1_prev, l.Hp, TB}}, H4, H, g->att_w_hh, g->ld_att_w_hh));
+    }
+  }
   if (g->att_b_ih && g->att_b_hh) {
     SSC_TRY(ssc_colsum2(dga, H4, TB, H4, nullptr, g->att_b_ih, 1, g->att_b_hh, 0, c.slabs, st));
   } else {
@@ -576,7 +586,17 @@ static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const s
     if (S) SSC_TRY(ssc_colsum2(dgd, H4, TB, H4, W + l.sent_all, gw + F + 2 * H, ld, nullptr, 0, c.slabs, st));
     SSC_TRY(gemm(c, false, false, {{dgd, H4, W + l.z, l.Zp, TB}}, H4, Z, gw + zcol, ld));
   }
-  if (g->dec_w_hh) SSC_TRY(gemm(c, false, false, {{dgd, H4, hd_prev, l.Hp, TB}}, H4, H, g->dec_w_hh, g->ld_dec_w_hh));
+  if (g->dec_w_hh) {
+    // dW_hh^dec = dGd^T HD_prev is the same product as the hd' block of dW_ih^dec
+    if (g->dec_w_ih) {
+      if (hipMemcpy2DAsync(g->dec_w_hh, (size_t)g->ld_dec_w_hh * sizeof(float), g->dec_w_ih + F + H,
+                           (size_t)g->ld_dec_w_ih * sizeof(float), (size_t)H * sizeof(float), H4, hipMemcpyDeviceToDevice,
+                           st) != hipSuccess)
+        return SSC_EHIP;
+    } else {
+      SSC_TRY(gemm(c, false, false, {{dgd, H4, hd_prev, l.Hp, TB}}, H4, H, g->dec_w_hh, g->ld_dec_w_hh));
+    }
+  }
   if (g->dec_b_ih && g->dec_b_hh) {
     SSC_TRY(ssc_colsum2(dgd, H4, TB, H4, nullptr, g->dec_b_ih, 1, g->dec_b_hh, 0, c.slabs, st));
   } else {
