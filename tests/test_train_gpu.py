@@ -81,3 +81,32 @@ def test_train_matches_oracle_medium(sv, B, R, dims):
     got = eng.grad_dict()
     for k, v in p.items():
         assert maxdiff(got[k], v.grad) < TOL, k
+
+
+def test_stress_shape_c5_like_regions_and_length():
+    """BASELINE configs[4] geometry (R=100 regions, L=40 -> T=41, B=128) at reduced widths: parity vs the oracle."""
+    cfg = oracle.OracleConfig(vocab_size=1500, image_feature_size=256, embedding_size=96, hidden_size=128,
+                              attention_projection_size=64, z_space=32, max_caption_length=40, sentiment_vae=1,
+                              senti_prior_multip=0.5)
+    params = oracle.init_params(cfg, seed=9)
+    g = torch.Generator().manual_seed(23)
+    B, R, L = 128, 100, 40
+    feats = torch.randn(B, R, 256, generator=g)
+    feats[3, 60:] = 0
+    caps = torch.zeros(B, L, dtype=torch.long)
+    for b in range(B):
+        n = int(torch.randint(5, L + 1, (1,), generator=g))
+        caps[b, :n] = torch.randint(2, 1500, (n,), generator=g)
+    senti = torch.randint(-1, 2, (B, 1), generator=g).float()
+    eps = torch.randn(L + 1, B, 32, generator=g)
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    out = oracle.train_forward(p, cfg, feats, caps, senti, eps)
+    oracle.train_objective(out, cfg).backward()
+    eng = engine_from(cfg, params)
+    loss, kld = eng.forward(dev(feats), dev(caps), dev(senti), dev(eps))
+    assert maxdiff(loss, out["loss"]) < 1e-3      # loss ~ O(250): 4e-6 relative
+    assert maxdiff(kld, out["kld"]) < 1e-3
+    eng.backward(torch.full((B,), 1.0 / B, device="cuda"), torch.full((B,), 1.0 / (B * cfg.kld_weight), device="cuda"))
+    got = eng.grad_dict()
+    for k, v in p.items():
+        assert maxdiff(got[k], v.grad) < TOL, k
