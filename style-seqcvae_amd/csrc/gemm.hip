@@ -181,17 +181,19 @@ struct Cursor {
     left = g.seg[seg].nsteps - 1 - k0 / BK;
   }
   // move to the next k-step unless `stay` (past the end of this workgroup's range: keep re-reading the last tile)
-  __device__ __forceinline__ void advance(const KArgs& g, bool stay) {
-    if (stay) return;
+  // returns 0: stayed, 1: next k-step of the same segment, 2: first k-step of the next segment
+  __device__ __forceinline__ int advance(const KArgs& g, bool stay) {
+    if (stay) return 0;
     if (left > 0) {
       --left;
       k0 += BK;
-    } else {
-      ++seg;
-      fetch(g);
-      k0 = 0;
-      left = g.seg[seg].nsteps - 1;
+      return 1;
     }
+    ++seg;
+    fetch(g);
+    k0 = 0;
+    left = g.seg[seg].nsteps - 1;
+    return 2;
   }
 };
 
@@ -257,6 +259,36 @@ struct Stage<A_KC, B_KC, RA, RB, true> {
     // timing-only ablations (SSC_GEMM_DBG): 16 / 32 make every A / B load hit one cached line (no memory traffic)
     oka = issue<A_KC, RA, NVA>(a, c.A, (g.dbg & 16) ? 0 : c.lda, g.M, c.K, (g.dbg & 16) ? 0 : m0, (g.dbg & 16) ? 0 : c.k0, tid);
     okb = issue<B_KC, RB, NVB>(b, c.B, (g.dbg & 32) ? 0 : c.ldb, g.N, c.K, (g.dbg & 32) ? 0 : n0, (g.dbg & 32) ? 0 : c.k0, tid);
+  }
+
+  // NT fast path: per-thread chunk pointers kept across k-steps (advanced by 32 floats per step, recomputed on a
+  // segment change), so the steady state issues its loads without any 64-bit multiply / clamp arithmetic.
+  // `full` = the whole 32-wide step is inside the segment (no k clamp, all chunks valid).
+  __device__ __forceinline__ void load_ptrs(const float* const (&pa)[NVA], const float* const (&pb)[NVB], bool full, int k0,
+                                            int K, int tid) {
+    oka = okb = 0xffffffffu;
+    if (full) {
+#pragma unroll
+      for (int u = 0; u < NVA; ++u) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(a[u]) : "v"(pa[u]) : "memory");
+#pragma unroll
+      for (int u = 0; u < NVB; ++u) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(b[u]) : "v"(pb[u]) : "memory");
+    } else {  // tail step of a segment: clamp the chunk's k into range, remember which chunks are out of range
+      oka = okb = 0;
+#pragma unroll
+      for (int u = 0; u < NVA; ++u) {
+        const int k = k0 + 4 * ((tid + 256 * u) & 7);
+        const float* p = pa[u] + (min(k, K - 4) - k);
+        oka |= (k < K ? 1u : 0u) << u;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(a[u]) : "v"(p) : "memory");
+      }
+#pragma unroll
+      for (int u = 0; u < NVB; ++u) {
+        const int k = k0 + 4 * ((tid + 256 * u) & 7);
+        const float* p = pb[u] + (min(k, K - 4) - k);
+        okb |= (k < K ? 1u : 0u) << u;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(b[u]) : "v"(p) : "memory");
+      }
+    }
   }
 
   template <int YOUNGER>
@@ -543,15 +575,41 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const KArgs a) {
 
   Cursor cur;
   int s_ld = s_lo;
+  const float* tpa[StageT::NVA];
+  const float* tpb[StageT::NVB];
+  auto recompute_ptrs = [&]() {
+#pragma unroll
+    for (int u = 0; u < StageT::NVA; ++u) {
+      const int idx = tid + 256 * u;
+      tpa[u] = cur.A + (size_t)min(m0 + (idx >> 3), a.M - 1) * cur.lda + cur.k0 + 4 * (idx & 7);
+    }
+#pragma unroll
+    for (int u = 0; u < StageT::NVB; ++u) {
+      const int idx = tid + 256 * u;
+      tpb[u] = cur.B + (size_t)min(n0 + (idx >> 3), a.N - 1) * cur.ldb + cur.k0 + 4 * (idx & 7);
+    }
+  };
+  auto step_ptrs = [&](int how) {  // how: Cursor::advance result
+    if (how == 1) {
+#pragma unroll
+      for (int u = 0; u < StageT::NVA; ++u) tpa[u] += BK;
+#pragma unroll
+      for (int u = 0; u < StageT::NVB; ++u) tpb[u] += BK;
+    } else if (how == 2) {
+      recompute_ptrs();
+    }
+  };
+  auto issue_loads = [&](StageT& x) { x.load_ptrs(tpa, tpb, cur.k0 + BK <= cur.K, cur.k0, cur.K, tid); };
   if (s_lo < s_hi) {
     cur.init(a, s_lo);
-    st[0].load(a, cur, m0, n0, tid);
+    recompute_ptrs();
+    issue_loads(st[0]);
     st[0].template wait<0>();
     put_planes(lds, st[0]);
 #pragma unroll
     for (int j = 0; j < PF; ++j) {
-      cur.advance(a, s_ld >= s_last); s_ld = min(s_ld + 1, s_last);
-      st[j].load(a, cur, m0, n0, tid);
+      step_ptrs(cur.advance(a, s_ld >= s_last)); s_ld = min(s_ld + 1, s_last);
+      issue_loads(st[j]);
     }
   }
   __syncthreads();
@@ -605,8 +663,8 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const KArgs a) {
           __syncthreads();  // every wave is done reading the single stage
           put_planes(lds, x);
         }
-        cur.advance(a, s_ld >= s_last); s_ld = min(s_ld + 1, s_last);
-        x.load(a, cur, m0, n0, tid);
+        step_ptrs(cur.advance(a, s_ld >= s_last)); s_ld = min(s_ld + 1, s_last);
+        issue_loads(x);
         __syncthreads();
       }
     }
@@ -713,7 +771,8 @@ inline int gemm_mode() {
 }
 inline bool use_x3(const ssc_gemm_desc* d, bool vec) { return gemm_mode() == 1 && d->a_kc && d->b_kc && vec; }
 int g_x3_nbuf = 1;  // single LDS stage: 31 KB per workgroup -> four resident workgroups per CU (rocprof r01: 37 vs 43 us)
-int g_x3_wide = 0;  // tuning hook: 1 = 64x128 block tile for skinny (M <= 64, N >= 1024) 3xBF16 products
+int g_x3_wide = 0;
+int g_x3_pf = 2;  // tuning hook: 1 = 64x128 block tile for skinny (M <= 64, N >= 1024) 3xBF16 products
 inline bool x3_wide(int M, int N) { return g_x3_wide && M <= 64 && N >= 1024; }
 inline bool big_tile(int M, int N) { return M >= 512 && N >= 512; }
 // M <= 64 with a wide N: 64x128 block tile (wave tile 32x64).  Every workgroup re-reads the whole A operand
@@ -743,6 +802,8 @@ int launch(const ssc_gemm_desc* d, KArgs& k, int splits, hipStream_t st) {
     }
     if (wide && g_x3_nbuf == 1) hipLaunchKernelGGL((gemm_x3_kernel<2, 2, 1>), grid, dim3(256), 0, st, k);
     else if (wide) hipLaunchKernelGGL((gemm_x3_kernel<2, 2, 2>), grid, dim3(256), 0, st, k);
+    else if (g_x3_nbuf == 1 && g_x3_pf == 4) hipLaunchKernelGGL((gemm_x3_kernel<4, 1, 1>), grid, dim3(256), 0, st, k);
+    else if (g_x3_nbuf == 1 && g_x3_pf == 1) hipLaunchKernelGGL((gemm_x3_kernel<1, 1, 1>), grid, dim3(256), 0, st, k);
     else if (g_x3_nbuf == 1) hipLaunchKernelGGL((gemm_x3_kernel<2, 1, 1>), grid, dim3(256), 0, st, k);
     else hipLaunchKernelGGL((gemm_x3_kernel<2, 1, 2>), grid, dim3(256), 0, st, k);
     if (rec) (void)hipEventRecord(rec->e1, st);
@@ -937,6 +998,9 @@ extern "C" int ssc_set_gemm_wide_min_n(int n) {
   if (n == -2) g_x3_wide = 0;
   if (n == -3) g_x3_nbuf = 1;
   if (n == -4) g_x3_nbuf = 2;
+  if (n == -5) g_x3_pf = 1;
+  if (n == -6) g_x3_pf = 2;
+  if (n == -7) g_x3_pf = 4;
   return prev;
 }
 

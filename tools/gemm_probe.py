@@ -21,6 +21,10 @@ def main():
     from ssc_runtime import lib as _L
     if _os.environ.get("SSC_X3_WIDE"):
         _L.load().ssc_set_gemm_wide_min_n(-1)
+    if _os.environ.get("SSC_X3_PF"):
+        _L.load().ssc_set_gemm_wide_min_n({"1": -5, "2": -6, "4": -7}[_os.environ["SSC_X3_PF"]])
+    if _os.environ.get("SSC_X3_NBUF") == "2":
+        _L.load().ssc_set_gemm_wide_min_n(-4)
     if _os.environ.get("SSC_X3_NBUF") == "1":
         _L.load().ssc_set_gemm_wide_min_n(-3)
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
