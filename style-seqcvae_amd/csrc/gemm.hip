@@ -264,30 +264,38 @@ struct Stage<A_KC, B_KC, RA, RB, true> {
   // NT fast path: per-thread chunk pointers kept across k-steps (advanced by 32 floats per step, recomputed on a
   // segment change), so the steady state issues its loads without any 64-bit multiply / clamp arithmetic.
   // `full` = the whole 32-wide step is inside the segment (no k clamp, all chunks valid).
+  template <bool KC, int ROWS, int NV>
+  static __device__ __forceinline__ unsigned tail_issue(f32x4 (&r)[NV], const float* const (&p)[NV], int k0, int K, int ld, int tid) {
+    unsigned okm = 0;
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int idx = tid + 256 * u;
+      const float* q;
+      if constexpr (KC) {
+        const int k = k0 + 4 * (idx & 7);
+        q = p[u] + (min(k, K - 4) - k);
+        okm |= (k < K ? 1u : 0u) << u;
+      } else {
+        const int gk = k0 + idx / (ROWS / 4);
+        q = p[u] + (ptrdiff_t)(min(gk, K - 1) - gk) * ld;
+        okm |= (gk < K ? 1u : 0u) << u;
+      }
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(r[u]) : "v"(q) : "memory");
+    }
+    return okm;
+  }
+  // `full` = the whole 32-wide k-step lies inside the segment (no clamp, every chunk valid)
   __device__ __forceinline__ void load_ptrs(const float* const (&pa)[NVA], const float* const (&pb)[NVB], bool full, int k0,
-                                            int K, int tid) {
-    oka = okb = 0xffffffffu;
+                                            int K, int lda, int ldb, int tid) {
     if (full) {
+      oka = okb = 0xffffffffu;
 #pragma unroll
       for (int u = 0; u < NVA; ++u) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(a[u]) : "v"(pa[u]) : "memory");
 #pragma unroll
       for (int u = 0; u < NVB; ++u) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(b[u]) : "v"(pb[u]) : "memory");
-    } else {  // tail step of a segment: clamp the chunk's k into range, remember which chunks are out of range
-      oka = okb = 0;
-#pragma unroll
-      for (int u = 0; u < NVA; ++u) {
-        const int k = k0 + 4 * ((tid + 256 * u) & 7);
-        const float* p = pa[u] + (min(k, K - 4) - k);
-        oka |= (k < K ? 1u : 0u) << u;
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(a[u]) : "v"(p) : "memory");
-      }
-#pragma unroll
-      for (int u = 0; u < NVB; ++u) {
-        const int k = k0 + 4 * ((tid + 256 * u) & 7);
-        const float* p = pb[u] + (min(k, K - 4) - k);
-        okb |= (k < K ? 1u : 0u) << u;
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(b[u]) : "v"(p) : "memory");
-      }
+    } else {  // tail step of a segment: clamp into range, remember which chunks are out of range
+      oka = tail_issue<A_KC, RA, NVA>(a, pa, k0, K, lda, tid);
+      okb = tail_issue<B_KC, RB, NVB>(b, pb, k0, K, ldb, tid);
     }
   }
 
@@ -324,6 +332,40 @@ struct Stage<A_KC, B_KC, RA, RB, true> {
   __device__ __forceinline__ void store(float* As, float* Bs, int tid) const {
     put<A_KC, RA, NVA>(As, a, tid, oka);
     put<B_KC, RB, NVB>(Bs, b, tid, okb);
+  }
+};
+
+// Per-thread chunk pointers of the 16 B/lane kernels, kept across k-steps: advanced by one k-step (32 floats for a
+// k-contiguous operand, 32 rows for an m/n-contiguous one) and recomputed only when the segment changes, so the
+// steady state issues its loads without 64-bit multiply / clamp arithmetic.
+template <bool A_KC, bool B_KC, int RA, int RB>
+struct ThreadPtrs {
+  static constexpr int NVA = RA / 32, NVB = RB / 32;
+  const float* pa[NVA];
+  const float* pb[NVB];
+  template <bool KC, int ROWS, int NV>
+  static __device__ __forceinline__ void base(const float* (&p)[NV], const float* src, int ld, int rows, int row0, int k0, int tid) {
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int idx = tid + 256 * u;
+      if constexpr (KC) p[u] = src + (size_t)min(row0 + (idx >> 3), rows - 1) * ld + k0 + 4 * (idx & 7);
+      else p[u] = src + (size_t)(k0 + idx / (ROWS / 4)) * ld + min(row0 + 4 * (idx % (ROWS / 4)), rows - 4);
+    }
+  }
+  __device__ __forceinline__ void recompute(const KArgs& g, const Cursor& c, int m0, int n0, int tid) {
+    base<A_KC, RA, NVA>(pa, c.A, c.lda, g.M, m0, c.k0, tid);
+    base<B_KC, RB, NVB>(pb, c.B, c.ldb, g.N, n0, c.k0, tid);
+  }
+  __device__ __forceinline__ void step(const KArgs& g, const Cursor& c, int how, int m0, int n0, int tid) {
+    if (how == 1) {
+      const size_t da = A_KC ? (size_t)BK : (size_t)BK * c.lda, db = B_KC ? (size_t)BK : (size_t)BK * c.ldb;
+#pragma unroll
+      for (int u = 0; u < NVA; ++u) pa[u] += da;
+#pragma unroll
+      for (int u = 0; u < NVB; ++u) pb[u] += db;
+    } else if (how == 2) {
+      recompute(g, c, m0, n0, tid);
+    }
   }
 };
 
@@ -375,15 +417,26 @@ __global__ __launch_bounds__(256) void gemm_kernel(const KArgs a) {
   // Loads are unconditional - a step index past the end is clamped and re-reads the last tile, which is never stored.
   Cursor cur;
   int s_ld = s_lo;  // step the cursor points at (the newest tile requested)
+  ThreadPtrs<A_KC, B_KC, RA, RB> tp;
+  auto issue_loads = [&](StageT& x) {
+    if constexpr (VEC) x.load_ptrs(tp.pa, tp.pb, cur.k0 + BK <= cur.K, cur.k0, cur.K, cur.lda, cur.ldb, tid);
+    else x.load(a, cur, m0, n0, tid);
+  };
+  auto advance = [&]() {
+    const int how = cur.advance(a, s_ld >= s_last);
+    s_ld = min(s_ld + 1, s_last);
+    if constexpr (VEC) tp.step(a, cur, how, m0, n0, tid);
+  };
   if (s_lo < s_hi) {
     cur.init(a, s_lo);
-    st[0].load(a, cur, m0, n0, tid);
+    if constexpr (VEC) tp.recompute(a, cur, m0, n0, tid);
+    issue_loads(st[0]);
     st[0].template wait<0>();
     st[0].store(As, Bs, tid);
 #pragma unroll
     for (int j = 0; j < PF; ++j) {
-      cur.advance(a, s_ld >= s_last); s_ld = min(s_ld + 1, s_last);
-      st[j].load(a, cur, m0, n0, tid);
+      advance();
+      issue_loads(st[j]);
     }
   }
   __syncthreads();
@@ -575,40 +628,17 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const KArgs a) {
 
   Cursor cur;
   int s_ld = s_lo;
-  const float* tpa[StageT::NVA];
-  const float* tpb[StageT::NVB];
-  auto recompute_ptrs = [&]() {
-#pragma unroll
-    for (int u = 0; u < StageT::NVA; ++u) {
-      const int idx = tid + 256 * u;
-      tpa[u] = cur.A + (size_t)min(m0 + (idx >> 3), a.M - 1) * cur.lda + cur.k0 + 4 * (idx & 7);
-    }
-#pragma unroll
-    for (int u = 0; u < StageT::NVB; ++u) {
-      const int idx = tid + 256 * u;
-      tpb[u] = cur.B + (size_t)min(n0 + (idx >> 3), a.N - 1) * cur.ldb + cur.k0 + 4 * (idx & 7);
-    }
-  };
-  auto step_ptrs = [&](int how) {  // how: Cursor::advance result
-    if (how == 1) {
-#pragma unroll
-      for (int u = 0; u < StageT::NVA; ++u) tpa[u] += BK;
-#pragma unroll
-      for (int u = 0; u < StageT::NVB; ++u) tpb[u] += BK;
-    } else if (how == 2) {
-      recompute_ptrs();
-    }
-  };
-  auto issue_loads = [&](StageT& x) { x.load_ptrs(tpa, tpb, cur.k0 + BK <= cur.K, cur.k0, cur.K, tid); };
+  ThreadPtrs<true, true, 64, RB> tp;
+  auto issue_loads = [&](StageT& x) { x.load_ptrs(tp.pa, tp.pb, cur.k0 + BK <= cur.K, cur.k0, cur.K, cur.lda, cur.ldb, tid); };
   if (s_lo < s_hi) {
     cur.init(a, s_lo);
-    recompute_ptrs();
+    tp.recompute(a, cur, m0, n0, tid);
     issue_loads(st[0]);
     st[0].template wait<0>();
     put_planes(lds, st[0]);
 #pragma unroll
     for (int j = 0; j < PF; ++j) {
-      step_ptrs(cur.advance(a, s_ld >= s_last)); s_ld = min(s_ld + 1, s_last);
+      tp.step(a, cur, cur.advance(a, s_ld >= s_last), m0, n0, tid); s_ld = min(s_ld + 1, s_last);
       issue_loads(st[j]);
     }
   }
@@ -663,7 +693,7 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const KArgs a) {
           __syncthreads();  // every wave is done reading the single stage
           put_planes(lds, x);
         }
-        step_ptrs(cur.advance(a, s_ld >= s_last)); s_ld = min(s_ld + 1, s_last);
+        tp.step(a, cur, cur.advance(a, s_ld >= s_last), m0, n0, tid); s_ld = min(s_ld + 1, s_last);
         issue_loads(x);
         __syncthreads();
       }
