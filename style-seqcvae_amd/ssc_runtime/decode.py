@@ -100,7 +100,8 @@ DecodeEngine.step_from_embedding = DecodeEngine._step_from_embedding
 
 
 def cbs_search(start_predictions: torch.Tensor, start_state, step: Callable, fsm: torch.Tensor, end_index: int,
-               max_steps: int, beam_size: int, per_node_beam_size: int, early_stop: bool = True):
+               max_steps: int, beam_size: int, per_node_beam_size: int, early_stop: bool = True,
+               early_stop_every: int = 1):
     """Constrained beam search with on-device bookkeeping (ssc_beam_first / ssc_beam_step / ssc_gather_rows /
     ssc_beam_backtrace).  `step(tokens (G,), state) -> (log_probs (G,V), state, ...)` as in cbs.py:127,170.
     Returns (predictions (B,S,beam,steps) int64, log_probs (B,S,beam))."""
@@ -131,7 +132,10 @@ def cbs_search(start_predictions: torch.Tensor, start_state, step: Callable, fsm
     nsteps = 1
     for t in range(1, max_steps):
         last = preds[t - 1].reshape(B * SB)
-        if early_stop and bool((last == end_index).all()):  # cbs.py:167 (host sync, as in the reference)
+        # cbs.py:167 stops as soon as every beam has ended (a host sync per step in the reference).  Steps taken after
+        # that point change nothing (ended beams re-emit END at log-prob +0), so the check may run every
+        # `early_stop_every` steps and the surplus columns are trimmed below: same output, fewer syncs.
+        if early_stop and (t - 1) % early_stop_every == 0 and bool((last == end_index).all()):
             break
         out = step(last, state)
         lp, state = out[0].contiguous(), out[1]
@@ -150,4 +154,12 @@ def cbs_search(start_predictions: torch.Tensor, start_state, step: Callable, fsm
         nsteps += 1
     allp = torch.empty(B, SB, nsteps, dtype=torch.int64, device=dev)
     lib.ssc_beam_backtrace(_lib.ptr(preds), _lib.ptr(backs), nsteps, B, SB, _lib.ptr(allp), st())
+    if early_stop and early_stop_every > 1 and nsteps > 1:
+        # trim trailing all-END columns beyond the first one (what a per-step check would never have produced)
+        all_end = (allp == end_index).all(dim=0).all(dim=0)            # (nsteps,)
+        keep = nsteps
+        while keep > 1 and bool(all_end[keep - 1]) and bool(all_end[keep - 2]):
+            keep -= 1
+        allp = allp[:, :, :keep].contiguous()
+        nsteps = keep
     return allp.view(B, S, beam_size, nsteps), last_lp

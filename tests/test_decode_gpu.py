@@ -78,3 +78,30 @@ def test_eval_forward_matches_oracle(sv):
     o1 = m1(dev(feats), None, None, sentiment=dev(senti))["predictions"]
     w1 = oracle.eval_forward(params, cfg, feats, senti, fsm, torch.tensor([0]), [e[:1] for e in eps], beam_size=1)
     assert torch.equal(o1.cpu(), w1["predictions"])
+
+
+def test_batched_diverse_decode_matches_oracle_per_sample():
+    """ssc_runtime.inference.diverse_decode (images x latent samples as ONE beam search, early-stop check every 4th
+    step + trimming) equals the oracle run with one batch entry per (image, sample)."""
+    from ssc_runtime.inference import diverse_decode
+    cfg = oracle.OracleConfig(vocab_size=90, image_feature_size=48, embedding_size=24, hidden_size=32,
+                              attention_projection_size=16, z_space=8, max_caption_length=9, sentiment_vae=1,
+                              senti_prior_multip=0.5, beam_size=3)
+    params = oracle.init_params(cfg, seed=13)
+    params["_output_layer.bias"][1] += 3.0  # captions end early: exercises the early-stop / trimming path
+    g = torch.Generator().manual_seed(8)
+    nimg, ns, beam, R = 2, 3, 3, 5
+    feats = torch.randn(nimg, R, 48, generator=g)
+    senti = torch.tensor([1.0, -1.0])
+    B = nimg * ns
+    eps = [torch.randn(B, 8, generator=g)] + [torch.randn(B * beam, 8, generator=g) for _ in range(12)]
+    fsm = torch.ones(B, 1, 1, 90, dtype=torch.uint8)
+    feats_rep = feats.unsqueeze(1).expand(nimg, ns, R, 48).reshape(B, R, 48)
+    senti_rep = senti.view(nimg, 1).expand(nimg, ns).reshape(B, 1)
+    want = oracle.eval_forward(params, cfg, feats_rep, senti_rep, fsm, torch.zeros(B, dtype=torch.long), eps, beam_size=beam)
+    m = build_model(cfg, params, beam=beam)
+    m.eval()
+    m._engine()
+    got, calls = diverse_decode(m._dec, dev(feats), dev(senti), ns, beam, cfg.max_caption_length, 1,
+                                eps_steps=[e.clone() for e in eps])
+    assert torch.equal(got.cpu().view(B, -1), want["predictions"])
