@@ -15,6 +15,7 @@ import torch
 from torch import nn
 
 from ssc_runtime import lib as _lib
+from ssc_runtime.cellops import cell_train_step
 from ssc_runtime.decode import DecodeEngine
 from ssc_runtime.decoding import select_best_beam_with_constraints
 from ssc_runtime.engine import FIELD_OF, ModelDims, TrainEngine
@@ -233,8 +234,28 @@ class UpDownCaptioner(nn.Module):
         (log_probs, states, prior_mean, prior_log_var, attention_weights).  prior_mean / prior_var are derived from
         `sentiment` (SENTI_PRIOR_MULTIP, PRIOR_STD) exactly as forward() does (:249-261)."""
         if self.training:
-            raise RuntimeError("training-mode stepping is fused: call forward(image_features, ..., caption_tokens, "
-                               "sentiment); _decode_step is the eval-mode (beam search) step")
+            # stand-alone training-mode step (no autograd): the 7-tuple of updown_captioner.py:452-453.  The
+            # differentiable path is forward(), which fuses all T steps.
+            eng = self._engine()
+            G = previous_predictions.size(0)
+            emb = self._embedding_layer.weight.detach()[previous_predictions.to(eng.device)]
+            eps = self._eps_override.pop(0) if self._eps_override is not None else (
+                torch.randn(G, self.z_space, device=eng.device) if self.eps_source == "device" else torch.randn(G, self.z_space))
+            h_dec, states, mean, log_var, alpha = cell_train_step(eng.dims, eng.params.views, image_features.to(eng.device),
+                                                                  emb, states, sentiment, eps)
+            d = eng.dims
+            logits = torch.empty(G, d.V, device=eng.device)
+            lib = _lib.load()
+            if self._tied:
+                raise NotImplementedError("stand-alone training step with the tied head: use forward()")
+            ow = eng.params.views["_output_layer.weight"]
+            from ssc_runtime.cellops import _gemm
+            _gemm(lib, [(h_dec.data_ptr(), d.H, ow.data_ptr(), ow.stride(0), d.H)], G, d.V, logits,
+                  bias=eng.params.views["_output_layer.bias"])
+            pm = (sentiment.reshape(G, 1).to(eng.device) * d.pm_scale).expand(G, self.z_space) if (
+                sentiment is not None and d.pm_scale != 0.0) else torch.zeros(G, self.z_space, device=eng.device)
+            plv = torch.full((G, self.z_space), float(torch.log(torch.tensor(d.prior_var))), device=eng.device)
+            return logits, states, mean, log_var, pm, plv, alpha
         eng = self._engine()
         dev = eng.device
         B = image_features.size(0)
@@ -256,9 +277,20 @@ class UpDownCaptioner(nn.Module):
 
     def _cell_forward(self, image_features, token_embedding, states, training, sentiment, prior_mean, prior_var, eps):
         """UpDownCell.forward backend (eval branch; updown_cell.py:86-231 with training=False)."""
-        if training:
-            raise NotImplementedError("UpDownCell.forward(training=True): the training recurrence is fused into "
-                                      "UpDownCaptioner.forward (ssc_train_fwd); single-step training is not exposed")
+        if training:  # stand-alone training-mode cell step (encoder LSTM + posterior sample), no autograd
+            eng = self._engine()
+            G = token_embedding.size(0)
+            if eps is None:
+                eps = torch.randn(G, self.z_space)
+            h_dec, new_states, mean, log_var, alpha = cell_train_step(eng.dims, eng.params.views,
+                                                                      image_features.to(eng.device), token_embedding.to(eng.device),
+                                                                      states, sentiment, eps)
+            d = eng.dims
+            pm = prior_mean if prior_mean is not None else torch.zeros(G, self.z_space, device=eng.device)
+            if self.simple_vae:
+                pm = torch.zeros_like(pm)
+            pv = prior_var if prior_var is not None else torch.full((G, self.z_space), d.prior_var, device=eng.device)
+            return h_dec, new_states, mean, log_var, pm, pv.log(), alpha
         eng = self._engine()
         G = token_embedding.size(0)
         B = image_features.size(0)

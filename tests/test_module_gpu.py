@@ -130,3 +130,29 @@ def test_tied_module_and_cpu_call_fails_loudly():
               z_space=cfg.z_space, prior_std=1.0, latent_embedding="glove", sentiment_vae=1, device="cpu")
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m2(ins["feats"], None, None, ins["caps"], ins["sentiment"])
+
+
+def test_standalone_training_cell_step_matches_reference_step0_and_1():
+    """UpDownCell.forward(training=True) / UpDownCaptioner._decode_step in training mode (op-level composition, no
+    autograd) reproduce the reference's per-step states of the training fixture."""
+    d, cfgd = load("g1_train_sv1")
+    cfg = oracle.OracleConfig(**cfgd)
+    params = group(d, "param/")
+    m = build_model(cfg, params)
+    m.train()
+    ins = group(d, "in/")
+    feats, caps, senti, eps = dev(ins["feats"]), ins["caps"], dev(ins["sentiment"]), ins["eps"]
+    tokens, _ = oracle.add_sentence_boundary_token_ids(caps, caps != 0, 1, 1)
+    states = None
+    for t in (0, 1):
+        m._eps_override = [eps[t]]
+        logits, states, mean, log_var, pm, plv, alpha = m._decode_step(feats, None, tokens[:, t].cuda(), states, sentiment=senti)
+        st = group(d, f"step{t}/")
+        for k in ("h1", "c1", "h_encoder", "c_encoder", "h_decoder", "c_decoder"):
+            assert maxdiff(states[k], st[k]) < TOL, (t, k)
+        assert maxdiff(alpha, st["alpha"]) < TOL and maxdiff(mean, st["mean"]) < TOL and maxdiff(log_var, st["log_var"]) < TOL
+        assert maxdiff(logits, st["logits"]) < TOL
+    # the cell API itself
+    emb = m._embedding_layer.weight.detach()[tokens[:, 0].cuda()]
+    out = m._updown_cell(feats, None, emb, None, True, senti, None, None, None, eps=eps[0])
+    assert maxdiff(out[0], group(d, "step0/")["h_decoder"]) < TOL and len(out) == 7
