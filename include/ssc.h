@@ -65,6 +65,15 @@ typedef struct {
   int accumulate;      /* 1: C += result */
   int splits;          /* >=1; 0 = choose automatically */
   float* workspace; size_t workspace_floats;
+  /* Optional device-side row compaction (all NULL = off).  Counts and index lists live in device memory, so the host
+   * needs no synchronisation to know how many rows are active; the launch covers the full M / K and workgroups beyond
+   * the device count exit.  Only with 16-B aligned operands (else SSC_EALIGN).
+   *   m_count: M = min(M, *m_count); a_rows: row r of the k-contiguous A operand is read from row a_rows[r];
+   *   c_rows: row r of the result is written to row c_rows[r]   (NT / NN products)
+   *   k_count: K = min(K, *k_count); ka_rows / kb_rows: k-row k of A / B is read from row k?_rows[k]
+   *            (single-segment TN products, a_kc = b_kc = 0) */
+  const int* m_count; const int* a_rows; const int* c_rows;
+  const int* k_count; const int* ka_rows; const int* kb_rows;
 } ssc_gemm_desc;
 
 int ssc_gemm(const ssc_gemm_desc* d, void* stream);

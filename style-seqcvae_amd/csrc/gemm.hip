@@ -47,6 +47,13 @@ struct KArgs {
   const float* bias;
   int accumulate;
   int steps_total, steps_per_split;
+  // optional device-side row compaction (gemm_x3b_kernel only; see ssc_gemm_desc)
+  const int* mcount;  // M = min(M, *mcount)
+  const int* arows;   // A (k-contiguous) row r is read from row arows[r]
+  const int* crows;   // C row r is written to row crows[r]
+  const int* kcount;  // K = min(K, *kcount)            (single segment, m/n-contiguous operands)
+  const int* karows;  // A's k-row k is read from row karows[k]
+  const int* kbrows;  // B's k-row k is read from row kbrows[k]
   int dbg;  // timing-only ablation switches (SSC_GEMM_DBG env; results are wrong when set): 1 = no global loads in
             // the loop, 2 = no LDS stores, 4 = no barriers
 };
@@ -484,7 +491,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(const KArgs a) {
       }
     }
   }
-  if constexpr (VEC) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the clamped tail loads
+  // Drain the clamped tail loads.  Their results are never used, but the wait must still PIN the staged registers
+  // ("+v" in wait()): past the loop the compiler sees them as dead and would hand them to the epilogue's address
+  // arithmetic while the loads are still in flight - the returning data then lands in a live pointer (observed as a
+  // codegen-dependent memory fault).
+  if constexpr (VEC) {
+#pragma unroll
+    for (int j = 0; j < PF; ++j) st[j].template wait<0>();
+  }
 
   // epilogue: acc[r] -> row (r&3) + 8*(r>>2) + 4*half, col l31 of each 32x32 tile
   float* out = a.out + (size_t)z * a.slab_stride;
@@ -699,7 +713,9 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const KArgs a) {
       }
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // drain the clamped tail loads with the staged registers pinned (see gemm_kernel)
+#pragma unroll
+  for (int j = 0; j < PF; ++j) st[j].template wait<0>();
 
   float* out = a.out + (size_t)z * a.slab_stride;
 #pragma unroll
@@ -724,9 +740,313 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const KArgs a) {
   }
 }
 
+// =====================================================================================================
+// 3xBF16 kernel for LARGE products in all three operand layouts (NT, NN, TN): 128x128 block tile, 2x2 waves, each wave
+// a 64x64 tile (2x2 v_mfma_f32_32x32x16_bf16 tiles, 64 fp32 accumulators).  Per k-step of 32 a wave issues 48 MFMAs
+// against 24 16-byte LDS fragment reads, so the matrix pipe - not the LDS or the wave's instruction stream, which bound
+// the 64x64 kernels above - is the limit.  One LDS stage of six bf16 planes (60 KB: two workgroups per CU), one k-step
+// prefetched in registers.
+//
+// Operand images in LDS (10 240 B per plane either way):
+//   k-contiguous operand   [128 rows][32 bf16 + 16 B pad] (80-B rows, as gemm_x3_kernel): fragment = ds_read_b128
+//   m/n-contiguous operand [32 k][128 bf16 + 64 B pad] (320-B rows): the fp32 tile arrives k-major, is split and stored
+//     as it comes (no register transpose), and the fragment - 8 consecutive k of one column - is two
+//     ds_read_b64_tr_b16 (cdna_hip_programming.md T10): 320-B rows put the 4 k-rows x 64 B a 32-lane half touches on
+//     64 distinct banks.
+//
+// Device-side row compaction (ssc_gemm_desc m_count / a_rows / c_rows / k_count / ka_rows / kb_rows) lives here: the
+// padded (t, b) rows of a caption batch are skipped without the host knowing how many there are.  KG = k-row gather
+// lists are in use (weight-gradient products): the row numbers for step s+2 are fetched while step s+1 is in flight, so
+// the pointer arithmetic never waits on them in the steady state.
+// =====================================================================================================
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+constexpr int X3B_PLANE = 10240;
+constexpr int X3B_MC_ROW_B = 320;
+
+template <bool A_KC, bool B_KC, bool KG>
+__global__ __launch_bounds__(256, 2) void gemm_x3b_kernel(const KArgs a) {
+  constexpr int PLN = X3B_PLANE;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[6 * PLN];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int half = lane >> 5, l31 = lane & 31;
+  int bx = blockIdx.x, by = blockIdx.y;
+  {
+    const int gx = gridDim.x, total = gridDim.x * gridDim.y;
+    const int lin = by * gx + bx;
+    const int q = total >> 3, rem = total & 7;
+    const int xcd = lin & 7, slot = lin >> 3;
+    const int nl = xcd * q + (xcd < rem ? xcd : rem) + slot;
+    by = nl / gx;
+    bx = nl - by * gx;
+  }
+  const int n0 = bx * 128, m0 = by * 128, z = blockIdx.z;
+  const int Meff = a.mcount ? min(a.M, *a.mcount) : a.M;  // uniform per launch
+  if (m0 >= Meff) return;
+  const int Kc = a.kcount ? max(0, min(a.seg[0].K, *a.kcount)) : 0;
+  int steps_total = a.steps_total, steps_per_split = a.steps_per_split;
+  if (a.kcount) {  // K is known only on the device: partition the k-steps here
+    steps_total = (Kc + BK - 1) / BK;
+    steps_per_split = (steps_total + (int)gridDim.z - 1) / (int)gridDim.z;
+  }
+  const int s_lo = z * steps_per_split;
+  int s_hi = s_lo + steps_per_split;
+  if (s_hi > steps_total) s_hi = steps_total;
+  const int s_last = s_hi - 1;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mi][ni][i] = 0.f;
+
+  // ---- staged tile: 4 + 4 float4 per thread --------------------------------------------------------
+  f32x4 ra[4], rb[4];
+  unsigned oka = 0, okb = 0;
+  const float* pa[4];
+  const float* pb[4];
+  int ia[4], ib[4];  // KG: gathered k-row numbers of the NEXT step
+  Cursor cur;
+  int s_ld = s_lo;
+
+  // chunk u of this thread: k-contiguous operand -> (row idx>>3, k 4*(idx&7)); m/n-contiguous -> (k idx>>5, col 4*(idx&31))
+  auto base_ptrs = [&]() {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = tid + 256 * u;
+      if constexpr (A_KC) {
+        int r = min(m0 + (idx >> 3), Meff - 1);
+        if (a.arows) r = a.arows[r];
+        pa[u] = cur.A + (size_t)r * cur.lda + cur.k0 + 4 * (idx & 7);
+      } else {
+        int kr = cur.k0 + (idx >> 5);
+        if constexpr (KG) { if (a.karows) kr = a.karows[min(kr, cur.K - 1)]; }
+        pa[u] = cur.A + (size_t)kr * cur.lda + min(m0 + 4 * (idx & 31), Meff - 4);
+      }
+      if constexpr (B_KC) {
+        pb[u] = cur.B + (size_t)min(n0 + (idx >> 3), a.N - 1) * cur.ldb + cur.k0 + 4 * (idx & 7);
+      } else {
+        int kr = cur.k0 + (idx >> 5);
+        if constexpr (KG) { if (a.kbrows) kr = a.kbrows[min(kr, cur.K - 1)]; }
+        pb[u] = cur.B + (size_t)kr * cur.ldb + min(n0 + 4 * (idx & 31), a.N - 4);
+      }
+    }
+  };
+  // KG: fetch the row numbers of the k-step after the cursor's (clamped; a step past the end is never used)
+  auto prefetch_rows = [&]() {
+    if constexpr (KG) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int kr = min(cur.k0 + BK + ((tid + 256 * u) >> 5), cur.K - 1);
+        ia[u] = a.karows ? a.karows[kr] : kr;
+        ib[u] = a.kbrows ? a.kbrows[kr] : kr;
+      }
+    }
+  };
+  auto step_ptrs = [&](int how) {
+    if (how == 2) {
+      base_ptrs();
+    } else if (how == 1) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = tid + 256 * u;
+        if constexpr (A_KC) pa[u] += BK;
+        else if constexpr (KG) pa[u] = cur.A + (size_t)ia[u] * cur.lda + min(m0 + 4 * (idx & 31), Meff - 4);
+        else pa[u] += (size_t)BK * cur.lda;
+        if constexpr (B_KC) pb[u] += BK;
+        else if constexpr (KG) pb[u] = cur.B + (size_t)ib[u] * cur.ldb + min(n0 + 4 * (idx & 31), a.N - 4);
+        else pb[u] += (size_t)BK * cur.ldb;
+      }
+      prefetch_rows();
+    }
+  };
+  auto issue_loads = [&]() {
+    const bool full = cur.k0 + BK <= cur.K;
+    if (full) {
+      oka = okb = 0xfu;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(ra[u]) : "v"(pa[u]) : "memory");
+#pragma unroll
+      for (int u = 0; u < 4; ++u) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(rb[u]) : "v"(pb[u]) : "memory");
+    } else {  // last k-step of a segment: clamp into range, remember which chunks are past the end
+      oka = okb = 0;
+      const float* qa[4];
+      const float* qb[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = tid + 256 * u;
+        if constexpr (A_KC) {
+          const int k = cur.k0 + 4 * (idx & 7);
+          qa[u] = pa[u] + (min(k, cur.K - 4) - k);
+          oka |= (k < cur.K ? 1u : 0u) << u;
+        } else {
+          const int gk = cur.k0 + (idx >> 5);
+          qa[u] = KG ? pa[u] : pa[u] + (ptrdiff_t)(min(gk, cur.K - 1) - gk) * cur.lda;
+          oka |= (gk < cur.K ? 1u : 0u) << u;
+        }
+        if constexpr (B_KC) {
+          const int k = cur.k0 + 4 * (idx & 7);
+          qb[u] = pb[u] + (min(k, cur.K - 4) - k);
+          okb |= (k < cur.K ? 1u : 0u) << u;
+        } else {
+          const int gk = cur.k0 + (idx >> 5);
+          qb[u] = KG ? pb[u] : pb[u] + (ptrdiff_t)(min(gk, cur.K - 1) - gk) * cur.ldb;
+          okb |= (gk < cur.K ? 1u : 0u) << u;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(ra[u]) : "v"(qa[u]) : "memory");
+#pragma unroll
+      for (int u = 0; u < 4; ++u) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(rb[u]) : "v"(qb[u]) : "memory");
+    }
+  };
+  // all staged loads have landed; "+v" pins every use of the staged registers behind the wait
+  auto wait_loads = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3])::"memory");
+  };
+  auto advance = [&]() {
+    const int how = cur.advance(a, s_ld >= s_last);
+    s_ld = min(s_ld + 1, s_last);
+    step_ptrs(how);
+  };
+  // registers -> three bf16 planes per operand
+  auto put_planes = [&]() {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = tid + 256 * u;
+      f32x4 v = ra[u];
+      if (!((oka >> u) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      u32x2 hi, mid, lo;
+      split4(v, hi, mid, lo);
+      unsigned char* p = lds + (A_KC ? (idx >> 3) * PL_ROW_B + (idx & 7) * 8 : (idx >> 5) * X3B_MC_ROW_B + (idx & 31) * 8);
+      *reinterpret_cast<u32x2*>(p) = hi;
+      *reinterpret_cast<u32x2*>(p + PLN) = mid;
+      *reinterpret_cast<u32x2*>(p + 2 * PLN) = lo;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = tid + 256 * u;
+      f32x4 v = rb[u];
+      if (!((okb >> u) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      u32x2 hi, mid, lo;
+      split4(v, hi, mid, lo);
+      unsigned char* p = lds + 3 * PLN + (B_KC ? (idx >> 3) * PL_ROW_B + (idx & 7) * 8 : (idx >> 5) * X3B_MC_ROW_B + (idx & 31) * 8);
+      *reinterpret_cast<u32x2*>(p) = hi;
+      *reinterpret_cast<u32x2*>(p + PLN) = mid;
+      *reinterpret_cast<u32x2*>(p + 2 * PLN) = lo;
+    }
+  };
+
+  if (s_lo < s_hi) {
+    cur.init(a, s_lo);
+    if (a.kcount) { cur.K = Kc; cur.left = steps_total - 1 - cur.k0 / BK; }
+    base_ptrs();
+    prefetch_rows();
+    issue_loads();
+    wait_loads();
+    put_planes();
+    advance();
+    issue_loads();
+  }
+  __syncthreads();
+
+  // fragment = 8 consecutive k (16*kk + 8*half ...) of tile row/column `rc` of one plane
+  const int g16 = lane >> 4, i16 = lane & 15;
+  auto frag = [&](const unsigned char* plane, bool kc, int rc0, int kk) -> bf16x8 {
+    if (kc) {
+      return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(plane + (rc0 + l31) * PL_ROW_B + kk * 32 + half * 16));
+    } else {
+      // transposed read: lane 4q+p of a 16-lane group addresses k-row q, columns 4p..4p+3 of the group's 4 x 16 block and
+      // receives column (lane & 15), k-rows 0..3; the second read takes the next 4 k-rows
+      const unsigned char* p = plane + (16 * kk + 8 * (g16 >> 1) + (i16 >> 2)) * X3B_MC_ROW_B + (rc0 + 16 * (g16 & 1) + 4 * (i16 & 3)) * 2;
+      typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+      const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+      const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * X3B_MC_ROW_B));
+      typedef short s16x8 __attribute__((ext_vector_type(8)));
+      const s16x8 v = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+      return __builtin_bit_cast(bf16x8, v);
+    }
+  };
+  auto compute = [&]() {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 fa[2][3], fb[2][3];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          fa[t][pl] = frag(lds + pl * PLN, A_KC, wm * 64 + t * 32, kk);
+          fb[t][pl] = frag(lds + (3 + pl) * PLN, B_KC, wn * 64 + t * 32, kk);
+        }
+      // six partial products, smallest first; consecutive MFMAs go to different accumulators
+#define SSC_X3B_MFMA(PA, PB)                                                                                        \
+  _Pragma("unroll") for (int mi = 0; mi < 2; ++mi) _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = \
+      __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi][PA], fb[ni][PB], acc[mi][ni], 0, 0, 0);
+      SSC_X3B_MFMA(2, 0)
+      SSC_X3B_MFMA(0, 2)
+      SSC_X3B_MFMA(1, 1)
+      SSC_X3B_MFMA(1, 0)
+      SSC_X3B_MFMA(0, 1)
+      SSC_X3B_MFMA(0, 0)
+#undef SSC_X3B_MFMA
+    }
+  };
+
+  if ((a.dbg & 32) && ((blockIdx.y * gridDim.x + blockIdx.x) >> 8 & 1)) __builtin_amdgcn_s_setprio(2);
+  for (int s = s_lo; s < s_hi; ++s) {
+    if (a.dbg & 16) __builtin_amdgcn_s_setprio(2);
+    if (!(a.dbg & 8)) compute();
+    if (a.dbg & 16) __builtin_amdgcn_s_setprio(0);
+    wait_loads();
+    __syncthreads();  // every wave is done reading the stage
+    if (s + 1 < s_hi && !(a.dbg & 2)) put_planes();
+    advance();
+    if (!(a.dbg & 1)) issue_loads();
+    __syncthreads();
+  }
+  wait_loads();  // drain the clamped tail loads with the staged registers pinned (see gemm_kernel)
+
+  float* out = a.out + (size_t)z * a.slab_stride;
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int col = n0 + wn * 64 + ni * 32 + l31;
+    if (col >= a.N) continue;
+    const float bv = (a.bias != nullptr) ? a.bias[col] : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const int rbase = m0 + wm * 64 + mi * 32 + 4 * half;
+      int rr[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        rr[r] = min(rbase + (r & 3) + 8 * (r >> 2), Meff - 1);
+        if (a.crows) rr[r] = a.crows[rr[r]];
+      }
+      float old[16];
+      if (a.accumulate) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) old[r] = out[(size_t)rr[r] * a.ldo + col];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) old[r] = 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (rbase + (r & 3) + 8 * (r >> 2) < Meff) out[(size_t)rr[r] * a.ldo + col] = acc[mi][ni][r] + bv + old[r];
+      }
+    }
+  }
+}
+
+
 __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int nslab, size_t slab_stride, int M, int N,
-                                    float* __restrict__ C, int ldc, const float* __restrict__ bias, int accumulate) {
+                                    float* __restrict__ C, int ldc, const float* __restrict__ bias, int accumulate,
+                                    const int* __restrict__ mcount, const int* __restrict__ crows) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (mcount) M = min(M, *mcount);
   size_t total = (size_t)M * N;
   if (i >= total) return;
   int row = (int)(i / N), col = (int)(i % N);
@@ -739,6 +1059,7 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int nslab, 
     for (int u = 0; u < 8; ++u) v += (s0 + u < nslab) ? t[u] : 0.f;
   }
   if (bias) v += bias[col];
+  if (crows) row = crows[row];
   float* p = C + (size_t)row * ldc + col;
   if (accumulate) v += *p;
   *p = v;
@@ -761,6 +1082,8 @@ int build_args(const ssc_gemm_desc* d, KArgs& k) {
   k.nseg = d->nseg;
   k.M = d->M;
   k.N = d->N;
+  k.mcount = d->m_count; k.arows = d->a_rows; k.crows = d->c_rows;
+  k.kcount = d->k_count; k.karows = d->ka_rows; k.kbrows = d->kb_rows;
   k.steps_total = 0;
   for (int i = 0; i < d->nseg; ++i) {
     const ssc_gemm_seg& s = d->seg[i];
@@ -800,6 +1123,7 @@ inline int gemm_mode() {
   return g_gemm_mode;
 }
 inline bool use_x3(const ssc_gemm_desc* d, bool vec) { return gemm_mode() == 1 && d->a_kc && d->b_kc && vec; }
+int g_x3b = 1;     // large products (M, N >= 512) of any layout on the 128x128 3xBF16 kernel (tuning hook -8 / -9: off / on)
 int g_x3_nbuf = 1;  // single LDS stage: 31 KB per workgroup -> four resident workgroups per CU (rocprof r01: 37 vs 43 us)
 int g_x3_wide = 0;
 int g_x3_pf = 2;  // tuning hook: 1 = 64x128 block tile for skinny (M <= 64, N >= 1024) 3xBF16 products
@@ -820,6 +1144,32 @@ int launch(const ssc_gemm_desc* d, KArgs& k, int splits, hipStream_t st) {
   }
   bool vec = true;  // every segment of both operands must allow 16 B/lane loads, else the 4 B/lane kernel runs
   for (int i = 0; i < k.nseg; ++i) vec = vec && k.seg[i].avec && k.seg[i].bvec;
+  const bool compact = k.mcount || k.arows || k.crows || k.kcount || k.karows || k.kbrows;
+  if (compact) {  // device-side row compaction: gemm_x3b_kernel only
+    if (!vec) return SSC_EALIGN;
+    if (gemm_mode() != 1 || (!d->a_kc && d->b_kc)) return SSC_EINVAL;
+    if ((k.kcount || k.karows || k.kbrows) && (k.nseg != 1 || d->a_kc || d->b_kc)) return SSC_EINVAL;
+    if ((k.mcount || k.arows || k.crows) && !d->a_kc) return SSC_EINVAL;
+  }
+  if (gemm_mode() == 1 && vec && !(!d->a_kc && d->b_kc) && (compact || (g_x3b && big_tile(d->M, d->N)))) {
+    dim3 grid(ssc_cdiv(d->N, 128), ssc_cdiv(d->M, 128), splits);
+    ProfRec* rec = nullptr;
+    if (g_prof_on && g_prof && g_prof_n < PROF_MAX) {
+      rec = &g_prof[g_prof_n++];
+      rec->kind = (d->a_kc ? 0 : 2) + (d->b_kc ? 0 : 1);
+      rec->M = d->M; rec->N = d->N; rec->splits = splits; rec->K = 0;
+      for (int i = 0; i < d->nseg; ++i) rec->K += d->seg[i].K;
+      (void)hipEventRecord(rec->e0, st);
+    }
+    const bool kg = k.karows || k.kbrows;
+    if (d->a_kc && d->b_kc) hipLaunchKernelGGL((gemm_x3b_kernel<true, true, false>), grid, dim3(256), 0, st, k);
+    else if (d->a_kc) hipLaunchKernelGGL((gemm_x3b_kernel<true, false, false>), grid, dim3(256), 0, st, k);
+    else if (kg) hipLaunchKernelGGL((gemm_x3b_kernel<false, false, true>), grid, dim3(256), 0, st, k);
+    else hipLaunchKernelGGL((gemm_x3b_kernel<false, false, false>), grid, dim3(256), 0, st, k);
+    if (rec) (void)hipEventRecord(rec->e1, st);
+    SSC_CHECK_LAUNCH();
+    return SSC_OK;
+  }
   if (use_x3(d, vec)) {
     const bool wide = x3_wide(d->M, d->N);
     dim3 grid(ssc_cdiv(d->N, wide ? 128 : 64), ssc_cdiv(d->M, 64), splits);
@@ -905,6 +1255,7 @@ int ssc_gemm_slabs(const ssc_gemm_desc* d, int splits, float* slabs, hipStream_t
   k.slab_stride = (size_t)d->M * d->N;
   k.bias = nullptr;
   k.accumulate = 0;
+  k.crows = nullptr;   // slabs hold compact rows; the consumer scatters
   return launch(d, k, splits, st);
 }
 
@@ -975,10 +1326,11 @@ extern "C" int ssc_gemm(const ssc_gemm_desc* d, void* stream) {
   k.slab_stride = (size_t)d->M * d->N;
   k.bias = nullptr;
   k.accumulate = 0;
+  k.crows = nullptr;   // slabs hold compact rows; reduce_slabs_kernel scatters
   SSC_TRY(launch(d, k, splits, st));
   size_t total = (size_t)d->M * d->N;
   hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d->workspace, splits,
-                     k.slab_stride, d->M, d->N, d->C, d->ldc, d->bias, d->accumulate);
+                     k.slab_stride, d->M, d->N, d->C, d->ldc, d->bias, d->accumulate, d->m_count, d->c_rows);
   SSC_CHECK_LAUNCH();
   return SSC_OK;
 }
@@ -1031,6 +1383,8 @@ extern "C" int ssc_set_gemm_wide_min_n(int n) {
   if (n == -5) g_x3_pf = 1;
   if (n == -6) g_x3_pf = 2;
   if (n == -7) g_x3_pf = 4;
+  if (n == -8) g_x3b = 0;       // large products back on the 64x64 3xBF16 (NT) / fp32 MFMA (NN, TN) kernels
+  if (n == -9) g_x3b = 1;
   return prev;
 }
 
@@ -1044,6 +1398,19 @@ extern "C" int ssc_debug_gemm_occupancy(int* out4) {
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_kernel<true, true, 1, 1, 4, true>, 256, 0) != hipSuccess) return SSC_EHIP;
   out4[2] = n;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_kernel<true, false, 1, 2, 2, true>, 256, 0) != hipSuccess) return SSC_EHIP;
+  out4[3] = n;
+  return SSC_OK;
+}
+
+extern "C" int ssc_debug_gemm_occupancy_x3b(int* out4) {
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_x3b_kernel<true, true, false>, 256, 0) != hipSuccess) return SSC_EHIP;
+  out4[0] = n;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_x3b_kernel<true, false, false>, 256, 0) != hipSuccess) return SSC_EHIP;
+  out4[1] = n;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_x3b_kernel<false, false, false>, 256, 0) != hipSuccess) return SSC_EHIP;
+  out4[2] = n;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_x3b_kernel<false, false, true>, 256, 0) != hipSuccess) return SSC_EHIP;
   out4[3] = n;
   return SSC_OK;
 }

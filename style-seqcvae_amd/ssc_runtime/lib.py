@@ -26,7 +26,8 @@ class GemmSeg(C.Structure):
 class GemmDesc(C.Structure):
     _fields_ = [("seg", GemmSeg * SSC_MAX_SEG), ("nseg", C.c_int), ("M", C.c_int), ("N", C.c_int), ("a_kc", C.c_int),
                 ("b_kc", C.c_int), ("C", vp), ("ldc", C.c_int), ("bias", vp), ("accumulate", C.c_int),
-                ("splits", C.c_int), ("workspace", vp), ("workspace_floats", C.c_size_t)]
+                ("splits", C.c_int), ("workspace", vp), ("workspace_floats", C.c_size_t), ("m_count", vp), ("a_rows", vp),
+                ("c_rows", vp), ("k_count", vp), ("ka_rows", vp), ("kb_rows", vp)]
 
 
 class LstmFwdDesc(C.Structure):

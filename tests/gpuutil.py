@@ -27,7 +27,7 @@ def dev(t):
     return t.cuda().contiguous()
 
 
-def gemm(segs, M, N, a_kc, b_kc, Cout, bias=None, accumulate=0, splits=0, ws=None):
+def gemm(segs, M, N, a_kc, b_kc, Cout, bias=None, accumulate=0, splits=0, ws=None, compact=None, check=True):
     """segs: list of (A, lda, B, ldb, K) with torch tensors (views allowed; pointer = data_ptr())."""
     lib = L.load()
     d = L.GemmDesc()
@@ -45,7 +45,10 @@ def gemm(segs, M, N, a_kc, b_kc, Cout, bias=None, accumulate=0, splits=0, ws=Non
     if ws is not None:
         d.workspace = ws.data_ptr()
         d.workspace_floats = ws.numel()
-    lib.ssc_gemm(C.byref(d), L.stream_ptr())
+    for k, v in (compact or {}).items():   # m_count / a_rows / c_rows / k_count / ka_rows / kb_rows: int32 device tensors
+        setattr(d, k, v.data_ptr())
+    rc = lib._raw_ssc_gemm(C.byref(d), L.stream_ptr()) if not check else lib.ssc_gemm(C.byref(d), L.stream_ptr())
+    return rc
 
 
 def maxdiff(a, b):

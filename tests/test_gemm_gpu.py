@@ -4,6 +4,7 @@ import pytest
 import torch
 
 from gpuutil import dev, gemm, maxdiff
+from ssc_runtime import lib as L
 
 pytestmark = pytest.mark.gpu
 
@@ -107,3 +108,147 @@ def test_nt_split_bf16_exact_on_small_integers():
     out = torch.empty(M, N, device="cuda")
     gemm([(dev(A), K, dev(B), K, K)], M, N, 1, 1, out)
     assert torch.equal(out.cpu(), A @ B.t())
+
+
+# ---- device-side row compaction (ssc_gemm_desc.m_count / a_rows / c_rows / k_count / ka_rows / kb_rows) ----------------
+def _active(n, frac, seed):
+    g = torch.Generator().manual_seed(seed)
+    keep = torch.rand(n, generator=g) < frac
+    keep[0] = True
+    idx = torch.nonzero(keep).flatten().to(torch.int32)
+    pad = torch.zeros(n, dtype=torch.int32)
+    pad[: idx.numel()] = idx
+    return pad.cuda(), torch.tensor([idx.numel()], dtype=torch.int32).cuda(), idx.long()
+
+
+@pytest.mark.parametrize("M,N,K,splits", [(1344, 1000, 1200, 1), (200, 4800, 1216, 3), (64, 4800, 2400, 9)])
+def test_gemm_m_compaction_nt(M, N, K, splits):
+    """y[c_rows[r]] = x[a_rows[r]] @ w.T for r < *m_count; other rows of y are left untouched."""
+    lib = L.load()
+    try:
+        torch.manual_seed(5)
+        x = torch.randn(M, K, device="cuda")
+        w = torch.randn(N, K, device="cuda")
+        b = torch.randn(N, device="cuda")
+        rows, cnt, idx = _active(M, 0.6, 11)
+        y = torch.full((M, N), 7.0, device="cuda")
+        ws = torch.empty(16 * M * N, device="cuda")
+        gemm([(x, K, w, K, K)], M, N, 1, 1, y, bias=b, splits=splits, ws=ws,
+             compact={"m_count": cnt, "a_rows": rows, "c_rows": rows})
+        ref = torch.full((M, N), 7.0, dtype=torch.float64)
+        ref[idx] = x.cpu().double()[idx] @ w.cpu().double().T + b.cpu().double()
+        scale = (x.abs().cpu().double()[idx] @ w.abs().cpu().double().T).max().item()
+        assert maxdiff(y, ref) <= 4e-6 * scale
+        assert torch.equal(y.cpu()[~torch.isin(torch.arange(M), idx)], torch.full((M - idx.numel(), N), 7.0))
+        # compact output (no c_rows), accumulate on top of existing values
+        y2 = torch.ones(M, N, device="cuda")
+        gemm([(x, K, w, K, K)], M, N, 1, 1, y2, accumulate=1, splits=splits, ws=ws, compact={"m_count": cnt, "a_rows": rows})
+        ref2 = torch.ones(M, N, dtype=torch.float64)
+        ref2[: idx.numel()] += x.cpu().double()[idx] @ w.cpu().double().T
+        assert maxdiff(y2, ref2) <= 4e-6 * scale
+    finally:
+        pass
+
+
+@pytest.mark.parametrize("M,N,K,splits,gather", [(4800, 1200, 1344, 1, True), (768, 1216, 1344, 7, True), (4800, 128, 1344, 0, True),
+                                                 (1000, 1200, 1344, 0, False), (128, 1200, 96, 2, True)])
+def test_gemm_k_compaction_tn(M, N, K, splits, gather):
+    """dW = sum over the active rows k of a[k, :]^T b[k, :]  (the weight-gradient products)."""
+    torch.manual_seed(6)
+    a = torch.randn(K, M, device="cuda")
+    b = torch.randn(K, N, device="cuda")
+    rows, cnt, idx = _active(K, 0.7, 3)
+    if not gather:
+        idx = torch.arange(idx.numel())
+    out = torch.zeros(M, N, device="cuda")
+    ws = torch.empty(16 * M * N, device="cuda")
+    comp = {"k_count": cnt}
+    if gather:
+        comp.update(ka_rows=rows, kb_rows=rows)
+    gemm([(a, M, b, N, K)], M, N, 0, 0, out, splits=splits, ws=ws, compact=comp)
+    ad, bd = a.cpu().double()[idx], b.cpu().double()[idx]
+    ref = ad.T @ bd
+    scale = (ad.abs().T @ bd.abs()).max().item()
+    assert maxdiff(out, ref) <= 4e-6 * scale
+    # zero active rows: the product is exactly zero
+    zero = torch.zeros(1, dtype=torch.int32, device="cuda")
+    out.fill_(3.0)
+    gemm([(a, M, b, N, K)], M, N, 0, 0, out, splits=splits, ws=ws, compact=dict(comp, k_count=zero))
+    assert torch.count_nonzero(out).item() == 0
+
+
+def test_gemm_compaction_rejects_unaligned():
+    a = torch.randn(64, 1201, device="cuda")
+    w = torch.randn(128, 1201, device="cuda")
+    y = torch.zeros(64, 128, device="cuda")
+    cnt = torch.tensor([10], dtype=torch.int32, device="cuda")
+    assert gemm([(a, 1201, w, 1201, 1201)], 64, 128, 1, 1, y, compact={"m_count": cnt}, check=False) != 0
+
+
+def test_gemm_m_compaction_nn():
+    """dx[c_rows[r]] = dy[a_rows[r]] @ W (W stored [K][N]) for the active rows."""
+    torch.manual_seed(8)
+    M, N, K = 1344, 1200, 2000
+    dy = torch.randn(M, K, device="cuda")
+    w = torch.randn(K, N, device="cuda")
+    rows, cnt, idx = _active(M, 0.7, 4)
+    out = torch.zeros(M, N, device="cuda")
+    ws = torch.empty(8 * M * N, device="cuda")
+    for splits in (1, 4):
+        out.zero_()
+        gemm([(dy, K, w, N, K)], M, N, 1, 0, out, splits=splits, ws=ws, compact={"m_count": cnt, "a_rows": rows, "c_rows": rows})
+        ref = torch.zeros(M, N, dtype=torch.float64)
+        ref[idx] = dy.cpu().double()[idx] @ w.cpu().double()
+        scale = (dy.abs().cpu().double()[idx] @ w.abs().cpu().double()).max().item()
+        assert maxdiff(out, ref) <= 4e-6 * scale
+
+
+def test_gemm_compaction_needs_split_mode():
+    """Row compaction is implemented by the 3xBF16 kernel only: the fp32-MFMA mode refuses it instead of ignoring it."""
+    lib = L.load()
+    x = torch.randn(256, 1200, device="cuda")
+    w = torch.randn(512, 1200, device="cuda")
+    y = torch.zeros(256, 512, device="cuda")
+    cnt = torch.tensor([10], dtype=torch.int32, device="cuda")
+    lib.ssc_set_gemm_mode(0)
+    try:
+        assert gemm([(x, 1200, w, 1200, 1200)], 256, 512, 1, 1, y, compact={"m_count": cnt}, check=False) != 0
+    finally:
+        lib.ssc_set_gemm_mode(1)
+
+
+@pytest.mark.parametrize("kind,M,N,Ks,splits", [
+    ("NT", 1344, 10000, [1200], 1), ("NT", 2304, 768, [2048], 5), ("NT", 600, 520, [1000, 36], 2),
+    ("NN", 1344, 1200, [10000], 5), ("NN", 1344, 1000, [4800], 0), ("NN", 516, 644, [1204, 100], 1),
+    ("TN", 4800, 1200, [1344], 1), ("TN", 10000, 1200, [1344], 0), ("TN", 768, 2048, [2304], 5), ("TN", 520, 600, [1350, 77], 3),
+])
+def test_large_products_split_bf16(kind, M, N, Ks, splits):
+    """The 128x128 3xBF16 kernel (all three layouts; the m/n-contiguous operands go through the transposing LDS read)
+    against float64: fp32-level accuracy, error <= 2e-6 * sum|a||b|."""
+    a_kc, b_kc = {"NT": (1, 1), "NN": (1, 0), "TN": (0, 0)}[kind]
+    g = torch.Generator().manual_seed(M + N + len(Ks))
+    As = [(torch.randn((M, K) if a_kc else (K, M), generator=g) * torch.exp(torch.randn((M, K) if a_kc else (K, M), generator=g))).cuda() for K in Ks]
+    Bs = [(torch.randn((N, K) if b_kc else (K, N), generator=g) * torch.exp(torch.randn((N, K) if b_kc else (K, N), generator=g))).cuda() for K in Ks]
+    bias = torch.randn(N, generator=g).cuda()
+    out = torch.empty(M, N, device="cuda")
+    ws = torch.empty(8 * M * N, device="cuda")
+    gemm([(a, a.stride(0), b, b.stride(0), K) for a, b, K in zip(As, Bs, Ks)], M, N, a_kc, b_kc, out, bias=bias, splits=splits, ws=ws)
+    ref = bias.cpu().double()[None, :].repeat(M, 1)
+    mag = torch.zeros(M, N, dtype=torch.float64)
+    for a, b in zip(As, Bs):
+        ad, bd = a.cpu().double(), b.cpu().double()
+        ad = ad if a_kc else ad.T
+        bd = bd.T if b_kc else bd
+        ref += ad @ bd
+        mag += ad.abs() @ bd.abs()
+    err = ((out.cpu().double() - ref).abs() / mag.clamp_min(1e-30)).max().item()
+    assert err <= 2e-6, err
+    # exact on small integers (every partial product and sum is representable)
+    Ai = [torch.randint(-3, 4, a.shape, generator=g).float().cuda() for a in As]
+    Bi = [torch.randint(-3, 4, b.shape, generator=g).float().cuda() for b in Bs]
+    gemm([(a, a.stride(0), b, b.stride(0), K) for a, b, K in zip(Ai, Bi, Ks)], M, N, a_kc, b_kc, out, splits=splits, ws=ws)
+    refi = torch.zeros(M, N, dtype=torch.float64)
+    for a, b in zip(Ai, Bi):
+        ad, bd = a.cpu().double(), b.cpu().double()
+        refi += (ad if a_kc else ad.T) @ (bd.T if b_kc else bd)
+    assert torch.equal(out.cpu().double(), refi)
