@@ -8,7 +8,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libssc_hip.so")
 SOURCES = ["gemm.hip", "pointwise.hip", "attention.hip", "sequence.hip", "decode.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-I" + INCLUDE, "-I" + CSRC]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-I" + INCLUDE, "-I" + CSRC]
 
 
 def _hipcc():

@@ -58,6 +58,8 @@ struct KArgs {
             // the loop, 2 = no LDS stores, 4 = no barriers
 };
 
+__device__ long long g_clk[4];  // SSC_GEMM_DBG=64 clock probe: {shader cycles, 100 MHz ticks, k-steps} of one workgroup's main loop
+
 // ---- global -> register staging of one ROWS x 32 operand tile (ROWS/8 floats per thread) --------------
 // Loads are UNCONDITIONAL: out-of-range rows / k are clamped to a valid address and (for k) zeroed with a select
 // afterwards.  No exec-masked branch surrounds a load, so hipcc keeps counted vmcnt waits and the register
@@ -1042,6 +1044,319 @@ __global__ __launch_bounds__(256, 2) void gemm_x3b_kernel(const KArgs a) {
 }
 
 
+// =====================================================================================================
+// Wave-specialised form of gemm_x3b_kernel (same tile, planes and compaction semantics): 8 waves per workgroup.
+// Waves 4-7 PRODUCE - global loads, fp32 -> 3 x bf16 split (VALU) and plane stores into LDS stage (s+1)&1 - while
+// waves 0-3 CONSUME stage s&1 (LDS fragment reads + 48 MFMAs per wave and k-step).  Each SIMD hosts one producer and
+// one consumer wave, so the split runs in the shadow of the matrix pipe instead of in series with it (in the
+// 4-wave kernel the phases of one workgroup are strictly serial and two co-resident workgroups only partly overlap:
+// rocprof K-scaling, tools/ktime.py: 2.13 us per k-step alone = 1.27 compute + 0.73 split + 0.13 other).
+// Two stages of six planes = 120 KB of LDS: one workgroup (8 waves) per CU, ONE barrier per k-step.
+// =====================================================================================================
+constexpr int X3W_LDS_BYTES = 2 * 6 * X3B_PLANE;
+
+template <bool A_KC, bool B_KC, bool KG>
+__global__ __launch_bounds__(512) void gemm_x3w_kernel(const KArgs a) {
+  constexpr int PLN = X3B_PLANE, STAGE = 6 * PLN;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int wave = threadIdx.x >> 6;
+  const bool producer = wave >= 4;
+  const int tid = threadIdx.x & 255;  // index within the role's 256 threads
+  const int lane = tid & 63;
+  int bx = blockIdx.x, by = blockIdx.y;
+  {
+    const int gx = gridDim.x, total = gridDim.x * gridDim.y;
+    const int lin = by * gx + bx;
+    const int q = total >> 3, rem = total & 7;
+    const int xcd = lin & 7, slot = lin >> 3;
+    const int nl = xcd * q + (xcd < rem ? xcd : rem) + slot;
+    by = nl / gx;
+    bx = nl - by * gx;
+  }
+  const int n0 = bx * 128, m0 = by * 128, z = blockIdx.z;
+  const int Meff = a.mcount ? min(a.M, *a.mcount) : a.M;  // uniform per launch
+  if (m0 >= Meff) return;
+  const int Kc = a.kcount ? max(0, min(a.seg[0].K, *a.kcount)) : 0;
+  int steps_total = a.steps_total, steps_per_split = a.steps_per_split;
+  if (a.kcount) {  // K is known only on the device: partition the k-steps here
+    steps_total = (Kc + BK - 1) / BK;
+    steps_per_split = (steps_total + (int)gridDim.z - 1) / (int)gridDim.z;
+  }
+  const int s_lo = z * steps_per_split;
+  int s_hi = s_lo + steps_per_split;
+  if (s_hi > steps_total) s_hi = steps_total;
+  const int s_last = s_hi - 1;
+
+  if (producer) {
+    // ================================ producer waves ================================
+    if (a.dbg & 16) __builtin_amdgcn_s_setprio(1);  // the younger half loses VALU arbitration otherwise (MI355X_MICROARCH.md, two waves per SIMD)
+    f32x4 ra[4], rb[4];
+    unsigned oka = 0, okb = 0;
+    const float* pa[4];
+    const float* pb[4];
+    int ia[4], ib[4];  // KG: gathered k-row numbers of the NEXT step
+    Cursor cur;
+    int s_ld = s_lo;
+    auto base_ptrs = [&]() {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = tid + 256 * u;
+        if constexpr (A_KC) {
+          int r = min(m0 + (idx >> 3), Meff - 1);
+          if (a.arows) r = a.arows[r];
+          pa[u] = cur.A + (size_t)r * cur.lda + cur.k0 + 4 * (idx & 7);
+        } else {
+          int kr = cur.k0 + (idx >> 5);
+          if constexpr (KG) { if (a.karows) kr = a.karows[min(kr, cur.K - 1)]; }
+          pa[u] = cur.A + (size_t)kr * cur.lda + min(m0 + 4 * (idx & 31), Meff - 4);
+        }
+        if constexpr (B_KC) {
+          pb[u] = cur.B + (size_t)min(n0 + (idx >> 3), a.N - 1) * cur.ldb + cur.k0 + 4 * (idx & 7);
+        } else {
+          int kr = cur.k0 + (idx >> 5);
+          if constexpr (KG) { if (a.kbrows) kr = a.kbrows[min(kr, cur.K - 1)]; }
+          pb[u] = cur.B + (size_t)kr * cur.ldb + min(n0 + 4 * (idx & 31), a.N - 4);
+        }
+      }
+    };
+    auto prefetch_rows = [&]() {  // KG: row numbers of the k-step after the cursor's (clamped)
+      if constexpr (KG) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int kr = min(cur.k0 + BK + ((tid + 256 * u) >> 5), cur.K - 1);
+          ia[u] = a.karows ? a.karows[kr] : kr;
+          ib[u] = a.kbrows ? a.kbrows[kr] : kr;
+        }
+      }
+    };
+    auto step_ptrs = [&](int how) {
+      if (how == 2) {
+        base_ptrs();
+      } else if (how == 1) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int idx = tid + 256 * u;
+          if constexpr (A_KC) pa[u] += BK;
+          else if constexpr (KG) pa[u] = cur.A + (size_t)ia[u] * cur.lda + min(m0 + 4 * (idx & 31), Meff - 4);
+          else pa[u] += (size_t)BK * cur.lda;
+          if constexpr (B_KC) pb[u] += BK;
+          else if constexpr (KG) pb[u] = cur.B + (size_t)ib[u] * cur.ldb + min(n0 + 4 * (idx & 31), a.N - 4);
+          else pb[u] += (size_t)BK * cur.ldb;
+        }
+        prefetch_rows();
+      }
+    };
+    auto issue_loads = [&]() {
+      const bool full = cur.k0 + BK <= cur.K;
+      if (full) {
+        oka = okb = 0xfu;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(ra[u]) : "v"(pa[u]) : "memory");
+#pragma unroll
+        for (int u = 0; u < 4; ++u) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(rb[u]) : "v"(pb[u]) : "memory");
+      } else {  // last k-step of a segment: clamp into range, remember which chunks are past the end
+        oka = okb = 0;
+        const float* qa[4];
+        const float* qb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int idx = tid + 256 * u;
+          if constexpr (A_KC) {
+            const int k = cur.k0 + 4 * (idx & 7);
+            qa[u] = pa[u] + (min(k, cur.K - 4) - k);
+            oka |= (k < cur.K ? 1u : 0u) << u;
+          } else {
+            const int gk = cur.k0 + (idx >> 5);
+            qa[u] = KG ? pa[u] : pa[u] + (ptrdiff_t)(min(gk, cur.K - 1) - gk) * cur.lda;
+            oka |= (gk < cur.K ? 1u : 0u) << u;
+          }
+          if constexpr (B_KC) {
+            const int k = cur.k0 + 4 * (idx & 7);
+            qb[u] = pb[u] + (min(k, cur.K - 4) - k);
+            okb |= (k < cur.K ? 1u : 0u) << u;
+          } else {
+            const int gk = cur.k0 + (idx >> 5);
+            qb[u] = KG ? pb[u] : pb[u] + (ptrdiff_t)(min(gk, cur.K - 1) - gk) * cur.ldb;
+            okb |= (gk < cur.K ? 1u : 0u) << u;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(ra[u]) : "v"(qa[u]) : "memory");
+#pragma unroll
+        for (int u = 0; u < 4; ++u) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(rb[u]) : "v"(qb[u]) : "memory");
+      }
+    };
+    auto wait_loads = [&]() {  // "+v" pins every use of the staged registers behind the wait
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3])::"memory");
+    };
+    auto advance = [&]() {
+      const int how = cur.advance(a, s_ld >= s_last);
+      s_ld = min(s_ld + 1, s_last);
+      step_ptrs(how);
+    };
+    auto put_chunk = [&](unsigned char* p, f32x4 v, bool ok) {
+      if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      u32x2 hi, mid, lo;
+      split4(v, hi, mid, lo);
+      *reinterpret_cast<u32x2*>(p) = hi;
+      *reinterpret_cast<u32x2*>(p + PLN) = mid;
+      *reinterpret_cast<u32x2*>(p + 2 * PLN) = lo;
+    };
+    auto put_planes = [&](unsigned char* st) {
+      if (oka == 0xfu && okb == 0xfu) {  // whole k-step in range (uniform): no per-chunk select
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int idx = tid + 256 * u;
+          put_chunk(st + (A_KC ? (idx >> 3) * PL_ROW_B + (idx & 7) * 8 : (idx >> 5) * X3B_MC_ROW_B + (idx & 31) * 8), ra[u], true);
+          put_chunk(st + 3 * PLN + (B_KC ? (idx >> 3) * PL_ROW_B + (idx & 7) * 8 : (idx >> 5) * X3B_MC_ROW_B + (idx & 31) * 8), rb[u], true);
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int idx = tid + 256 * u;
+          put_chunk(st + (A_KC ? (idx >> 3) * PL_ROW_B + (idx & 7) * 8 : (idx >> 5) * X3B_MC_ROW_B + (idx & 31) * 8), ra[u], (oka >> u) & 1u);
+          put_chunk(st + 3 * PLN + (B_KC ? (idx >> 3) * PL_ROW_B + (idx & 7) * 8 : (idx >> 5) * X3B_MC_ROW_B + (idx & 31) * 8), rb[u], (okb >> u) & 1u);
+        }
+      }
+    };
+
+    if (s_lo < s_hi) {
+      cur.init(a, s_lo);
+      if (a.kcount) { cur.K = Kc; cur.left = steps_total - 1 - cur.k0 / BK; }
+      base_ptrs();
+      prefetch_rows();
+      issue_loads();
+      wait_loads();
+      put_planes(lds);
+      advance();
+      issue_loads();
+    }
+    __syncthreads();
+    for (int s = s_lo; s < s_hi; ++s) {
+      wait_loads();
+      if (s + 1 < s_hi && !(a.dbg & 2)) put_planes(lds + ((s + 1 - s_lo) & 1) * STAGE);
+      advance();
+      if (!(a.dbg & 1)) issue_loads();
+      __syncthreads();
+    }
+    wait_loads();  // drain the clamped tail loads with the staged registers pinned (see gemm_kernel)
+    return;
+  }
+
+  // ================================ consumer waves ================================
+  const int wm = wave >> 1, wn = wave & 1;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int g16 = lane >> 4, i16 = lane & 15;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mi][ni][i] = 0.f;
+
+  // fragment = 8 consecutive k (16*kk + 8*half ...) of tile row/column rc0 + (lane & 31) of one plane
+  auto frag = [&](const unsigned char* plane, bool kc, int rc0, int kk) -> bf16x8 {
+    if (kc) {
+      return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(plane + (rc0 + l31) * PL_ROW_B + kk * 32 + half * 16));
+    } else {
+      // transposed read: lane 4q+p of a 16-lane group addresses k-row q, columns 4p..4p+3 of the group's 4 x 16 block and
+      // receives column (lane & 15), k-rows 0..3; the second read takes the next 4 k-rows
+      const unsigned char* p = plane + (16 * kk + 8 * (g16 >> 1) + (i16 >> 2)) * X3B_MC_ROW_B + (rc0 + 16 * (g16 & 1) + 4 * (i16 & 3)) * 2;
+      typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+      const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+      const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * X3B_MC_ROW_B));
+      typedef short s16x8 __attribute__((ext_vector_type(8)));
+      const s16x8 v = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+      return __builtin_bit_cast(bf16x8, v);
+    }
+  };
+#define SSC_X3W_MFMA(FA, FB, PA, PB)                                                                                 \
+  _Pragma("unroll") for (int mi = 0; mi < 2; ++mi) _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = \
+      __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[mi][PA], FB[ni][PB], acc[mi][ni], 0, 0, 0);
+  auto compute = [&](const unsigned char* st) {
+    bf16x8 fa[2][2][3], fb[2][2][3];  // [kk][tile][plane]
+    auto rda = [&](int kk, int pl) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) fa[kk][t][pl] = frag(st + pl * PLN, A_KC, wm * 64 + t * 32, kk);
+    };
+    auto rdb = [&](int kk, int pl) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) fb[kk][t][pl] = frag(st + (3 + pl) * PLN, B_KC, wn * 64 + t * 32, kk);
+    };
+    // six partial products per accumulator, smallest first (lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi); the reads are
+    // ordered by first use and the first fragments of the second k-half are requested under the first half's MFMAs
+    rda(0, 2); rdb(0, 0); rda(0, 0); rdb(0, 2); rda(0, 1); rdb(0, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    SSC_X3W_MFMA(fa[0], fb[0], 2, 0)
+    SSC_X3W_MFMA(fa[0], fb[0], 0, 2)
+    SSC_X3W_MFMA(fa[0], fb[0], 1, 1)
+    __builtin_amdgcn_sched_barrier(0);
+    rda(1, 2); rdb(1, 0); rda(1, 0); rdb(1, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    SSC_X3W_MFMA(fa[0], fb[0], 1, 0)
+    SSC_X3W_MFMA(fa[0], fb[0], 0, 1)
+    SSC_X3W_MFMA(fa[0], fb[0], 0, 0)
+    __builtin_amdgcn_sched_barrier(0);
+    rda(1, 1); rdb(1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    SSC_X3W_MFMA(fa[1], fb[1], 2, 0)
+    SSC_X3W_MFMA(fa[1], fb[1], 0, 2)
+    SSC_X3W_MFMA(fa[1], fb[1], 1, 1)
+    SSC_X3W_MFMA(fa[1], fb[1], 1, 0)
+    SSC_X3W_MFMA(fa[1], fb[1], 0, 1)
+    SSC_X3W_MFMA(fa[1], fb[1], 0, 0)
+  };
+#undef SSC_X3W_MFMA_UNUSED
+
+  __syncthreads();
+  long long t0 = 0, r0 = 0;
+  const bool probe = (a.dbg & 64) && blockIdx.x == 1 && blockIdx.y == 1 && threadIdx.x == 0;
+  if (probe) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+  for (int s = s_lo; s < s_hi; ++s) {
+    if (!(a.dbg & 8)) compute(lds + ((s - s_lo) & 1) * STAGE);
+    __syncthreads();
+  }
+  if (probe) {
+    g_clk[0] = __builtin_amdgcn_s_memtime() - t0;
+    g_clk[1] = __builtin_amdgcn_s_memrealtime() - r0;
+    g_clk[2] = s_hi - s_lo;
+  }
+#undef SSC_X3W_MFMA
+
+  float* out = a.out + (size_t)z * a.slab_stride;
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int col = n0 + wn * 64 + ni * 32 + l31;
+    if (col >= a.N) continue;
+    const float bv = (a.bias != nullptr) ? a.bias[col] : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const int rbase = m0 + wm * 64 + mi * 32 + 4 * half;
+      int rr[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        rr[r] = min(rbase + (r & 3) + 8 * (r >> 2), Meff - 1);
+        if (a.crows) rr[r] = a.crows[rr[r]];
+      }
+      float old[16];
+      if (a.accumulate) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) old[r] = out[(size_t)rr[r] * a.ldo + col];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) old[r] = 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (rbase + (r & 3) + 8 * (r >> 2) < Meff) out[(size_t)rr[r] * a.ldo + col] = acc[mi][ni][r] + bv + old[r];
+      }
+    }
+  }
+}
+
+
 __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int nslab, size_t slab_stride, int M, int N,
                                     float* __restrict__ C, int ldc, const float* __restrict__ bias, int accumulate,
                                     const int* __restrict__ mcount, const int* __restrict__ crows) {
@@ -1123,7 +1438,7 @@ inline int gemm_mode() {
   return g_gemm_mode;
 }
 inline bool use_x3(const ssc_gemm_desc* d, bool vec) { return gemm_mode() == 1 && d->a_kc && d->b_kc && vec; }
-int g_x3b = 1;     // large products (M, N >= 512) of any layout on the 128x128 3xBF16 kernel (tuning hook -8 / -9: off / on)
+int g_x3b = getenv("SSC_X3B") ? atoi(getenv("SSC_X3B")) : 1;  // large products (M, N >= 512): 0 = 64x64 kernels, 1 = 128x128 3xBF16 kernel, 2 = its wave-specialised form (hook -8 / -9 / -10)
 int g_x3_nbuf = 1;  // single LDS stage: 31 KB per workgroup -> four resident workgroups per CU (rocprof r01: 37 vs 43 us)
 int g_x3_wide = 0;
 int g_x3_pf = 2;  // tuning hook: 1 = 64x128 block tile for skinny (M <= 64, N >= 1024) 3xBF16 products
@@ -1162,6 +1477,21 @@ int launch(const ssc_gemm_desc* d, KArgs& k, int splits, hipStream_t st) {
       (void)hipEventRecord(rec->e0, st);
     }
     const bool kg = k.karows || k.kbrows;
+    if (g_x3b == 2) {  // wave-specialised form: 8 waves, 120 KB of dynamic LDS
+      gemm_fn fn = (d->a_kc && d->b_kc) ? gemm_x3w_kernel<true, true, false>
+                   : d->a_kc            ? gemm_x3w_kernel<true, false, false>
+                   : kg                 ? gemm_x3w_kernel<false, false, true>
+                                        : gemm_x3w_kernel<false, false, false>;
+      static bool attr_set = false;
+      if (!attr_set) {
+        gemm_fn all[4] = {gemm_x3w_kernel<true, true, false>, gemm_x3w_kernel<true, false, false>,
+                          gemm_x3w_kernel<false, false, true>, gemm_x3w_kernel<false, false, false>};
+        for (gemm_fn f : all)
+          if (hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, X3W_LDS_BYTES) != hipSuccess) return SSC_EHIP;
+        attr_set = true;
+      }
+      hipLaunchKernelGGL(fn, grid, dim3(512), X3W_LDS_BYTES, st, k);
+    } else
     if (d->a_kc && d->b_kc) hipLaunchKernelGGL((gemm_x3b_kernel<true, true, false>), grid, dim3(256), 0, st, k);
     else if (d->a_kc) hipLaunchKernelGGL((gemm_x3b_kernel<true, false, false>), grid, dim3(256), 0, st, k);
     else if (kg) hipLaunchKernelGGL((gemm_x3b_kernel<false, false, true>), grid, dim3(256), 0, st, k);
@@ -1385,7 +1715,14 @@ extern "C" int ssc_set_gemm_wide_min_n(int n) {
   if (n == -7) g_x3_pf = 4;
   if (n == -8) g_x3b = 0;       // large products back on the 64x64 3xBF16 (NT) / fp32 MFMA (NN, TN) kernels
   if (n == -9) g_x3b = 1;
+  if (n == -10) g_x3b = 2;      // ... on the wave-specialised (producer / consumer) form of that kernel
   return prev;
+}
+
+// diagnostic: in-kernel clock probe of gemm_x3w_kernel (SSC_GEMM_DBG=64): {shader cycles, 100 MHz ticks, k-steps}
+extern "C" int ssc_debug_gemm_clock(long long* out3) {
+  if (hipMemcpyFromSymbol(out3, HIP_SYMBOL(g_clk), 3 * sizeof(long long)) != hipSuccess) return SSC_EHIP;
+  return SSC_OK;
 }
 
 // diagnostic: resident workgroups per CU the runtime reports for the GEMM kernels (tools/, not used by the product path)

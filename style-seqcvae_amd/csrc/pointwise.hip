@@ -273,6 +273,10 @@ __global__ void ce_fwd_kernel(const float* __restrict__ logits, int ldl, const i
                               const float* __restrict__ w, int V, float* __restrict__ lse, float* __restrict__ nllw) {
   __shared__ float sh[16];
   int row = blockIdx.x;
+  if (w[row] == 0.f) {  // padded target: no loss, and its logits row may not have been computed at all
+    if (threadIdx.x == 0) { lse[row] = 0.f; nllw[row] = 0.f; }
+    return;
+  }
   const float* p = logits + (size_t)row * ldl;
   float mx = -INFINITY;
   for (int v = threadIdx.x; v < V; v += blockDim.x) mx = fmaxf(mx, p[v]);

@@ -25,6 +25,7 @@ struct Layout {
   int V, E, H, A, F, Z, S, tied;
   int Ep, Hp, Ap, Fp, Zp, Vp, H4, XW;  // padded leading dims ; XW = F + 2H
   size_t total = 0;                    // floats
+  size_t act;  // int32: [0] = number of active (t, b) rows, [4 ...] = their row numbers t*B+b in ascending order
   size_t tok, w, nvalid, sent_all, wcol_e, wcol_d, mask, avg, pv, emb, ga_static, ga_avg;
   size_t h1, c1, he, ce, hd, cd, gates_a, gates_e, gates_d, q, attn_logits, alpha, att, mu, lv, z, mulv;
   size_t slabs, slab_floats, logits, lse, proj;
@@ -49,6 +50,7 @@ Layout make_layout(const ssc_model_cfg* c, int B, int R, int L) {
   l.tok = l.take(2 * (size_t)(L + 2) * B);
   l.w = l.take(TB);
   l.nvalid = l.take(B);
+  l.act = l.take(TB + 4);
   l.sent_all = l.take(TB);
   l.wcol_e = l.take(l.H4); l.wcol_d = l.take(l.H4);
   l.mask = l.take((size_t)B * R);
@@ -116,6 +118,8 @@ struct Ctx {
   hipStream_t st;
   float* slabs;
   size_t slab_floats;
+  const int* act_count = nullptr;  // device: number of (t, b) rows with a non-pad target ...
+  const int* act_rows = nullptr;   // ... and their row numbers (build_active_rows_kernel); nullptr = no compaction
 };
 
 void fill_desc(ssc_gemm_desc& d, bool a_kc, bool b_kc, std::initializer_list<Seg> segs, int M, int N) {
@@ -140,6 +144,64 @@ int gemm(const Ctx& c, bool a_kc, bool b_kc, std::initializer_list<Seg> segs, in
   d.splits = 0;
   d.workspace = c.slabs; d.workspace_floats = c.slab_floats;
   return ssc_gemm(&d, c.st);
+}
+
+// Products over the (t, b) rows of the caption batch skip the padded rows on the device (ssc_gemm_desc row compaction):
+// those rows carry zero loss weight, so they contribute exact zeros to every weight gradient and their outputs are
+// never used.  When the operands do not qualify (alignment, fp32-MFMA mode) the product runs over all rows as before.
+//   gemm_rows: C[r] = A[r] . B for the active rows r only (other rows of C are left as they are)
+//   gemm_dw:   C = A^T B summed over the active rows only
+int gemm_rows(const Ctx& c, bool b_kc, std::initializer_list<Seg> segs, int M, int N, float* C, int ldc, const float* bias = nullptr) {
+  ssc_gemm_desc d;
+  fill_desc(d, true, b_kc, segs, M, N);
+  d.C = C; d.ldc = ldc; d.bias = bias; d.accumulate = 0;
+  d.splits = 0;
+  d.workspace = c.slabs; d.workspace_floats = c.slab_floats;
+  if (c.act_rows) {
+    d.m_count = c.act_count; d.a_rows = c.act_rows; d.c_rows = c.act_rows;
+    const int rc = ssc_gemm(&d, c.st);
+    if (rc != SSC_EALIGN && rc != SSC_EINVAL) return rc;
+    d.m_count = d.a_rows = d.c_rows = nullptr;
+  }
+  return ssc_gemm(&d, c.st);
+}
+int gemm_dw(const Ctx& c, const float* A, int lda, const float* Bm, int ldb, int K, int M, int N, float* C, int ldc) {
+  ssc_gemm_desc d;
+  fill_desc(d, false, false, {{A, lda, Bm, ldb, K}}, M, N);
+  d.C = C; d.ldc = ldc;
+  d.splits = 0;
+  d.workspace = c.slabs; d.workspace_floats = c.slab_floats;
+  if (c.act_rows) {
+    d.k_count = c.act_count; d.ka_rows = c.act_rows; d.kb_rows = c.act_rows;
+    const int rc = ssc_gemm(&d, c.st);
+    if (rc != SSC_EALIGN && rc != SSC_EINVAL) return rc;
+    d.k_count = d.ka_rows = d.kb_rows = nullptr;
+  }
+  return ssc_gemm(&d, c.st);
+}
+
+// ascending list of the rows t*B+b whose target token is not padding (w = 1); one workgroup, ordered block scan
+__global__ __launch_bounds__(1024) void build_active_rows_kernel(const float* __restrict__ w, int n, int* __restrict__ act) {
+  __shared__ int part[1024];
+  const int tid = threadIdx.x;
+  const int per = (n + 1023) / 1024;
+  const int lo = min(tid * per, n), hi = min(lo + per, n);
+  int cnt = 0;
+  for (int i = lo; i < hi; ++i) cnt += w[i] != 0.f;
+  part[tid] = cnt;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {  // inclusive scan
+    const int v = tid >= off ? part[tid - off] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  int pos = part[tid] - cnt;
+  for (int i = lo; i < hi; ++i)
+    if (w[i] != 0.f) act[4 + pos++] = i;
+  if (tid == 1023) act[0] = part[1023];
+  // entries past the count are never read by a product; keep them in range anyway
+  for (int i = part[1023] + tid; i < n; i += 1024) act[4 + i] = 0;
 }
 
 // GEMM that leaves its split-K slabs (M x N, ld N) in `region` for a fused epilogue / consumer
@@ -238,6 +300,10 @@ extern "C" int ssc_train_fwd(const ssc_model_cfg* cfg, const ssc_params* p, cons
 
   // ---- per-sequence precompute --------------------------------------------------------------
   SSC_TRY(ssc_prep_tokens(bt->caps, B, l.L, cfg->pad, cfg->boundary, tok, W + l.w, W + l.nvalid, st));
+  int* act = (int*)(W + l.act);
+  hipLaunchKernelGGL(build_active_rows_kernel, dim3(1), dim3(1024), 0, st, W + l.w, TB, act);
+  SSC_CHECK_LAUNCH();
+  c.act_count = act; c.act_rows = act + 4;
   SSC_TRY(ssc_feat_prep(bt->feats, B, R, F, W + l.mask, W + l.avg, st));
   SSC_TRY(gemm(c, true, true, {{bt->feats, F, p->wv, p->ld_wv, F}}, B * R, A, W + l.pv, A));
   SSC_TRY(ssc_embed_gather(p->emb, p->ld_emb, tok, TB, E, W + l.emb, l.Ep, st));
@@ -350,12 +416,14 @@ extern "C" int ssc_train_fwd(const ssc_model_cfg* cfg, const ssc_params* p, cons
 
   // ---- vocabulary projection + CE over all steps (updown_captioner.py:444-445, 457-466) -----------
   const float* hd_all = W + l.hd + sH;  // rows t*B+b = h_dec after step t
+  // only the rows with a real target are projected (ssc_ce_fwd skips the others)
   if (cfg->tied) {
-    SSC_TRY(gemm(c, true, true, {{hd_all, l.Hp, p->proj_w, p->ld_proj_w, H}}, TB, E, W + l.proj, l.Ep));
+    SSC_TRY(ssc_fill(W + l.proj, (size_t)TB * l.Ep, 0.f, st));  // padded rows stay finite through the tanh
+    SSC_TRY(gemm_rows(c, true, {{hd_all, l.Hp, p->proj_w, p->ld_proj_w, H}}, TB, E, W + l.proj, l.Ep));
     SSC_TRY(ssc_bias_tanh(W + l.proj, l.Ep, TB, E, p->proj_b, st));
-    SSC_TRY(gemm(c, true, true, {{W + l.proj, l.Ep, p->emb, p->ld_emb, E}}, TB, V, W + l.logits, l.Vp));
+    SSC_TRY(gemm_rows(c, true, {{W + l.proj, l.Ep, p->emb, p->ld_emb, E}}, TB, V, W + l.logits, l.Vp));
   } else {
-    SSC_TRY(gemm(c, true, true, {{hd_all, l.Hp, p->out_w, p->ld_out_w, H}}, TB, V, W + l.logits, l.Vp, p->out_b));
+    SSC_TRY(gemm_rows(c, true, {{hd_all, l.Hp, p->out_w, p->ld_out_w, H}}, TB, V, W + l.logits, l.Vp, p->out_b));
   }
   SSC_TRY(ssc_ce_fwd(W + l.logits, l.Vp, tok + B, W + l.w, W + l.nvalid, T, B, V, W + l.lse, loss, st));
   return SSC_OK;
@@ -387,21 +455,24 @@ static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const s
   int64_t* tok = (int64_t*)(W + l.tok);
   const size_t sH = (size_t)B * l.Hp;
   const float* hd_all = W + l.hd + sH;
+  c.act_count = (const int*)(W + l.act); c.act_rows = c.act_count + 4;  // built by ssc_train_fwd of this minibatch
 
   if (phases & 1u) {
   // ---- vocabulary head ------------------------------------------------------------------------------
   SSC_TRY(ssc_ce_bwd(W + l.logits, l.Vp, tok + B, W + l.w, W + l.nvalid, W + l.lse, gl, T, B, V, st));
   const float* dlog = W + l.logits;
+  SSC_TRY(ssc_fill(W + l.dhdv, (size_t)TB * l.Hp, 0.f, st));  // the padded rows receive no gradient
   if (cfg->tied) {
     float* dP = W + l.dproj;
-    SSC_TRY(gemm(c, true, false, {{dlog, l.Vp, p->emb, p->ld_emb, V}}, TB, E, dP, l.Ep));
+    SSC_TRY(ssc_fill(dP, (size_t)TB * l.Ep, 0.f, st));
+    SSC_TRY(gemm_rows(c, false, {{dlog, l.Vp, p->emb, p->ld_emb, V}}, TB, E, dP, l.Ep));
     SSC_TRY(ssc_tanh_bwd(dP, l.Ep, W + l.proj, l.Ep, TB, E, st));
-    SSC_TRY(gemm(c, true, false, {{dP, l.Ep, p->proj_w, p->ld_proj_w, E}}, TB, H, W + l.dhdv, l.Hp));
-    if (g->proj_w) SSC_TRY(gemm(c, false, false, {{dP, l.Ep, hd_all, l.Hp, TB}}, E, H, g->proj_w, g->ld_proj_w));
+    SSC_TRY(gemm_rows(c, false, {{dP, l.Ep, p->proj_w, p->ld_proj_w, E}}, TB, H, W + l.dhdv, l.Hp));
+    if (g->proj_w) SSC_TRY(gemm_dw(c, dP, l.Ep, hd_all, l.Hp, TB, E, H, g->proj_w, g->ld_proj_w));
     if (g->proj_b) SSC_TRY(ssc_colsum2(dP, l.Ep, TB, E, nullptr, g->proj_b, 1, nullptr, 0, c.slabs, st));
   } else {
-    SSC_TRY(gemm(c, true, false, {{dlog, l.Vp, p->out_w, p->ld_out_w, V}}, TB, H, W + l.dhdv, l.Hp));
-    if (g->out_w) SSC_TRY(gemm(c, false, false, {{dlog, l.Vp, hd_all, l.Hp, TB}}, V, H, g->out_w, g->ld_out_w));
+    SSC_TRY(gemm_rows(c, false, {{dlog, l.Vp, p->out_w, p->ld_out_w, V}}, TB, H, W + l.dhdv, l.Hp));
+    if (g->out_w) SSC_TRY(gemm_dw(c, dlog, l.Vp, hd_all, l.Hp, TB, V, H, g->out_w, g->ld_out_w));
     if (g->out_b) SSC_TRY(ssc_colsum2(dlog, l.Vp, TB, V, nullptr, g->out_b, 1, nullptr, 0, c.slabs, st));
   }
 
@@ -519,10 +590,10 @@ static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const s
   // attention LSTM
   if (g->att_w_ih) {
     float* gw = g->att_w_ih; int ld = g->ld_att_w_ih;
-    SSC_TRY(gemm(c, false, false, {{dga, H4, W + l.emb, l.Ep, TB}}, H4, E, gw, ld));
+    SSC_TRY(gemm_dw(c, dga, H4, W + l.emb, l.Ep, TB, H4, E, gw, ld));
     SSC_TRY(gemm(c, false, false, {{W + l.dga_sum, H4, W + l.avg, F, B}}, H4, F, gw + E, ld));
-    SSC_TRY(gemm(c, false, false, {{dga, H4, h1_prev, l.Hp, TB}}, H4, H, gw + E + F, ld));
-    SSC_TRY(gemm(c, false, false, {{dga, H4, hd_prev, l.Hp, TB}}, H4, H, gw + E + F + H, ld));
+    SSC_TRY(gemm_dw(c, dga, H4, h1_prev, l.Hp, TB, H4, H, gw + E + F, ld));
+    SSC_TRY(gemm_dw(c, dga, H4, hd_prev, l.Hp, TB, H4, H, gw + E + F + H, ld));
   }
   if (g->att_w_hh) {
     // dW_hh^att = dGa^T H1_prev is the same product as the h1' block of dW_ih^att (both multiply h1'): copy, do not recompute
@@ -532,7 +603,7 @@ static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const s
                            st) != hipSuccess)
         return SSC_EHIP;
     } else {
-      SSC_TRY(gemm(c, false, false, {{dga, H4, h1_prev, l.Hp, TB}}, H4, H, g->att_w_hh, g->ld_att_w_hh));
+      SSC_TRY(gemm_dw(c, dga, H4, h1_prev, l.Hp, TB, H4, H, g->att_w_hh, g->ld_att_w_hh));
     }
   }
   if (g->att_b_ih && g->att_b_hh) {
@@ -542,14 +613,15 @@ static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const s
     if (g->att_b_hh) SSC_TRY(ssc_colsum2(dga, H4, TB, H4, nullptr, g->att_b_hh, 1, nullptr, 0, c.slabs, st));
   }
   if (g->emb && !cfg->tied) {
-    SSC_TRY(gemm(c, true, false, {{dga, H4, p->att_w_ih, p->ld_att_w_ih, H4}}, TB, E, W + l.demb, l.Ep));
+    SSC_TRY(ssc_fill(W + l.demb, (size_t)TB * l.Ep, 0.f, st));  // padded rows add nothing to the embedding gradient
+    SSC_TRY(gemm_rows(c, false, {{dga, H4, p->att_w_ih, p->ld_att_w_ih, H4}}, TB, E, W + l.demb, l.Ep));
     // zero the table gradient, then scatter-add rows by token id (padding_idx row gets none)
     if (hipMemset2DAsync(g->emb, (size_t)g->ld_emb * sizeof(float), 0, (size_t)E * sizeof(float), V, st) != hipSuccess)
       return SSC_EHIP;
     SSC_TRY(ssc_embed_scatter_add(g->emb, g->ld_emb, tok, TB, E, W + l.demb, l.Ep, cfg->pad, st));
   }
   // attention projections
-  if (g->wq) SSC_TRY(gemm(c, false, false, {{W + l.dq, l.Ap, h1_new, l.Hp, TB}}, A, H, g->wq, g->ld_wq));
+  if (g->wq) SSC_TRY(gemm_dw(c, W + l.dq, l.Ap, h1_new, l.Hp, TB, A, H, g->wq, g->ld_wq));
   if (g->wv) SSC_TRY(gemm(c, false, false, {{W + l.dpv, A, bt->feats, F, B * R}}, A, F, g->wv, g->ld_wv));
   if (g->wa) SSC_TRY(ssc_colsum(W + l.dwa, A, B, A, nullptr, g->wa, 1, 0, st));
   }  // phase 2
@@ -557,12 +629,12 @@ static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const s
   // encoder LSTM
   if (g->enc_w_ih) {
     float* gw = g->enc_w_ih; int ld = g->ld_enc_w_ih;
-    SSC_TRY(gemm(c, false, false, {{dge, H4, att, l.Fp, TB}}, H4, F, gw, ld));
-    SSC_TRY(gemm(c, false, false, {{dge, H4, h1_new, l.Hp, TB}}, H4, H, gw + F, ld));
-    SSC_TRY(gemm(c, false, false, {{dge, H4, hd_prev, l.Hp, TB}}, H4, H, gw + F + H, ld));
+    SSC_TRY(gemm_dw(c, dge, H4, att, l.Fp, TB, H4, F, gw, ld));
+    SSC_TRY(gemm_dw(c, dge, H4, h1_new, l.Hp, TB, H4, H, gw + F, ld));
+    SSC_TRY(gemm_dw(c, dge, H4, hd_prev, l.Hp, TB, H4, H, gw + F + H, ld));
     if (S) SSC_TRY(ssc_colsum2(dge, H4, TB, H4, W + l.sent_all, gw + F + 2 * H, ld, nullptr, 0, c.slabs, st));
   }
-  if (g->enc_w_hh) SSC_TRY(gemm(c, false, false, {{dge, H4, he_prev, l.Hp, TB}}, H4, H, g->enc_w_hh, g->ld_enc_w_hh));
+  if (g->enc_w_hh) SSC_TRY(gemm_dw(c, dge, H4, he_prev, l.Hp, TB, H4, H, g->enc_w_hh, g->ld_enc_w_hh));
   if (g->enc_b_ih && g->enc_b_hh) {
     SSC_TRY(ssc_colsum2(dge, H4, TB, H4, nullptr, g->enc_b_ih, 1, g->enc_b_hh, 0, c.slabs, st));
   } else {
@@ -571,8 +643,8 @@ static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const s
   }
   // latent heads
   const float* dmulv = W + l.dmulv;
-  if (g->fc_mean_w) SSC_TRY(gemm(c, false, false, {{dmulv, 2 * Z, he_new, l.Hp, TB}}, Z, H, g->fc_mean_w, g->ld_fc_mean_w));
-  if (g->fc_lv_w) SSC_TRY(gemm(c, false, false, {{dmulv + Z, 2 * Z, he_new, l.Hp, TB}}, Z, H, g->fc_lv_w, g->ld_fc_lv_w));
+  if (g->fc_mean_w) SSC_TRY(gemm_dw(c, dmulv, 2 * Z, he_new, l.Hp, TB, Z, H, g->fc_mean_w, g->ld_fc_mean_w));
+  if (g->fc_lv_w) SSC_TRY(gemm_dw(c, dmulv + Z, 2 * Z, he_new, l.Hp, TB, Z, H, g->fc_lv_w, g->ld_fc_lv_w));
   if (g->fc_mean_b) SSC_TRY(ssc_colsum2(dmulv, 2 * Z, TB, Z, nullptr, g->fc_mean_b, 1, nullptr, 0, c.slabs, st));
   if (g->fc_lv_b) SSC_TRY(ssc_colsum2(dmulv + Z, 2 * Z, TB, Z, nullptr, g->fc_lv_b, 1, nullptr, 0, c.slabs, st));
   }  // phase 4
@@ -580,11 +652,11 @@ static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const s
   // decoder LSTM (skipped while frozen: train.py:156-161)
   if (g->dec_w_ih) {
     float* gw = g->dec_w_ih; int ld = g->ld_dec_w_ih;
-    SSC_TRY(gemm(c, false, false, {{dgd, H4, att, l.Fp, TB}}, H4, F, gw, ld));
-    SSC_TRY(gemm(c, false, false, {{dgd, H4, h1_new, l.Hp, TB}}, H4, H, gw + F, ld));
-    SSC_TRY(gemm(c, false, false, {{dgd, H4, hd_prev, l.Hp, TB}}, H4, H, gw + F + H, ld));
+    SSC_TRY(gemm_dw(c, dgd, H4, att, l.Fp, TB, H4, F, gw, ld));
+    SSC_TRY(gemm_dw(c, dgd, H4, h1_new, l.Hp, TB, H4, H, gw + F, ld));
+    SSC_TRY(gemm_dw(c, dgd, H4, hd_prev, l.Hp, TB, H4, H, gw + F + H, ld));
     if (S) SSC_TRY(ssc_colsum2(dgd, H4, TB, H4, W + l.sent_all, gw + F + 2 * H, ld, nullptr, 0, c.slabs, st));
-    SSC_TRY(gemm(c, false, false, {{dgd, H4, W + l.z, l.Zp, TB}}, H4, Z, gw + zcol, ld));
+    SSC_TRY(gemm_dw(c, dgd, H4, W + l.z, l.Zp, TB, H4, Z, gw + zcol, ld));
   }
   if (g->dec_w_hh) {
     // dW_hh^dec = dGd^T HD_prev is the same product as the hd' block of dW_ih^dec
@@ -594,7 +666,7 @@ static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const s
                            st) != hipSuccess)
         return SSC_EHIP;
     } else {
-      SSC_TRY(gemm(c, false, false, {{dgd, H4, hd_prev, l.Hp, TB}}, H4, H, g->dec_w_hh, g->ld_dec_w_hh));
+      SSC_TRY(gemm_dw(c, dgd, H4, hd_prev, l.Hp, TB, H4, H, g->dec_w_hh, g->ld_dec_w_hh));
     }
   }
   if (g->dec_b_ih && g->dec_b_hh) {

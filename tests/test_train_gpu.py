@@ -34,7 +34,10 @@ def test_train_matches_reference_golden(name):
         assert maxdiff(eng.workspace_view(6)[t], st["alpha"]) < TOL
         assert maxdiff(eng.workspace_view(7)[t], st["mean"]) < TOL
         assert maxdiff(eng.workspace_view(8)[t], st["log_var"]) < TOL
-        assert maxdiff(eng.workspace_view(9)[t], st["logits"]) < TOL
+        # logits exist only for rows with a real target (the padded (t, b) rows are skipped on the device; the reference
+        # computes and then masks them): caption b is active at step t iff t <= its length
+        act = (ins["caps"] != cfg.pad_index).sum(1) >= t
+        assert maxdiff(eng.workspace_view(9)[t][act.cuda()], st["logits"][act]) < TOL
     B = loss.numel()
     gl = torch.full((B,), 1.0 / B, device="cuda")
     gk = torch.full((B,), 1.0 / (B * 750.0), device="cuda")

@@ -27,6 +27,8 @@ def main():
         _L.load().ssc_set_gemm_wide_min_n(-4)
     if _os.environ.get("SSC_X3_NBUF") == "1":
         _L.load().ssc_set_gemm_wide_min_n(-3)
+    if _os.environ.get("SSC_X3B"):
+        _L.load().ssc_set_gemm_wide_min_n({"0": -8, "1": -9, "2": -10}[_os.environ["SSC_X3B"]])
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     shapes = sys.argv[2:] or DEFAULT
     for sh in shapes:
