@@ -21,6 +21,16 @@ def short(name):
         a, b, wm, wn, pf, vec = m.groups()
         kind = {("true", "true"): "NT", ("true", "false"): "NN", ("false", "false"): "TN", ("false", "true"): "TT"}[(a, b)]
         return f"gemm_kernel<{kind},{64 * int(wm)}x{64 * int(wn)},{'vec' if vec == 'true' else 'scalar'}>"
+    m = re.search(r"gemm_x3b_kernel<(\w+), (\w+), (\w+)>", name)
+    if m:
+        a, b, kg = m.groups()
+        kind = {("true", "true"): "NT", ("true", "false"): "NN", ("false", "false"): "TN"}[(a, b)]
+        return f"gemm_x3b_kernel<{kind},128x128{',rowgather' if kg == 'true' else ''}>"
+    m = re.search(r"gemm_x3w_kernel<(\w+), (\w+), (\w+), (\d+), (\d+), (\d)>", name)
+    if m:
+        a, b, kg, tm, tn, pf = m.groups()
+        kind = {("true", "true"): "NT", ("true", "false"): "NN", ("false", "false"): "TN"}[(a, b)]
+        return f"gemm_x3w_kernel<{kind},{tm}x{tn}{',rowgather' if kg == 'true' else ''}>"
     m = re.search(r"gemm_x3_kernel<(\d), (\d), (\d)>", name)
     if m:
         return f"gemm_x3_kernel<NT,64x{64 * int(m.group(2))},lds{m.group(3)}>"

@@ -58,7 +58,7 @@ struct KArgs {
             // the loop, 2 = no LDS stores, 4 = no barriers
 };
 
-__device__ long long g_clk[4];  // SSC_GEMM_DBG=64 clock probe: {shader cycles, 100 MHz ticks, k-steps} of one workgroup's main loop
+__device__ long long g_clk[8];  // SSC_GEMM_DBG=64 clock probe: {shader cycles, 100 MHz ticks, k-steps} of one workgroup's main loop
 
 // ---- global -> register staging of one ROWS x 32 operand tile (ROWS/8 floats per thread) --------------
 // Loads are UNCONDITIONAL: out-of-range rows / k are clamped to a valid address and (for k) zeroed with a select
@@ -1045,20 +1045,39 @@ __global__ __launch_bounds__(256, 2) void gemm_x3b_kernel(const KArgs a) {
 
 
 // =====================================================================================================
-// Wave-specialised form of gemm_x3b_kernel (same tile, planes and compaction semantics): 8 waves per workgroup.
+// Wave-specialised 3xBF16 kernel (same planes and compaction semantics as gemm_x3b_kernel): 8 waves per workgroup.
 // Waves 4-7 PRODUCE - global loads, fp32 -> 3 x bf16 split (VALU) and plane stores into LDS stage (s+1)&1 - while
-// waves 0-3 CONSUME stage s&1 (LDS fragment reads + 48 MFMAs per wave and k-step).  Each SIMD hosts one producer and
-// one consumer wave, so the split runs in the shadow of the matrix pipe instead of in series with it (in the
-// 4-wave kernel the phases of one workgroup are strictly serial and two co-resident workgroups only partly overlap:
-// rocprof K-scaling, tools/ktime.py: 2.13 us per k-step alone = 1.27 compute + 0.73 split + 0.13 other).
-// Two stages of six planes = 120 KB of LDS: one workgroup (8 waves) per CU, ONE barrier per k-step.
+// waves 0-3 CONSUME stage s&1 (LDS fragment reads + 48 MFMAs per wave and k-step, each wave a 64x64 tile).  Each SIMD
+// hosts one producer and one consumer wave, so loads and the split run beside the matrix pipe instead of in series with
+// it (in the 4-wave kernels the phases of one workgroup are strictly serial and co-resident workgroups only partly
+// overlap: rocprof K-scaling, tools/ktime.py + tools/gemm_clock.py).  ONE barrier per k-step; PF k-steps of operand
+// tiles in flight in the producers' registers (the consumers need theirs for accumulators and fragments).
+//
+// Block tile TM x TN:
+//   128 x 128  large products (consumer waves 2 x 2)
+//    64 x 256  M = minibatch (<= 64 rows) against a wide weight matrix (consumer waves 1 x 4): per streamed weight byte
+//              the 64-row activation tile is re-read and re-split a quarter as often as with a 64-wide tile, and one
+//              k-step moves 32 KB of weights per CU, so a single workgroup per CU keeps HBM busy.
+// Two LDS stages of six planes: 120 KB / 150 KB of dynamic LDS, one workgroup (8 waves) per CU.
 // =====================================================================================================
-constexpr int X3W_LDS_BYTES = 2 * 6 * X3B_PLANE;
+template <int R> struct X3wPlane {   // one bf16 plane of an R-row operand tile: k-contiguous or m/n-contiguous image
+  static constexpr int MC_ROW_B = 2 * R + 64;                        // [32 k][R bf16 + 64 B pad]: 4 k-rows x 64 B on 64 banks
+  static constexpr int KC_BYTES = R * PL_ROW_B, MC_BYTES = 32 * MC_ROW_B;
+  static constexpr int BYTES = KC_BYTES > MC_BYTES ? KC_BYTES : MC_BYTES;
+};
+template <int TM, int TN> constexpr int x3w_lds_bytes() { return 2 * 3 * (X3wPlane<TM>::BYTES + X3wPlane<TN>::BYTES); }
 
-template <bool A_KC, bool B_KC, bool KG>
+template <bool A_KC, bool B_KC, bool KG, int TM, int TN, int PF>
 __global__ __launch_bounds__(512) void gemm_x3w_kernel(const KArgs a) {
-  constexpr int PLN = X3B_PLANE, STAGE = 6 * PLN;
+  static_assert((TM == 128 && TN == 128) || (TM == 64 && TN == 256), "unsupported tile");
+  static_assert(PF == 1 || PF == 2, "prefetch depth");
+  static_assert(!KG || PF == 1, "the gather lists' own loads share the vector-memory counter");
+  constexpr int PLA = X3wPlane<TM>::BYTES, PLB = X3wPlane<TN>::BYTES, STAGE = 3 * (PLA + PLB);
+  constexpr int MCA = X3wPlane<TM>::MC_ROW_B, MCB = X3wPlane<TN>::MC_ROW_B;
+  constexpr int NA = TM / 32, NB = TN / 32;      // float4 chunks per producer thread and k-step
+  constexpr int QA = TM / 4, QB = TN / 4;        // float4 per k-row of an m/n-contiguous tile
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const long long r_entry = __builtin_amdgcn_s_memrealtime();
   const int wave = threadIdx.x >> 6;
   const bool producer = wave >= 4;
   const int tid = threadIdx.x & 255;  // index within the role's 256 threads
@@ -1073,7 +1092,7 @@ __global__ __launch_bounds__(512) void gemm_x3w_kernel(const KArgs a) {
     by = nl / gx;
     bx = nl - by * gx;
   }
-  const int n0 = bx * 128, m0 = by * 128, z = blockIdx.z;
+  const int n0 = bx * TN, m0 = by * TM, z = blockIdx.z;
   const int Meff = a.mcount ? min(a.M, *a.mcount) : a.M;  // uniform per launch
   if (m0 >= Meff) return;
   const int Kc = a.kcount ? max(0, min(a.seg[0].K, *a.kcount)) : 0;
@@ -1089,42 +1108,50 @@ __global__ __launch_bounds__(512) void gemm_x3w_kernel(const KArgs a) {
 
   if (producer) {
     // ================================ producer waves ================================
-    if (a.dbg & 16) __builtin_amdgcn_s_setprio(1);  // the younger half loses VALU arbitration otherwise (MI355X_MICROARCH.md, two waves per SIMD)
-    f32x4 ra[4], rb[4];
-    unsigned oka = 0, okb = 0;
-    const float* pa[4];
-    const float* pb[4];
-    int ia[4], ib[4];  // KG: gathered k-row numbers of the NEXT step
+    f32x4 ra[PF][NA], rb[PF][NB];
+    unsigned oka[PF], okb[PF];
+    const float* pa[NA];
+    const float* pb[NB];
+    int ia[NA], ib[NB];  // KG: gathered k-row numbers of the NEXT step
     Cursor cur;
     int s_ld = s_lo;
+    // chunk idx: k-contiguous operand -> (row idx>>3, k 4*(idx&7)); m/n-contiguous -> (k idx/Q, column 4*(idx%Q))
     auto base_ptrs = [&]() {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < NA; ++u) {
         const int idx = tid + 256 * u;
         if constexpr (A_KC) {
           int r = min(m0 + (idx >> 3), Meff - 1);
           if (a.arows) r = a.arows[r];
           pa[u] = cur.A + (size_t)r * cur.lda + cur.k0 + 4 * (idx & 7);
         } else {
-          int kr = cur.k0 + (idx >> 5);
+          int kr = cur.k0 + idx / QA;
           if constexpr (KG) { if (a.karows) kr = a.karows[min(kr, cur.K - 1)]; }
-          pa[u] = cur.A + (size_t)kr * cur.lda + min(m0 + 4 * (idx & 31), Meff - 4);
+          pa[u] = cur.A + (size_t)kr * cur.lda + min(m0 + 4 * (idx % QA), Meff - 4);
         }
+      }
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        const int idx = tid + 256 * u;
         if constexpr (B_KC) {
           pb[u] = cur.B + (size_t)min(n0 + (idx >> 3), a.N - 1) * cur.ldb + cur.k0 + 4 * (idx & 7);
         } else {
-          int kr = cur.k0 + (idx >> 5);
+          int kr = cur.k0 + idx / QB;
           if constexpr (KG) { if (a.kbrows) kr = a.kbrows[min(kr, cur.K - 1)]; }
-          pb[u] = cur.B + (size_t)kr * cur.ldb + min(n0 + 4 * (idx & 31), a.N - 4);
+          pb[u] = cur.B + (size_t)kr * cur.ldb + min(n0 + 4 * (idx % QB), a.N - 4);
         }
       }
     };
     auto prefetch_rows = [&]() {  // KG: row numbers of the k-step after the cursor's (clamped)
       if constexpr (KG) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int kr = min(cur.k0 + BK + ((tid + 256 * u) >> 5), cur.K - 1);
+        for (int u = 0; u < NA; ++u) {
+          const int kr = min(cur.k0 + BK + (tid + 256 * u) / QA, cur.K - 1);
           ia[u] = a.karows ? a.karows[kr] : kr;
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+          const int kr = min(cur.k0 + BK + (tid + 256 * u) / QB, cur.K - 1);
           ib[u] = a.kbrows ? a.kbrows[kr] : kr;
         }
       }
@@ -1134,118 +1161,147 @@ __global__ __launch_bounds__(512) void gemm_x3w_kernel(const KArgs a) {
         base_ptrs();
       } else if (how == 1) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < NA; ++u) {
           const int idx = tid + 256 * u;
           if constexpr (A_KC) pa[u] += BK;
-          else if constexpr (KG) pa[u] = cur.A + (size_t)ia[u] * cur.lda + min(m0 + 4 * (idx & 31), Meff - 4);
+          else if constexpr (KG) pa[u] = cur.A + (size_t)ia[u] * cur.lda + min(m0 + 4 * (idx % QA), Meff - 4);
           else pa[u] += (size_t)BK * cur.lda;
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+          const int idx = tid + 256 * u;
           if constexpr (B_KC) pb[u] += BK;
-          else if constexpr (KG) pb[u] = cur.B + (size_t)ib[u] * cur.ldb + min(n0 + 4 * (idx & 31), a.N - 4);
+          else if constexpr (KG) pb[u] = cur.B + (size_t)ib[u] * cur.ldb + min(n0 + 4 * (idx % QB), a.N - 4);
           else pb[u] += (size_t)BK * cur.ldb;
         }
         prefetch_rows();
       }
     };
-    auto issue_loads = [&]() {
+    auto issue_loads = [&](f32x4 (&xa)[NA], f32x4 (&xb)[NB], unsigned& ma, unsigned& mb) {
       const bool full = cur.k0 + BK <= cur.K;
       if (full) {
-        oka = okb = 0xfu;
+        ma = mb = 0xffu;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(ra[u]) : "v"(pa[u]) : "memory");
+        for (int u = 0; u < NA; ++u) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(xa[u]) : "v"(pa[u]) : "memory");
 #pragma unroll
-        for (int u = 0; u < 4; ++u) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(rb[u]) : "v"(pb[u]) : "memory");
+        for (int u = 0; u < NB; ++u) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(xb[u]) : "v"(pb[u]) : "memory");
       } else {  // last k-step of a segment: clamp into range, remember which chunks are past the end
-        oka = okb = 0;
-        const float* qa[4];
-        const float* qb[4];
+        ma = mb = 0;
+        const float* qa[NA];
+        const float* qb[NB];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < NA; ++u) {
           const int idx = tid + 256 * u;
           if constexpr (A_KC) {
             const int k = cur.k0 + 4 * (idx & 7);
             qa[u] = pa[u] + (min(k, cur.K - 4) - k);
-            oka |= (k < cur.K ? 1u : 0u) << u;
+            ma |= (k < cur.K ? 1u : 0u) << u;
           } else {
-            const int gk = cur.k0 + (idx >> 5);
+            const int gk = cur.k0 + idx / QA;
             qa[u] = KG ? pa[u] : pa[u] + (ptrdiff_t)(min(gk, cur.K - 1) - gk) * cur.lda;
-            oka |= (gk < cur.K ? 1u : 0u) << u;
-          }
-          if constexpr (B_KC) {
-            const int k = cur.k0 + 4 * (idx & 7);
-            qb[u] = pb[u] + (min(k, cur.K - 4) - k);
-            okb |= (k < cur.K ? 1u : 0u) << u;
-          } else {
-            const int gk = cur.k0 + (idx >> 5);
-            qb[u] = KG ? pb[u] : pb[u] + (ptrdiff_t)(min(gk, cur.K - 1) - gk) * cur.ldb;
-            okb |= (gk < cur.K ? 1u : 0u) << u;
+            ma |= (gk < cur.K ? 1u : 0u) << u;
           }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(ra[u]) : "v"(qa[u]) : "memory");
+        for (int u = 0; u < NB; ++u) {
+          const int idx = tid + 256 * u;
+          if constexpr (B_KC) {
+            const int k = cur.k0 + 4 * (idx & 7);
+            qb[u] = pb[u] + (min(k, cur.K - 4) - k);
+            mb |= (k < cur.K ? 1u : 0u) << u;
+          } else {
+            const int gk = cur.k0 + idx / QB;
+            qb[u] = KG ? pb[u] : pb[u] + (ptrdiff_t)(min(gk, cur.K - 1) - gk) * cur.ldb;
+            mb |= (gk < cur.K ? 1u : 0u) << u;
+          }
+        }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(rb[u]) : "v"(qb[u]) : "memory");
+        for (int u = 0; u < NA; ++u) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(xa[u]) : "v"(qa[u]) : "memory");
+#pragma unroll
+        for (int u = 0; u < NB; ++u) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(xb[u]) : "v"(qb[u]) : "memory");
       }
     };
-    auto wait_loads = [&]() {  // "+v" pins every use of the staged registers behind the wait
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      asm volatile("" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3])::"memory");
+    // wait until at most YOUNGER of the hand-issued loads are outstanding; "+v" pins every use of this stage's registers
+    // behind the wait (cdna_hip_programming.md 5.7)
+    auto pin = [&](f32x4 (&xa)[NA], f32x4 (&xb)[NB]) {
+#pragma unroll
+      for (int u = 0; u < NA; ++u) asm volatile("" : "+v"(xa[u])::"memory");
+#pragma unroll
+      for (int u = 0; u < NB; ++u) asm volatile("" : "+v"(xb[u])::"memory");
     };
     auto advance = [&]() {
       const int how = cur.advance(a, s_ld >= s_last);
       s_ld = min(s_ld + 1, s_last);
       step_ptrs(how);
     };
-    auto put_chunk = [&](unsigned char* p, f32x4 v, bool ok) {
+    auto put_chunk = [&](unsigned char* p, int plane, f32x4 v, bool ok) {
       if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
       u32x2 hi, mid, lo;
       split4(v, hi, mid, lo);
       *reinterpret_cast<u32x2*>(p) = hi;
-      *reinterpret_cast<u32x2*>(p + PLN) = mid;
-      *reinterpret_cast<u32x2*>(p + 2 * PLN) = lo;
+      *reinterpret_cast<u32x2*>(p + plane) = mid;
+      *reinterpret_cast<u32x2*>(p + 2 * plane) = lo;
     };
-    auto put_planes = [&](unsigned char* st) {
-      if (oka == 0xfu && okb == 0xfu) {  // whole k-step in range (uniform): no per-chunk select
+    auto put_planes = [&](unsigned char* st, const f32x4 (&xa)[NA], const f32x4 (&xb)[NB], unsigned ma, unsigned mb) {
+      const bool all = (ma == 0xffu && mb == 0xffu);  // whole k-step in range (uniform): no per-chunk select
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int idx = tid + 256 * u;
-          put_chunk(st + (A_KC ? (idx >> 3) * PL_ROW_B + (idx & 7) * 8 : (idx >> 5) * X3B_MC_ROW_B + (idx & 31) * 8), ra[u], true);
-          put_chunk(st + 3 * PLN + (B_KC ? (idx >> 3) * PL_ROW_B + (idx & 7) * 8 : (idx >> 5) * X3B_MC_ROW_B + (idx & 31) * 8), rb[u], true);
-        }
-      } else {
+      for (int u = 0; u < NA; ++u) {
+        const int idx = tid + 256 * u;
+        put_chunk(st + (A_KC ? (idx >> 3) * PL_ROW_B + (idx & 7) * 8 : (idx / QA) * MCA + (idx % QA) * 8), PLA, xa[u], all || ((ma >> u) & 1u));
+      }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int idx = tid + 256 * u;
-          put_chunk(st + (A_KC ? (idx >> 3) * PL_ROW_B + (idx & 7) * 8 : (idx >> 5) * X3B_MC_ROW_B + (idx & 31) * 8), ra[u], (oka >> u) & 1u);
-          put_chunk(st + 3 * PLN + (B_KC ? (idx >> 3) * PL_ROW_B + (idx & 7) * 8 : (idx >> 5) * X3B_MC_ROW_B + (idx & 31) * 8), rb[u], (okb >> u) & 1u);
-        }
+      for (int u = 0; u < NB; ++u) {
+        const int idx = tid + 256 * u;
+        put_chunk(st + 3 * PLA + (B_KC ? (idx >> 3) * PL_ROW_B + (idx & 7) * 8 : (idx / QB) * MCB + (idx % QB) * 8), PLB, xb[u], all || ((mb >> u) & 1u));
       }
     };
+    constexpr int NL = NA + NB;
 
     if (s_lo < s_hi) {
       cur.init(a, s_lo);
       if (a.kcount) { cur.K = Kc; cur.left = steps_total - 1 - cur.k0 / BK; }
       base_ptrs();
       prefetch_rows();
-      issue_loads();
-      wait_loads();
-      put_planes(lds);
+      // the first PF tiles are requested back to back (one exposed memory latency, not two); afterwards set (r+1) % PF
+      // holds tile s_lo + r + 1 when iteration r starts
+      issue_loads(ra[0], rb[0], oka[0], okb[0]);
+#pragma unroll
+      for (int j = 1; j < PF; ++j) {
+        advance();
+        issue_loads(ra[j], rb[j], oka[j], okb[j]);
+      }
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PF - 1) * NL) : "memory");
+      pin(ra[0], rb[0]);
+      put_planes(lds, ra[0], rb[0], oka[0], okb[0]);
       advance();
-      issue_loads();
+      issue_loads(ra[0], rb[0], oka[0], okb[0]);
     }
     __syncthreads();
-    for (int s = s_lo; s < s_hi; ++s) {
-      wait_loads();
-      if (s + 1 < s_hi && !(a.dbg & 2)) put_planes(lds + ((s + 1 - s_lo) & 1) * STAGE);
-      advance();
-      if (!(a.dbg & 1)) issue_loads();
-      __syncthreads();
+    for (int s = s_lo; s < s_hi; s += 2) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if (s + h < s_hi) {
+          constexpr int dummy = 0; (void)dummy;
+          const int j = (h + 1) % PF;   // (s + h - s_lo + 1) % PF: s - s_lo is even here
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PF - 1) * NL) : "memory");
+          pin(ra[j], rb[j]);
+          if (s + h + 1 < s_hi && !(a.dbg & 2)) put_planes(lds + ((h + 1) & 1) * STAGE, ra[j], rb[j], oka[j], okb[j]);
+          advance();
+          if (!(a.dbg & 1)) issue_loads(ra[j], rb[j], oka[j], okb[j]);
+          __syncthreads();
+        }
+      }
     }
-    wait_loads();  // drain the clamped tail loads with the staged registers pinned (see gemm_kernel)
+    // drain the clamped tail loads with the staged registers pinned (see gemm_kernel)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < PF; ++j) pin(ra[j], rb[j]);
     return;
   }
 
   // ================================ consumer waves ================================
-  const int wm = wave >> 1, wn = wave & 1;
+  constexpr int WNW = TN / 64;  // consumer waves along N
+  const int wm = wave / WNW, wn = wave % WNW;
   const int half = lane >> 5, l31 = lane & 31;
   const int g16 = lane >> 4, i16 = lane & 15;
   f32x16 acc[2][2];
@@ -1257,16 +1313,16 @@ __global__ __launch_bounds__(512) void gemm_x3w_kernel(const KArgs a) {
       for (int i = 0; i < 16; ++i) acc[mi][ni][i] = 0.f;
 
   // fragment = 8 consecutive k (16*kk + 8*half ...) of tile row/column rc0 + (lane & 31) of one plane
-  auto frag = [&](const unsigned char* plane, bool kc, int rc0, int kk) -> bf16x8 {
+  auto frag = [&](const unsigned char* plane, bool kc, int mc_row_b, int rc0, int kk) -> bf16x8 {
     if (kc) {
       return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(plane + (rc0 + l31) * PL_ROW_B + kk * 32 + half * 16));
     } else {
       // transposed read: lane 4q+p of a 16-lane group addresses k-row q, columns 4p..4p+3 of the group's 4 x 16 block and
       // receives column (lane & 15), k-rows 0..3; the second read takes the next 4 k-rows
-      const unsigned char* p = plane + (16 * kk + 8 * (g16 >> 1) + (i16 >> 2)) * X3B_MC_ROW_B + (rc0 + 16 * (g16 & 1) + 4 * (i16 & 3)) * 2;
+      const unsigned char* p = plane + (16 * kk + 8 * (g16 >> 1) + (i16 >> 2)) * mc_row_b + (rc0 + 16 * (g16 & 1) + 4 * (i16 & 3)) * 2;
       typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
       const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
-      const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * X3B_MC_ROW_B));
+      const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * mc_row_b));
       typedef short s16x8 __attribute__((ext_vector_type(8)));
       const s16x8 v = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
       return __builtin_bit_cast(bf16x8, v);
@@ -1279,11 +1335,11 @@ __global__ __launch_bounds__(512) void gemm_x3w_kernel(const KArgs a) {
     bf16x8 fa[2][2][3], fb[2][2][3];  // [kk][tile][plane]
     auto rda = [&](int kk, int pl) {
 #pragma unroll
-      for (int t = 0; t < 2; ++t) fa[kk][t][pl] = frag(st + pl * PLN, A_KC, wm * 64 + t * 32, kk);
+      for (int t = 0; t < 2; ++t) fa[kk][t][pl] = frag(st + pl * PLA, A_KC, MCA, wm * 64 + t * 32, kk);
     };
     auto rdb = [&](int kk, int pl) {
 #pragma unroll
-      for (int t = 0; t < 2; ++t) fb[kk][t][pl] = frag(st + (3 + pl) * PLN, B_KC, wn * 64 + t * 32, kk);
+      for (int t = 0; t < 2; ++t) fb[kk][t][pl] = frag(st + 3 * PLA + pl * PLB, B_KC, MCB, wn * 64 + t * 32, kk);
     };
     // six partial products per accumulator, smallest first (lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi); the reads are
     // ordered by first use and the first fragments of the second k-half are requested under the first half's MFMAs
@@ -1308,11 +1364,10 @@ __global__ __launch_bounds__(512) void gemm_x3w_kernel(const KArgs a) {
     SSC_X3W_MFMA(fa[1], fb[1], 0, 1)
     SSC_X3W_MFMA(fa[1], fb[1], 0, 0)
   };
-#undef SSC_X3W_MFMA_UNUSED
 
   __syncthreads();
   long long t0 = 0, r0 = 0;
-  const bool probe = (a.dbg & 64) && blockIdx.x == 1 && blockIdx.y == 1 && threadIdx.x == 0;
+  const bool probe = (a.dbg & 64) && blockIdx.x == 1 && blockIdx.y == 0 && threadIdx.x == 0;
   if (probe) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
   for (int s = s_lo; s < s_hi; ++s) {
     if (!(a.dbg & 8)) compute(lds + ((s - s_lo) & 1) * STAGE);
@@ -1322,6 +1377,7 @@ __global__ __launch_bounds__(512) void gemm_x3w_kernel(const KArgs a) {
     g_clk[0] = __builtin_amdgcn_s_memtime() - t0;
     g_clk[1] = __builtin_amdgcn_s_memrealtime() - r0;
     g_clk[2] = s_hi - s_lo;
+    g_clk[3] = r0 - r_entry;   // 100 MHz ticks from kernel entry to the end of the prologue
   }
 #undef SSC_X3W_MFMA
 
@@ -1353,6 +1409,10 @@ __global__ __launch_bounds__(512) void gemm_x3w_kernel(const KArgs a) {
         if (rbase + (r & 3) + 8 * (r >> 2) < Meff) out[(size_t)rr[r] * a.ldo + col] = acc[mi][ni][r] + bv + old[r];
       }
     }
+  }
+  if (probe) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    g_clk[4] = __builtin_amdgcn_s_memrealtime() - r_entry;  // ... and to the end of the epilogue
   }
 }
 
@@ -1451,6 +1511,27 @@ inline bool big_tile(int M, int N) { return M >= 512 && N >= 512; }
 int g_wide_min_n = 1024;
 inline bool wide_tile(int M, int N) { return M <= 64 && N >= g_wide_min_n; }
 
+// the wave-specialised kernels need more than the default 64 KB of LDS per workgroup: raise the limit once
+int x3w_prepare() {
+  static bool done = false;
+  if (done) return SSC_OK;
+  gemm_fn big[4] = {gemm_x3w_kernel<true, true, false, 128, 128, 2>, gemm_x3w_kernel<true, false, false, 128, 128, 2>,
+                    gemm_x3w_kernel<false, false, true, 128, 128, 1>, gemm_x3w_kernel<false, false, false, 128, 128, 2>};
+  for (gemm_fn f : big)
+    if (hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, x3w_lds_bytes<128, 128>()) != hipSuccess) return SSC_EHIP;
+  gemm_fn skinny[2] = {gemm_x3w_kernel<true, true, false, 64, 256, 2>, gemm_x3w_kernel<true, false, false, 64, 256, 2>};
+  for (gemm_fn f : skinny)
+    if (hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, x3w_lds_bytes<64, 256>()) != hipSuccess) return SSC_EHIP;
+  done = true;
+  return SSC_OK;
+}
+int g_x3w_skinny = getenv("SSC_X3W_SKINNY") ? atoi(getenv("SSC_X3W_SKINNY")) : 2;  // 0 off, 1 NT and NN, 2 NN only (hook -11 / -12 / -13)
+int g_x3w_min_n = 2048;   // narrower products do not fill the chip with 256-column tiles (rocprof: slower than the 64-wide kernels)
+inline bool x3w_skinny_shape(int M, int N) { return g_x3w_skinny && gemm_mode() == 1 && M <= 64 && N >= g_x3w_min_n; }
+inline bool x3w_skinny(const ssc_gemm_desc* d, bool vec) {   // 2 = only where the weight matrix is [K][N] (backward dG W)
+  return vec && d->a_kc && x3w_skinny_shape(d->M, d->N) && (g_x3w_skinny == 1 || !d->b_kc);
+}
+
 int launch(const ssc_gemm_desc* d, KArgs& k, int splits, hipStream_t st) {
   k.steps_per_split = ssc_cdiv(k.steps_total, splits);
   {
@@ -1466,6 +1547,23 @@ int launch(const ssc_gemm_desc* d, KArgs& k, int splits, hipStream_t st) {
     if ((k.kcount || k.karows || k.kbrows) && (k.nseg != 1 || d->a_kc || d->b_kc)) return SSC_EINVAL;
     if ((k.mcount || k.arows || k.crows) && !d->a_kc) return SSC_EINVAL;
   }
+  if (x3w_skinny(d, vec) && !compact) {  // M = minibatch against a wide weight matrix: 64 x 256 wave-specialised tile
+    dim3 grid(ssc_cdiv(d->N, 256), ssc_cdiv(d->M, 64), splits);
+    ProfRec* rec = nullptr;
+    if (g_prof_on && g_prof && g_prof_n < PROF_MAX) {
+      rec = &g_prof[g_prof_n++];
+      rec->kind = (d->a_kc ? 0 : 2) + (d->b_kc ? 0 : 1);
+      rec->M = d->M; rec->N = d->N; rec->splits = splits; rec->K = 0;
+      for (int i = 0; i < d->nseg; ++i) rec->K += d->seg[i].K;
+      (void)hipEventRecord(rec->e0, st);
+    }
+    SSC_TRY(x3w_prepare());
+    if (d->b_kc) hipLaunchKernelGGL((gemm_x3w_kernel<true, true, false, 64, 256, 2>), grid, dim3(512), (x3w_lds_bytes<64, 256>()), st, k);
+    else hipLaunchKernelGGL((gemm_x3w_kernel<true, false, false, 64, 256, 2>), grid, dim3(512), (x3w_lds_bytes<64, 256>()), st, k);
+    if (rec) (void)hipEventRecord(rec->e1, st);
+    SSC_CHECK_LAUNCH();
+    return SSC_OK;
+  }
   if (gemm_mode() == 1 && vec && !(!d->a_kc && d->b_kc) && (compact || (g_x3b && big_tile(d->M, d->N)))) {
     dim3 grid(ssc_cdiv(d->N, 128), ssc_cdiv(d->M, 128), splits);
     ProfRec* rec = nullptr;
@@ -1478,19 +1576,12 @@ int launch(const ssc_gemm_desc* d, KArgs& k, int splits, hipStream_t st) {
     }
     const bool kg = k.karows || k.kbrows;
     if (g_x3b == 2) {  // wave-specialised form: 8 waves, 120 KB of dynamic LDS
-      gemm_fn fn = (d->a_kc && d->b_kc) ? gemm_x3w_kernel<true, true, false>
-                   : d->a_kc            ? gemm_x3w_kernel<true, false, false>
-                   : kg                 ? gemm_x3w_kernel<false, false, true>
-                                        : gemm_x3w_kernel<false, false, false>;
-      static bool attr_set = false;
-      if (!attr_set) {
-        gemm_fn all[4] = {gemm_x3w_kernel<true, true, false>, gemm_x3w_kernel<true, false, false>,
-                          gemm_x3w_kernel<false, false, true>, gemm_x3w_kernel<false, false, false>};
-        for (gemm_fn f : all)
-          if (hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, X3W_LDS_BYTES) != hipSuccess) return SSC_EHIP;
-        attr_set = true;
-      }
-      hipLaunchKernelGGL(fn, grid, dim3(512), X3W_LDS_BYTES, st, k);
+      gemm_fn fn = (d->a_kc && d->b_kc) ? gemm_x3w_kernel<true, true, false, 128, 128, 2>
+                   : d->a_kc            ? gemm_x3w_kernel<true, false, false, 128, 128, 2>
+                   : kg                 ? gemm_x3w_kernel<false, false, true, 128, 128, 1>
+                                        : gemm_x3w_kernel<false, false, false, 128, 128, 2>;
+      SSC_TRY(x3w_prepare());
+      hipLaunchKernelGGL(fn, grid, dim3(512), (x3w_lds_bytes<128, 128>()), st, k);
     } else
     if (d->a_kc && d->b_kc) hipLaunchKernelGGL((gemm_x3b_kernel<true, true, false>), grid, dim3(256), 0, st, k);
     else if (d->a_kc) hipLaunchKernelGGL((gemm_x3b_kernel<true, false, false>), grid, dim3(256), 0, st, k);
@@ -1548,6 +1639,16 @@ int launch(const ssc_gemm_desc* d, KArgs& k, int splits, hipStream_t st) {
 // time ~ (workgroups on the busiest CU) x (k-steps per workgroup + fixed per-workgroup cost) / efficiency(occupancy)
 //        + per-slab cost.  One wave per SIMD leaves the MFMA pipe ~45 % busy, three or four ~85-90 %.
 extern "C" int ssc_gemm_auto_splits(int M, int N, int ksteps) {
+  if (x3w_skinny_shape(M, N)) {
+    // one workgroup per CU: split K until the grid covers the chip once, at least 4 k-steps per workgroup
+    const int tiles = ssc_cdiv(N, 256);
+    int s = 256 / tiles;
+    if (s > ksteps / 4) s = ksteps / 4;
+    if (s > 32) s = 32;
+    if (s < 1) s = 1;
+    const int per = ssc_cdiv(ksteps, s);
+    return ssc_cdiv(ksteps, per);
+  }
   const bool big = big_tile(M, N);
   const bool wide = !big && wide_tile(M, N);
   const long tiles = big ? (long)ssc_cdiv(M, 128) * ssc_cdiv(N, 128)
@@ -1715,13 +1816,16 @@ extern "C" int ssc_set_gemm_wide_min_n(int n) {
   if (n == -7) g_x3_pf = 4;
   if (n == -8) g_x3b = 0;       // large products back on the 64x64 3xBF16 (NT) / fp32 MFMA (NN, TN) kernels
   if (n == -9) g_x3b = 1;
-  if (n == -10) g_x3b = 2;      // ... on the wave-specialised (producer / consumer) form of that kernel
+  if (n == -10) g_x3b = 2;
+  if (n == -11) g_x3w_skinny = 0;
+  if (n == -12) g_x3w_skinny = 1;
+  if (n == -13) g_x3w_skinny = 2;      // ... on the wave-specialised (producer / consumer) form of that kernel
   return prev;
 }
 
 // diagnostic: in-kernel clock probe of gemm_x3w_kernel (SSC_GEMM_DBG=64): {shader cycles, 100 MHz ticks, k-steps}
 extern "C" int ssc_debug_gemm_clock(long long* out3) {
-  if (hipMemcpyFromSymbol(out3, HIP_SYMBOL(g_clk), 3 * sizeof(long long)) != hipSuccess) return SSC_EHIP;
+  if (hipMemcpyFromSymbol(out3, HIP_SYMBOL(g_clk), 5 * sizeof(long long)) != hipSuccess) return SSC_EHIP;
   return SSC_OK;
 }
 

@@ -15,7 +15,7 @@ from gpuutil import gemm
 from ssc_runtime import lib as L
 
 raw = C.CDLL(L.LIB_PATH)
-rec = (C.c_longlong * 3)()
+rec = (C.c_longlong * 5)()
 for sh in sys.argv[1:]:
     parts = sh.split(":")
     kind, M, N = parts[0], int(parts[1]), int(parts[2])
@@ -32,4 +32,4 @@ for sh in sys.argv[1:]:
     torch.cuda.synchronize()
     assert raw.ssc_debug_gemm_clock(rec) == 0
     cyc, ticks, steps = rec[0], rec[1], max(rec[2], 1)
-    print(f"{sh:28s} dbg={os.environ.get('SSC_GEMM_DBG')}: {cyc / steps:8.0f} cycles/k-step  {ticks * 10.0 / steps:7.1f} ns/k-step  clock {cyc / max(ticks, 1) * 0.1:5.2f} GHz", flush=True)
+    print(f"{sh:28s} dbg={os.environ.get('SSC_GEMM_DBG')}: {cyc / steps:8.0f} cycles/k-step  {ticks * 10.0 / steps:7.1f} ns/k-step  clock {cyc / max(ticks, 1) * 0.1:5.2f} GHz  prologue {rec[3] * 0.01:6.2f} us  loop {ticks * 0.01:6.2f} us  entry->end {rec[4] * 0.01:6.2f} us", flush=True)
