@@ -1105,6 +1105,8 @@ __global__ __launch_bounds__(512) void gemm_x3w_kernel(const KArgs a) {
   int s_hi = s_lo + steps_per_split;
   if (s_hi > steps_total) s_hi = steps_total;
   const int s_last = s_hi - 1;
+  const bool probe = (a.dbg & 64) && blockIdx.x == 1 && blockIdx.y == 0 && threadIdx.x == 0;
+  constexpr int CT_LD = TN + 4;   // epilogue C tile in LDS
 
   if (producer) {
     // ================================ producer waves ================================
@@ -1296,9 +1298,7 @@ __global__ __launch_bounds__(512) void gemm_x3w_kernel(const KArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int j = 0; j < PF; ++j) pin(ra[j], rb[j]);
-    return;
-  }
-
+  } else {
   // ================================ consumer waves ================================
   constexpr int WNW = TN / 64;  // consumer waves along N
   const int wm = wave / WNW, wn = wave % WNW;
@@ -1367,7 +1367,6 @@ __global__ __launch_bounds__(512) void gemm_x3w_kernel(const KArgs a) {
 
   __syncthreads();
   long long t0 = 0, r0 = 0;
-  const bool probe = (a.dbg & 64) && blockIdx.x == 1 && blockIdx.y == 0 && threadIdx.x == 0;
   if (probe) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
   for (int s = s_lo; s < s_hi; ++s) {
     if (!(a.dbg & 8)) compute(lds + ((s - s_lo) & 1) * STAGE);
@@ -1381,32 +1380,45 @@ __global__ __launch_bounds__(512) void gemm_x3w_kernel(const KArgs a) {
   }
 #undef SSC_X3W_MFMA
 
-  float* out = a.out + (size_t)z * a.slab_stride;
+  // accumulators -> fp32 C tile in LDS (the operand stages are free after the last barrier): row-major [TM][TN + 4]
+  float* ct = reinterpret_cast<float*>(lds);
 #pragma unroll
-  for (int ni = 0; ni < 2; ++ni) {
-    const int col = n0 + wn * 64 + ni * 32 + l31;
-    if (col >= a.N) continue;
-    const float bv = (a.bias != nullptr) ? a.bias[col] : 0.f;
+  for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-      const int rbase = m0 + wm * 64 + mi * 32 + 4 * half;
-      int rr[16];
+    for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        rr[r] = min(rbase + (r & 3) + 8 * (r >> 2), Meff - 1);
-        if (a.crows) rr[r] = a.crows[rr[r]];
-      }
-      float old[16];
-      if (a.accumulate) {
+      for (int r = 0; r < 16; ++r)
+        ct[(wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * CT_LD + wn * 64 + ni * 32 + l31] = acc[mi][ni][r];
+  }  // role split
+
+  // ---- epilogue, all 8 waves: C tile rows leave LDS as 16-byte stores, 1 KB contiguous per 64 lanes (the accumulator
+  // layout itself would give 64 four-byte stores per lane in two 128-B pieces each: store-issue-bound, ~8 us per launch)
+  __syncthreads();
+  {
+    const float* ct = reinterpret_cast<const float*>(lds);
+    float* out = a.out + (size_t)z * a.slab_stride;
+    const bool wide = !(a.ldo & 3) && !(a.N & 3) && !(a.slab_stride & 3) && !(reinterpret_cast<uintptr_t>(a.out) & 15) &&
+                      !(reinterpret_cast<uintptr_t>(a.bias) & 15);
+    constexpr int CPR = TN / 4;  // float4 chunks per tile row
 #pragma unroll
-        for (int r = 0; r < 16; ++r) old[r] = out[(size_t)rr[r] * a.ldo + col];
+    for (int i = 0; i < TM * CPR / 512; ++i) {
+      const int c = (int)threadIdx.x + 512 * i;
+      const int row = c / CPR, col = 4 * (c % CPR);
+      const int grow = m0 + row, gcol = n0 + col;
+      if (grow >= Meff || gcol >= a.N) continue;
+      const int rr = a.crows ? a.crows[grow] : grow;
+      float4 v = *reinterpret_cast<const float4*>(&ct[row * CT_LD + col]);
+      float* dst = out + (size_t)rr * a.ldo + gcol;
+      if (wide) {
+        if (a.bias) { const float4 b4 = *reinterpret_cast<const float4*>(a.bias + gcol); v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w; }
+        if (a.accumulate) { const float4 o4 = *reinterpret_cast<const float4*>(dst); v.x += o4.x; v.y += o4.y; v.z += o4.z; v.w += o4.w; }
+        *reinterpret_cast<float4*>(dst) = v;
       } else {
+        const float e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-        for (int r = 0; r < 16; ++r) old[r] = 0.f;
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        if (rbase + (r & 3) + 8 * (r >> 2) < Meff) out[(size_t)rr[r] * a.ldo + col] = acc[mi][ni][r] + bv + old[r];
+        for (int q = 0; q < 4; ++q) {
+          if (gcol + q < a.N) dst[q] = e[q] + (a.bias ? a.bias[gcol + q] : 0.f) + (a.accumulate ? dst[q] : 0.f);
+        }
       }
     }
   }
@@ -1525,8 +1537,8 @@ int x3w_prepare() {
   done = true;
   return SSC_OK;
 }
-int g_x3w_skinny = getenv("SSC_X3W_SKINNY") ? atoi(getenv("SSC_X3W_SKINNY")) : 2;  // 0 off, 1 NT and NN, 2 NN only (hook -11 / -12 / -13)
-int g_x3w_min_n = 2048;   // narrower products do not fill the chip with 256-column tiles (rocprof: slower than the 64-wide kernels)
+int g_x3w_skinny = getenv("SSC_X3W_SKINNY") ? atoi(getenv("SSC_X3W_SKINNY")) : 1;  // 0 off, 1 NT and NN, 2 NN only (hook -11 / -12 / -13)
+int g_x3w_min_n = getenv("SSC_X3W_MIN_N") ? atoi(getenv("SSC_X3W_MIN_N")) : 1024;   // narrower products do not fill the chip with 256-column tiles (rocprof: slower than the 64-wide kernels)
 inline bool x3w_skinny_shape(int M, int N) { return g_x3w_skinny && gemm_mode() == 1 && M <= 64 && N >= g_x3w_min_n; }
 inline bool x3w_skinny(const ssc_gemm_desc* d, bool vec) {   // 2 = only where the weight matrix is [K][N] (backward dG W)
   return vec && d->a_kc && x3w_skinny_shape(d->M, d->N) && (g_x3w_skinny == 1 || !d->b_kc);

@@ -284,4 +284,4 @@ def test_minibatch_products_wave_specialised(kind, N, Ks, splits, form):
         err = ((out.cpu().double() - ref).abs() / mag.clamp_min(1e-30)).max().item()
         assert err <= (2e-6 if (form != -11 or kind == "NT") else 4e-6), err
     finally:
-        lib.ssc_set_gemm_wide_min_n(-13)
+        lib.ssc_set_gemm_wide_min_n(-12)
