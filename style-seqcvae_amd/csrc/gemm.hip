@@ -439,14 +439,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(const KArgs a) {
   if (s_lo < s_hi) {
     cur.init(a, s_lo);
     if constexpr (VEC) tp.recompute(a, cur, m0, n0, tid);
+    // the first PF tiles are requested back to back (one exposed memory latency, not two - what a short K range is
+    // made of); afterwards stage (r + 1) % PF holds tile s_lo + r + 1 when sub-iteration r starts
     issue_loads(st[0]);
-    st[0].template wait<0>();
-    st[0].store(As, Bs, tid);
 #pragma unroll
-    for (int j = 0; j < PF; ++j) {
+    for (int j = 1; j < PF; ++j) {
       advance();
       issue_loads(st[j]);
     }
+    st[0].template wait<(PF - 1) * NL>();
+    st[0].store(As, Bs, tid);
+    advance();
+    issue_loads(st[0]);
   }
   __syncthreads();
 
@@ -483,7 +487,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const KArgs a) {
 #pragma unroll
     for (int j = 0; j < U; ++j) {
       if (s + j < s_hi) {
-        StageT& x = st[j % PF];
+        StageT& x = st[(j + 1) % PF];
         compute(j & 1);
         x.template wait<(PF - 1) * NL>();
         if (s + j + 1 < s_hi && !(a.dbg & 2)) x.store(As + ((j + 1) & 1) * TA, Bs + ((j + 1) & 1) * TB, tid);
@@ -649,14 +653,17 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const KArgs a) {
   if (s_lo < s_hi) {
     cur.init(a, s_lo);
     tp.recompute(a, cur, m0, n0, tid);
+    // first PF tiles requested back to back (see gemm_kernel); stage (r + 1) % PF then holds tile s_lo + r + 1
     issue_loads(st[0]);
-    st[0].template wait<0>();
-    put_planes(lds, st[0]);
 #pragma unroll
-    for (int j = 0; j < PF; ++j) {
+    for (int j = 1; j < PF; ++j) {
       tp.step(a, cur, cur.advance(a, s_ld >= s_last), m0, n0, tid); s_ld = min(s_ld + 1, s_last);
       issue_loads(st[j]);
     }
+    st[0].template wait<(PF - 1) * NL>();
+    put_planes(lds, st[0]);
+    tp.step(a, cur, cur.advance(a, s_ld >= s_last), m0, n0, tid); s_ld = min(s_ld + 1, s_last);
+    issue_loads(st[0]);
   }
   __syncthreads();
 
@@ -690,7 +697,7 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const KArgs a) {
 #pragma unroll
     for (int j = 0; j < U; ++j) {
       if (s + j < s_hi) {
-        StageT& x = st[j % PF];
+        StageT& x = st[(j + 1) % PF];
         // One basic block: this step's MFMA chain and the NEXT tile's fp32 -> 3xbf16 split (VALU) + plane stores.  A wave
         // issues in order and a dependent MFMA blocks everything behind it, so the split must sit BETWEEN the MFMAs to
         // run in their shadow (sched_group_barrier below); the store is unconditional (past the end it re-stores the
