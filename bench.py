@@ -23,6 +23,7 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3   # MI355X_MICROARCH.md: fp32 MFMA = fp32 vector peak
+MFMA_BF16_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
 
 C2 = dict(B=64, R=36, F=2048, L=20, Z=128, V=10000, E=1000, H=1200, A=768)
 
@@ -309,25 +310,47 @@ def main():
                     us = tot / cnt * 1e3
                     f.write(f"{names[kind][12:14]},{M},{N},{K},{sp},{cnt / nprof:.1f},{us:.1f},{tot / nprof:.3f},"
                             f"{2.0 * M * N * K / us / 1e6:.1f},{4.0 * (K * (M + N) + M * N * sp) / us / 1e3:.0f}\n")
-        dom = max(agg, key=lambda k: agg[k]["ms"])
-        d = agg[dom]
-        tf = d["flops"] / (d["ms"] * 1e-3) / 1e12
-        gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+        # Two regimes (DESIGN.md "GEMM"): the per-timestep MINIBATCH products (M = B rows against a wide weight matrix,
+        # forward x W^T and backward dG W) stream every weight once per launch -> HBM-bound; the LARGE products over the
+        # (t, b) rows (hoisted gate terms, vocabulary head, weight gradients) are bound by the bf16 matrix pipe, on which
+        # the 3xBF16 kernels spend six MFMA passes per fp32 product.
+        fam = {"minibatch": dict(ms=0.0, bytes=0.0, flops=0.0, n=0), "large": dict(ms=0.0, bytes=0.0, flops=0.0, n=0)}
+        for kind, M, N, K, splits, msr in rec.tolist():
+            f = fam["minibatch" if M <= c["B"] else "large"]
+            f["ms"] += msr
+            f["bytes"] += 4.0 * (K * N + M * K + M * N)          # algorithmic: every operand and the result once
+            f["flops"] += 2.0 * M * N * K
+            f["n"] += 1
+        pm = {}
+        try:  # HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/)
+            pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")))["kernels"]
+        except Exception:
+            pm = {}
+
+        def traffic_of(prefixes):
+            sel = [v for k, v in pm.items() if any(k.startswith(f) for f in prefixes)]
+            if not sel:
+                return None
+            return sum(v["hbm_bytes_per_launch"] * v["launches"] for v in sel) / max(1, sum(v["launches"] for v in sel))
+
+        mb, lg = fam["minibatch"], fam["large"]
+        total_gemm_ms = mb["ms"] + lg["ms"]
+        gbs = mb["bytes"] / (mb["ms"] * 1e-3) / 1e9
+        roof_mb = {"bound": "hbm", "kernel": "minibatch GEMMs (M = B: gemm_x3w_kernel<64x256>, gemm_x3_kernel<64x64>, gemm_kernel<64x64>)",
+                   "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                   "traffic": traffic_of(("gemm_x3w_kernel<NT,64x256", "gemm_x3w_kernel<NN,64x256", "gemm_x3_kernel", "gemm_kernel<NN,64x", "gemm_kernel<NT,64x")),
+                   "algorithmic_bytes_per_launch": mb["bytes"] / max(1, mb["n"]), "launches_per_step": mb["n"] / nprof,
+                   "avg_launch_us": mb["ms"] / max(1, mb["n"]) * 1e3, "share_of_gemm_time": mb["ms"] / total_gemm_ms}
+        tf6 = 6.0 * lg["flops"] / (lg["ms"] * 1e-3) / 1e12
+        roof_lg = {"bound": "mfma", "kernel": "large 3xBF16 GEMMs (gemm_x3b_kernel<128x128>; 6 bf16 MFMA passes per fp32 product; "
+                   "nominal K - padded rows skipped on the device count as done)",
+                   "achieved": tf6, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": tf6 / MFMA_BF16_PEAK_TF,
+                   "traffic": traffic_of(("gemm_x3b_kernel", "gemm_x3w_kernel<NT,128", "gemm_x3w_kernel<NN,128", "gemm_x3w_kernel<TN,128")),
+                   "fp32_equivalent_TFLOPs": lg["flops"] / (lg["ms"] * 1e-3) / 1e12, "launches_per_step": lg["n"] / nprof,
+                   "avg_launch_us": lg["ms"] / max(1, lg["n"]) * 1e3, "share_of_gemm_time": lg["ms"] / total_gemm_ms}
+        roofline, roofline_other = (roof_mb, roof_lg) if mb["ms"] >= lg["ms"] else (roof_lg, roof_mb)
         # the recurrent (per-timestep) gate GEMMs of the fused attention+LSTM step: NT launches with M == B, N == 4H
         step_recs = [r for r in rec.tolist() if int(r[0]) == 0 and int(r[1]) == c["B"] and int(r[2]) == 4 * c["H"]]
-        traffic = None
-        try:  # HBM-side bytes per launch of this kernel family from the committed rocprofv3 PMC passes (profiles/)
-            pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")))["kernels"]
-            fam = {0: ("gemm_x3", "gemm_kernel<NT"), 1: ("gemm_kernel<NN",), 3: ("gemm_kernel<TN",)}[dom]
-            sel = [v for k, v in pm.items() if any(k.startswith(f) for f in fam)]
-            traffic = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in sel) / max(1, sum(v["launches"] for v in sel))
-        except Exception:
-            traffic = None
-        roofline = {"bound": "mfma", "kernel": names[dom], "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                    "frac": tf / MFMA_F32_PEAK_TF, "traffic": traffic, "launches_per_step": d["n"] / nprof,
-                    "avg_launch_us": d["ms"] / d["n"] * 1e3, "algorithmic_GBps": gbs,
-                    "hbm_frac_of_8TBps": gbs / HBM_PEAK_GBS,
-                    "share_of_gemm_time": d["ms"] / sum(a["ms"] for a in agg.values())}
         T = c["L"] + 1
         fused = fused_step_bytes(c)
         fwd_step_us = (sum(fwd_ms) / len(fwd_ms)) / T * 1e3   # whole forward / T: upper bound on one fused step
@@ -342,7 +365,8 @@ def main():
                   "config": {"workload": "C2 train step: fwd+bwd+allreduce+clip+SGD, B=%d/GPU, R=36, F=2048, L=20 (T=21), "
                                          "Z=128, V=10000, E=1000, H=1200, A=768, SENTIMENT_VAE=1" % c["B"],
                              "global_batch": world * c["B"], "parallelism": f"dp{world}", "loss_probe": loss_probe},
-                  "roofline": roofline, "roofline_step": roofline_step,
+                  "roofline": roofline, "roofline_large_gemm" if roofline is roof_mb else "roofline_minibatch_gemm": roofline_other,
+                  "roofline_step": roofline_step,
                   "gemm_time_ms_per_step": {names[k]: agg[k]["ms"] / nprof for k in agg}}
         result["attention_roofline"] = attention_roofline(device)
         if world == 1 and not args.no_cpu_baseline:
