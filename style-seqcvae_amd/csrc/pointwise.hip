@@ -87,35 +87,47 @@ __global__ void lstm_fwd_kernel(const ssc_lstm_fwd_desc d) {
   int b = blockIdx.y;
   if (j >= d.H) return;
   const int H = d.H, H4 = 4 * d.H;
-  float pre[4] = {0.f, 0.f, 0.f, 0.f};
-  // split-K slabs: summed in index order per gate; the loads of all four gates x 8 slabs (32) are in flight together
-  // (a `v += load` loop with a dynamic trip count serialises one memory latency per slab)
-  for (int s0 = 0; s0 < d.nslab; s0 += 8) {
-    float t[4][8];
+  // The kernel moves ~20 MB: it is bound by memory latency, not bandwidth.  Every operand that does not depend on the
+  // slab sums is requested first and all slabs (up to 16) in one batch, so about one latency is exposed in total.
+  float a0[4], a1[4], bi[4], bh[4], sw[4];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+  for (int g = 0; g < 4; ++g) {
+    const int n = g * H + j;
+    a0[g] = d.add0 ? d.add0[(size_t)b * d.ld_add0 + n] : 0.f;
+    a1[g] = d.add1 ? d.add1[(size_t)(b / d.rows_per_add1) * d.ld_add1 + n] : 0.f;
+    bi[g] = d.b_ih ? d.b_ih[n] : 0.f;
+    bh[g] = d.b_hh ? d.b_hh[n] : 0.f;
+    sw[g] = d.sent ? d.wcol[(size_t)n * d.ldwcol] : 0.f;
+  }
+  const float sv = d.sent ? d.sent[b] : 0.f;
+  const float cp = d.c_prev ? d.c_prev[(size_t)b * d.ld_cprev + j] : 0.f;
+  float pre[4] = {0.f, 0.f, 0.f, 0.f};
+  // split-K slabs: summed in index order per gate (a `v += load` loop with a dynamic trip count would serialise one
+  // memory latency per slab)
+  for (int s0 = 0; s0 < d.nslab; s0 += 16) {
+    float t[4][16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
       const float* sp = d.slabs + (size_t)min(s0 + u, d.nslab - 1) * d.slab_stride + (size_t)b * H4 + j;
 #pragma unroll
       for (int g = 0; g < 4; ++g) t[g][u] = sp[g * H];
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
+    for (int u = 0; u < 16; ++u)
 #pragma unroll
       for (int g = 0; g < 4; ++g) pre[g] += (s0 + u < d.nslab) ? t[g][u] : 0.f;
   }
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    int n = g * H + j;
+  for (int g = 0; g < 4; ++g) {  // absent terms add +0.f, which leaves every value unchanged
     float v = pre[g];
-    if (d.add0) v += d.add0[(size_t)b * d.ld_add0 + n];
-    if (d.add1) v += d.add1[(size_t)(b / d.rows_per_add1) * d.ld_add1 + n];
-    if (d.b_ih) v += d.b_ih[n];
-    if (d.b_hh) v += d.b_hh[n];
-    if (d.sent) v += d.sent[b] * d.wcol[(size_t)n * d.ldwcol];
+    v += a0[g];
+    v += a1[g];
+    v += bi[g];
+    v += bh[g];
+    if (d.sent) v += sv * sw[g];
     pre[g] = v;
   }
   float ig = ssc_sigmoid(pre[0]), fg = ssc_sigmoid(pre[1]), gg = tanhf(pre[2]), og = ssc_sigmoid(pre[3]);
-  float cp = d.c_prev ? d.c_prev[(size_t)b * d.ld_cprev + j] : 0.f;
   float c = fg * cp + ig * gg;
   float h = og * tanhf(c);
   if (d.gates_out) {
@@ -125,33 +137,34 @@ __global__ void lstm_fwd_kernel(const ssc_lstm_fwd_desc d) {
   d.c_out[(size_t)b * d.ld_cout + j] = c;
   d.h_out[(size_t)b * d.ld_hout + j] = h;
 }
-
 __global__ void lstm_bwd_kernel(const ssc_lstm_bwd_desc d) {
   int j = blockIdx.x * blockDim.x + threadIdx.x;
   int b = blockIdx.y;
   if (j >= d.H) return;
   const int H = d.H, H4 = 4 * d.H;
+  // latency-bound like lstm_fwd_kernel: the saved activations are requested before the slab sums are consumed
+  const float dcin = d.dc_in ? d.dc_in[(size_t)b * d.ld_dcin + j] : 0.f;
+  const float* g = d.gates + (size_t)b * H4 + j;
+  const float ig = g[0], fg = g[H], gg = g[2 * H], og = g[3 * H];
+  const float cp = d.c_prev[(size_t)b * d.ld_cprev + j];
+  const float cn = d.c_new[(size_t)b * d.ld_cnew + j];
   float dh = d.dh ? d.dh[(size_t)b * d.ld_dh + j] : 0.f;
   if (d.dh2) dh += d.dh2[(size_t)b * d.ld_dh2 + j];
-  for (int s0 = 0; s0 < d.nA; s0 += 8) {  // split-K slabs of the producing GEMMs, fixed order, 8 loads in flight
-    float t[8];
+  for (int s0 = 0; s0 < d.nA; s0 += 16) {  // split-K slabs of the producing GEMMs, fixed order, 16 loads in flight
+    float t[16];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) t[u] = d.slabsA[(size_t)min(s0 + u, d.nA - 1) * d.strideA + (size_t)b * H + j];
+    for (int u = 0; u < 16; ++u) t[u] = d.slabsA[(size_t)min(s0 + u, d.nA - 1) * d.strideA + (size_t)b * H + j];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) dh += (s0 + u < d.nA) ? t[u] : 0.f;
+    for (int u = 0; u < 16; ++u) dh += (s0 + u < d.nA) ? t[u] : 0.f;
   }
-  for (int s0 = 0; s0 < d.nB; s0 += 8) {
-    float t[8];
+  for (int s0 = 0; s0 < d.nB; s0 += 16) {
+    float t[16];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) t[u] = d.slabsB[(size_t)min(s0 + u, d.nB - 1) * d.strideB + (size_t)b * H + j];
+    for (int u = 0; u < 16; ++u) t[u] = d.slabsB[(size_t)min(s0 + u, d.nB - 1) * d.strideB + (size_t)b * H + j];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) dh += (s0 + u < d.nB) ? t[u] : 0.f;
+    for (int u = 0; u < 16; ++u) dh += (s0 + u < d.nB) ? t[u] : 0.f;
   }
-  float dcin = d.dc_in ? d.dc_in[(size_t)b * d.ld_dcin + j] : 0.f;
-  const float* g = d.gates + (size_t)b * H4 + j;
-  float ig = g[0], fg = g[H], gg = g[2 * H], og = g[3 * H];
-  float cp = d.c_prev[(size_t)b * d.ld_cprev + j];
-  float tc = tanhf(d.c_new[(size_t)b * d.ld_cnew + j]);
+  float tc = tanhf(cn);
   float d_o = dh * tc;
   float dc = dcin + dh * og * (1.f - tc * tc);
   float dgi = dc * gg * ig * (1.f - ig);
