@@ -1517,7 +1517,7 @@ inline int gemm_mode() {
   return g_gemm_mode;
 }
 inline bool use_x3(const ssc_gemm_desc* d, bool vec) { return gemm_mode() == 1 && d->a_kc && d->b_kc && vec; }
-int g_x3b = getenv("SSC_X3B") ? atoi(getenv("SSC_X3B")) : 1;  // large products (M, N >= 512): 0 = 64x64 kernels, 1 = 128x128 3xBF16 kernel, 2 = its wave-specialised form (hook -8 / -9 / -10)
+int g_x3b = getenv("SSC_X3B") ? atoi(getenv("SSC_X3B")) : 1;  // large products (M, N >= 512): 0 = 64x64 kernels, 1 = 128x128 3xBF16 kernels, form chosen by grid size, 2 / 3 = always the wave-specialised / the 4-wave form (hooks -8, -14, -10, -9)
 int g_x3_nbuf = 1;  // single LDS stage: 31 KB per workgroup -> four resident workgroups per CU (rocprof r01: 37 vs 43 us)
 int g_x3_wide = 0;
 int g_x3_pf = 2;  // tuning hook: 1 = 64x128 block tile for skinny (M <= 64, N >= 1024) 3xBF16 products
@@ -1594,7 +1594,11 @@ int launch(const ssc_gemm_desc* d, KArgs& k, int splits, hipStream_t st) {
       (void)hipEventRecord(rec->e0, st);
     }
     const bool kg = k.karows || k.kbrows;
-    if (g_x3b == 2) {  // wave-specialised form: 8 waves, 120 KB of dynamic LDS
+    // Form: the 4-wave kernel keeps two workgroups per CU, which evens out small grids (380 tiles on 256 CUs); the
+    // wave-specialised one runs ~13 % fewer cycles per k-step and wins once the grid is several rounds deep (decode:
+    // 1520 tiles, +10 % tokens/s).  g_x3b: 1 = choose by grid size, 2 = always wave-specialised, 3 = always 4-wave.
+    const long wgs = (long)grid.x * grid.y * grid.z;
+    if (g_x3b == 2 || (g_x3b == 1 && wgs >= 768)) {  // wave-specialised form: 8 waves, 120 KB of dynamic LDS
       gemm_fn fn = (d->a_kc && d->b_kc) ? gemm_x3w_kernel<true, true, false, 128, 128, 2>
                    : d->a_kc            ? gemm_x3w_kernel<true, false, false, 128, 128, 2>
                    : kg                 ? gemm_x3w_kernel<false, false, true, 128, 128, 1>
@@ -1834,8 +1838,9 @@ extern "C" int ssc_set_gemm_wide_min_n(int n) {
   if (n == -6) g_x3_pf = 2;
   if (n == -7) g_x3_pf = 4;
   if (n == -8) g_x3b = 0;       // large products back on the 64x64 3xBF16 (NT) / fp32 MFMA (NN, TN) kernels
-  if (n == -9) g_x3b = 1;
+  if (n == -9) g_x3b = 3;   // (tests: the 4-wave form regardless of the grid)
   if (n == -10) g_x3b = 2;
+  if (n == -14) g_x3b = 1;
   if (n == -11) g_x3w_skinny = 0;
   if (n == -12) g_x3w_skinny = 1;
   if (n == -13) g_x3w_skinny = 2;      // ... on the wave-specialised (producer / consumer) form of that kernel

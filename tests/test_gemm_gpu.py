@@ -254,7 +254,7 @@ def test_large_products_split_bf16(kind, M, N, Ks, splits, form):
         ad, bd = a.cpu().double(), b.cpu().double()
         refi += (ad if a_kc else ad.T) @ (bd.T if b_kc else bd)
     assert torch.equal(out.cpu().double(), refi)
-    L.load().ssc_set_gemm_wide_min_n(-9)
+    L.load().ssc_set_gemm_wide_min_n(-14)
 
 
 @pytest.mark.parametrize("form", [-12, -13, -11])
