@@ -232,7 +232,7 @@ int ssc_log_softmax(const float* logits, int ldl, int rows, int V, float* out, i
 /* out[n] (+)= sum_rows wrow[row]*X[row,n]  (bias grads: wrow=0 -> weights 1; sentiment column grads) */
 int ssc_colsum(const float* X, int ldx, int rows, int N, const float* wrow, float* out, int out_stride, int accumulate,
                void* stream);
-/* same, two-stage for many rows: scratch >= 16*N floats; out2 (optional, stride 1) receives a second copy
+/* same, two-stage for many rows: scratch >= 64*N floats; out2 (optional, stride 1) receives a second copy
  * (nn.LSTMCell's bias_ih / bias_hh gradients are the same vector). */
 int ssc_colsum2(const float* X, int ldx, int rows, int N, const float* wrow, float* out, int out_stride, float* out2,
                 int accumulate, float* scratch, void* stream);

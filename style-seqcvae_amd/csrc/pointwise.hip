@@ -354,7 +354,7 @@ __global__ void log_softmax_kernel(const float* __restrict__ logits, int ldl, in
 // ---------------------------------------------------------------------------------------------
 // column sums in two deterministic stages: stage 1 - workgroup (column slice of 256, row chunk) -> partials
 // [chunk][N] (thread per column: 1 KiB coalesced row reads); stage 2 - sum the chunks, write out (and out2).
-constexpr int COLSUM_CHUNKS = 16;
+constexpr int COLSUM_CHUNKS = 64;   // 19 column slices x 64 row chunks = 1216 workgroups at N = 4H (latency-bound otherwise)
 __global__ __launch_bounds__(256) void colsum_stage1_kernel(const float* __restrict__ X, int ldx, int rows, int N,
                                                             const float* __restrict__ wrow, float* __restrict__ part) {
   int n = blockIdx.x * 256 + threadIdx.x;
@@ -363,19 +363,37 @@ __global__ __launch_bounds__(256) void colsum_stage1_kernel(const float* __restr
   int r0 = chunk * per, r1 = r0 + per < rows ? r0 + per : rows;
   if (n >= N) return;
   float s = 0.f;
-  for (int r = r0; r < r1; ++r) {
-    float x = X[(size_t)r * ldx + n];
-    s += wrow ? wrow[r] * x : x;
+  for (int r = r0; r < r1; r += 8) {  // 8 row loads in flight, summed in row order
+    float x[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int rr = min(r + u, r1 - 1);
+      x[u] = X[(size_t)rr * ldx + n];
+      if (wrow) x[u] *= wrow[rr];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += (r + u < r1) ? x[u] : 0.f;
   }
   part[(size_t)chunk * N + n] = s;
 }
 __global__ __launch_bounds__(256) void colsum_stage2_kernel(const float* __restrict__ part, int N, float* __restrict__ out,
                                                             int out_stride, float* __restrict__ out2, int accumulate) {
-  int n = blockIdx.x * 256 + threadIdx.x;
-  if (n >= N) return;
+  // 64 columns per workgroup; wave q sums chunks 16q .. 16q+15 (16 loads in flight), wave 0 adds the four partial sums
+  __shared__ float sh[4][64];
+  const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + c;
   float t = 0.f;
+  if (n < N) {
+    float x[COLSUM_CHUNKS / 4];
 #pragma unroll
-  for (int c = 0; c < COLSUM_CHUNKS; ++c) t += part[(size_t)c * N + n];
+    for (int u = 0; u < COLSUM_CHUNKS / 4; ++u) x[u] = part[(size_t)(q * (COLSUM_CHUNKS / 4) + u) * N + n];
+#pragma unroll
+    for (int u = 0; u < COLSUM_CHUNKS / 4; ++u) t += x[u];
+  }
+  sh[q][c] = t;
+  __syncthreads();
+  if (q != 0 || n >= N) return;
+  t = ((sh[0][c] + sh[1][c]) + sh[2][c]) + sh[3][c];
   float* o = out + (size_t)n * out_stride;
   *o = accumulate ? *o + t : t;
   if (out2) out2[n] = accumulate ? out2[n] + t : t;
@@ -594,7 +612,7 @@ extern "C" int ssc_colsum2(const float* X, int ldx, int rows, int N, const float
     hipLaunchKernelGGL(colsum_stage1_kernel, dim3(ssc_cdiv(N, 256), COLSUM_CHUNKS), dim3(256), 0, S(stream), X, ldx, rows, N,
                        wrow, scratch);
     SSC_CHECK_LAUNCH();
-    hipLaunchKernelGGL(colsum_stage2_kernel, dim3(ssc_cdiv(N, 256)), dim3(256), 0, S(stream), scratch, N, out, out_stride,
+    hipLaunchKernelGGL(colsum_stage2_kernel, dim3(ssc_cdiv(N, 64)), dim3(256), 0, S(stream), scratch, N, out, out_stride,
                        out2, accumulate);
     SSC_CHECK_LAUNCH();
     return SSC_OK;
