@@ -123,10 +123,15 @@ __global__ __launch_bounds__(64) void attn_apply_kernel(const float* __restrict_
   if (((F & 3) == 0) && ssc_aligned16_dev(fp) && ((ldatt & 3) == 0) && ssc_aligned16_dev(att)) {
     if (f < F) {
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int r = 0; r < R; ++r) {
-        float a = sa[r];
-        float4 v = *reinterpret_cast<const float4*>(fp + (size_t)r * F + f);
-        acc.x += a * v.x; acc.y += a * v.y; acc.z += a * v.z; acc.w += a * v.w;
+      for (int r0 = 0; r0 < R; r0 += 12) {  // 12 region rows in flight (the kernel is latency-bound), summed in region order
+        float4 v[12];
+#pragma unroll
+        for (int u = 0; u < 12; ++u) v[u] = *reinterpret_cast<const float4*>(fp + (size_t)min(r0 + u, R - 1) * F + f);
+#pragma unroll
+        for (int u = 0; u < 12; ++u) {
+          const float a = (r0 + u < R) ? sa[r0 + u] : 0.f;
+          acc.x += a * v[u].x; acc.y += a * v[u].y; acc.z += a * v[u].z; acc.w += a * v[u].w;
+        }
       }
       *reinterpret_cast<float4*>(att + (size_t)g * ldatt + f) = acc;
     }
@@ -197,22 +202,33 @@ __global__ __launch_bounds__(256) void attn_bwd_apply_kernel(const float* __rest
       const float4 qv = *reinterpret_cast<const float4*>(q + (size_t)g * ldq + a0);
       const float4 wv = *reinterpret_cast<const float4*>(wa + a0);
       const float qa[4] = {qv.x, qv.y, qv.z, qv.w}, ww[4] = {wv.x, wv.y, wv.z, wv.w};
-      for (int r = wave; r < R; r += 4) {
-        const size_t off = ((size_t)g * R + r) * A + a0;
-        const float4 p4 = *reinterpret_cast<const float4*>(pv + off);
-        float4 acc = *reinterpret_cast<const float4*>(dpv_acc + off);
-        const float pp[4] = {p4.x, p4.y, p4.z, p4.w};
-        float dp[4];
-        const float dl = sdl[r];
+      for (int rb = wave; rb < R; rb += 4 * 5) {  // 5 of this wave's regions per batch: 10 loads in flight, region order kept
+        float4 p4[5], ac[5];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          float u = tanhf(qa[k] + pp[k]);
-          dp[k] = dl * ww[k] * (1.f - u * u);
-          dqa[k] += dp[k];
-          dw[k] += dl * u;
+        for (int i = 0; i < 5; ++i) {
+          const size_t off = ((size_t)g * R + min(rb + 4 * i, R - 1)) * A + a0;
+          p4[i] = *reinterpret_cast<const float4*>(pv + off);
+          ac[i] = *reinterpret_cast<const float4*>(dpv_acc + off);
         }
-        acc.x += dp[0]; acc.y += dp[1]; acc.z += dp[2]; acc.w += dp[3];
-        *reinterpret_cast<float4*>(dpv_acc + off) = acc;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+          const int r = rb + 4 * i;
+          if (r < R) {
+            const float pp[4] = {p4[i].x, p4[i].y, p4[i].z, p4[i].w};
+            float dp[4];
+            const float dl = sdl[r];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              float u = tanhf(qa[k] + pp[k]);
+              dp[k] = dl * ww[k] * (1.f - u * u);
+              dqa[k] += dp[k];
+              dw[k] += dl * u;
+            }
+            float4 acc = ac[i];
+            acc.x += dp[0]; acc.y += dp[1]; acc.z += dp[2]; acc.w += dp[3];
+            *reinterpret_cast<float4*>(dpv_acc + ((size_t)g * R + r) * A + a0) = acc;
+          }
+        }
       }
     }
   } else {
