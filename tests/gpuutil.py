@@ -3,8 +3,7 @@ import ctypes as C
 
 import torch
 
-import oracle
-from ssc_runtime import lib as L
+from ssc_runtime import lib as L   # (no oracle import here: tools/ reuse the GEMM helper and must stay oracle-free)
 from ssc_runtime.engine import ModelDims, TrainEngine
 
 
