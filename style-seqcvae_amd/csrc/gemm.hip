@@ -1075,7 +1075,8 @@ template <int R> struct X3wPlane {   // one bf16 plane of an R-row operand tile:
 template <int TM, int TN> constexpr int x3w_lds_bytes() { return 2 * 3 * (X3wPlane<TM>::BYTES + X3wPlane<TN>::BYTES); }
 
 template <bool A_KC, bool B_KC, bool KG, int TM, int TN, int PF>
-__global__ __launch_bounds__(512) void gemm_x3w_kernel(const KArgs a) {
+__device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const int blk_y, const int blk_z, const int grid_x,
+                                         const int grid_y, const int grid_z) {
   static_assert((TM == 128 && TN == 128) || (TM == 64 && TN == 256), "unsupported tile");
   static_assert(PF == 1 || PF == 2, "prefetch depth");
   static_assert(!KG || PF == 1, "the gather lists' own loads share the vector-memory counter");
@@ -1089,9 +1090,9 @@ __global__ __launch_bounds__(512) void gemm_x3w_kernel(const KArgs a) {
   const bool producer = wave >= 4;
   const int tid = threadIdx.x & 255;  // index within the role's 256 threads
   const int lane = tid & 63;
-  int bx = blockIdx.x, by = blockIdx.y;
+  int bx = blk_x, by = blk_y;
   {
-    const int gx = gridDim.x, total = gridDim.x * gridDim.y;
+    const int gx = grid_x, total = grid_x * grid_y;
     const int lin = by * gx + bx;
     const int q = total >> 3, rem = total & 7;
     const int xcd = lin & 7, slot = lin >> 3;
@@ -1099,20 +1100,20 @@ __global__ __launch_bounds__(512) void gemm_x3w_kernel(const KArgs a) {
     by = nl / gx;
     bx = nl - by * gx;
   }
-  const int n0 = bx * TN, m0 = by * TM, z = blockIdx.z;
+  const int n0 = bx * TN, m0 = by * TM, z = blk_z;
   const int Meff = a.mcount ? min(a.M, *a.mcount) : a.M;  // uniform per launch
   if (m0 >= Meff) return;
   const int Kc = a.kcount ? max(0, min(a.seg[0].K, *a.kcount)) : 0;
   int steps_total = a.steps_total, steps_per_split = a.steps_per_split;
   if (a.kcount) {  // K is known only on the device: partition the k-steps here
     steps_total = (Kc + BK - 1) / BK;
-    steps_per_split = (steps_total + (int)gridDim.z - 1) / (int)gridDim.z;
+    steps_per_split = (steps_total + grid_z - 1) / grid_z;
   }
   const int s_lo = z * steps_per_split;
   int s_hi = s_lo + steps_per_split;
   if (s_hi > steps_total) s_hi = steps_total;
   const int s_last = s_hi - 1;
-  const bool probe = (a.dbg & 64) && blockIdx.x == 1 && blockIdx.y == 0 && threadIdx.x == 0;
+  const bool probe = (a.dbg & 64) && blk_x == 1 && blk_y == 0 && threadIdx.x == 0;
   constexpr int CT_LD = TN + 4;   // epilogue C tile in LDS
 
   if (producer) {
@@ -1436,6 +1437,30 @@ __global__ __launch_bounds__(512) void gemm_x3w_kernel(const KArgs a) {
 }
 
 
+// Launch form: a GROUP of up to SSC_GROUP_MAX independent products (own operands, K and output each) in one grid, e.g.
+// the three hidden-state gradients BPTT carries to step t-1 (each alone covers 150 of the 256 CUs and pays its own
+// ramp); a single product is a group of one.  Workgroup w belongs to the product p with first[p] <= w < first[p+1];
+// inside it the usual (tile, split) decomposition applies.
+constexpr int SSC_GROUP_MAX = 3;
+struct KGroup {
+  KArgs a[SSC_GROUP_MAX];
+  int n;
+  int first[SSC_GROUP_MAX + 1];
+  int gx[SSC_GROUP_MAX], gy[SSC_GROUP_MAX], gz[SSC_GROUP_MAX];
+};
+template <bool A_KC, bool B_KC, bool KG, int TM, int TN, int PF>
+__global__ __launch_bounds__(512) void gemm_x3w_kernel(const KGroup g) {
+  const int w = blockIdx.x;
+  int p = 0;
+#pragma unroll
+  for (int i = 1; i < SSC_GROUP_MAX; ++i)
+    if (i < g.n && w >= g.first[i]) p = i;   // workgroup-uniform
+  const int local = w - g.first[p];
+  const int gx = g.gx[p], gy = g.gy[p], gz = g.gz[p];
+  const int x = local % gx, yz = local / gx;
+  x3w_body<A_KC, B_KC, KG, TM, TN, PF>(g.a[p], x, yz % gy, yz / gy, gx, gy, gz);
+}
+
 __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int nslab, size_t slab_stride, int M, int N,
                                     float* __restrict__ C, int ldc, const float* __restrict__ bias, int accumulate,
                                     const int* __restrict__ mcount, const int* __restrict__ crows) {
@@ -1530,16 +1555,28 @@ inline bool big_tile(int M, int N) { return M >= 512 && N >= 512; }
 int g_wide_min_n = 1024;
 inline bool wide_tile(int M, int N) { return M <= 64 && N >= g_wide_min_n; }
 
+typedef void (*group_fn)(const KGroup);
+// a single product as a group of one
+inline void group_of_one(KGroup& g, const KArgs& k, dim3 grid) {
+  g.a[0] = k;
+  g.n = 1;
+  g.first[0] = 0;
+  for (int i = 0; i < SSC_GROUP_MAX; ++i) {
+    g.first[i + 1] = (int)(grid.x * grid.y * grid.z);
+    g.gx[i] = (int)grid.x; g.gy[i] = (int)grid.y; g.gz[i] = (int)grid.z;
+  }
+}
+
 // the wave-specialised kernels need more than the default 64 KB of LDS per workgroup: raise the limit once
 int x3w_prepare() {
   static bool done = false;
   if (done) return SSC_OK;
-  gemm_fn big[4] = {gemm_x3w_kernel<true, true, false, 128, 128, 2>, gemm_x3w_kernel<true, false, false, 128, 128, 2>,
-                    gemm_x3w_kernel<false, false, true, 128, 128, 1>, gemm_x3w_kernel<false, false, false, 128, 128, 2>};
-  for (gemm_fn f : big)
+  group_fn big[4] = {gemm_x3w_kernel<true, true, false, 128, 128, 2>, gemm_x3w_kernel<true, false, false, 128, 128, 2>,
+                     gemm_x3w_kernel<false, false, true, 128, 128, 1>, gemm_x3w_kernel<false, false, false, 128, 128, 2>};
+  for (group_fn f : big)
     if (hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, x3w_lds_bytes<128, 128>()) != hipSuccess) return SSC_EHIP;
-  gemm_fn skinny[2] = {gemm_x3w_kernel<true, true, false, 64, 256, 2>, gemm_x3w_kernel<true, false, false, 64, 256, 2>};
-  for (gemm_fn f : skinny)
+  group_fn skinny[2] = {gemm_x3w_kernel<true, true, false, 64, 256, 2>, gemm_x3w_kernel<true, false, false, 64, 256, 2>};
+  for (group_fn f : skinny)
     if (hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, x3w_lds_bytes<64, 256>()) != hipSuccess) return SSC_EHIP;
   done = true;
   return SSC_OK;
@@ -1577,8 +1614,10 @@ int launch(const ssc_gemm_desc* d, KArgs& k, int splits, hipStream_t st) {
       (void)hipEventRecord(rec->e0, st);
     }
     SSC_TRY(x3w_prepare());
-    if (d->b_kc) hipLaunchKernelGGL((gemm_x3w_kernel<true, true, false, 64, 256, 2>), grid, dim3(512), (x3w_lds_bytes<64, 256>()), st, k);
-    else hipLaunchKernelGGL((gemm_x3w_kernel<true, false, false, 64, 256, 2>), grid, dim3(512), (x3w_lds_bytes<64, 256>()), st, k);
+    KGroup g1;
+    group_of_one(g1, k, grid);
+    if (d->b_kc) hipLaunchKernelGGL((gemm_x3w_kernel<true, true, false, 64, 256, 2>), dim3(g1.first[1]), dim3(512), (x3w_lds_bytes<64, 256>()), st, g1);
+    else hipLaunchKernelGGL((gemm_x3w_kernel<true, false, false, 64, 256, 2>), dim3(g1.first[1]), dim3(512), (x3w_lds_bytes<64, 256>()), st, g1);
     if (rec) (void)hipEventRecord(rec->e1, st);
     SSC_CHECK_LAUNCH();
     return SSC_OK;
@@ -1599,12 +1638,14 @@ int launch(const ssc_gemm_desc* d, KArgs& k, int splits, hipStream_t st) {
     // 1520 tiles, +10 % tokens/s).  g_x3b: 1 = choose by grid size, 2 = always wave-specialised, 3 = always 4-wave.
     const long wgs = (long)grid.x * grid.y * grid.z;
     if (g_x3b == 2 || (g_x3b == 1 && wgs >= 768)) {  // wave-specialised form: 8 waves, 120 KB of dynamic LDS
-      gemm_fn fn = (d->a_kc && d->b_kc) ? gemm_x3w_kernel<true, true, false, 128, 128, 2>
-                   : d->a_kc            ? gemm_x3w_kernel<true, false, false, 128, 128, 2>
-                   : kg                 ? gemm_x3w_kernel<false, false, true, 128, 128, 1>
-                                        : gemm_x3w_kernel<false, false, false, 128, 128, 2>;
+      group_fn fn = (d->a_kc && d->b_kc) ? gemm_x3w_kernel<true, true, false, 128, 128, 2>
+                    : d->a_kc            ? gemm_x3w_kernel<true, false, false, 128, 128, 2>
+                    : kg                 ? gemm_x3w_kernel<false, false, true, 128, 128, 1>
+                                         : gemm_x3w_kernel<false, false, false, 128, 128, 2>;
       SSC_TRY(x3w_prepare());
-      hipLaunchKernelGGL(fn, grid, dim3(512), (x3w_lds_bytes<128, 128>()), st, k);
+      KGroup g1;
+      group_of_one(g1, k, grid);
+      hipLaunchKernelGGL(fn, dim3(g1.first[1]), dim3(512), (x3w_lds_bytes<128, 128>()), st, g1);
     } else
     if (d->a_kc && d->b_kc) hipLaunchKernelGGL((gemm_x3b_kernel<true, true, false>), grid, dim3(256), 0, st, k);
     else if (d->a_kc) hipLaunchKernelGGL((gemm_x3b_kernel<true, false, false>), grid, dim3(256), 0, st, k);
@@ -1744,6 +1785,76 @@ int ssc_gemm_slabs_auto(const ssc_gemm_desc* d, float* slabs, size_t cap_floats,
     total += splits;
   }
   *nslab = total;
+  return SSC_OK;
+}
+
+int ssc_gemm_slabs_group(const ssc_gemm_desc* const* d, int n, float* const* regions, const size_t* caps, int* nslab,
+                         hipStream_t st) {
+  if (!d || n < 1 || n > SSC_GROUP_MAX || !regions || !caps || !nslab) return SSC_EINVAL;
+  static const bool group_on = !(getenv("SSC_GEMM_GROUP") && atoi(getenv("SSC_GEMM_GROUP")) == 0);   // A/B switch (tools)
+  KGroup g;
+  bool ok = n >= 2 && group_on;
+  long work = 0;
+  for (int i = 0; i < n && ok; ++i) {
+    SSC_TRY(build_args(d[i], g.a[i]));
+    KArgs& k = g.a[i];
+    bool vec = true;
+    for (int s = 0; s < k.nseg; ++s) vec = vec && k.seg[s].avec && k.seg[s].bvec;
+    const bool compact = k.mcount || k.arows || k.crows || k.kcount || k.karows || k.kbrows;
+    ok = !compact && x3w_skinny(d[i], vec) && d[i]->b_kc == d[0]->b_kc && regions[i];
+    work += (long)ssc_cdiv(d[i]->N, 256) * k.steps_total;
+  }
+  if (!ok) {
+    for (int i = 0; i < n; ++i) SSC_TRY(ssc_gemm_slabs_auto(d[i], regions[i], caps[i], &nslab[i], st));
+    return SSC_OK;
+  }
+  // one workgroup per CU in total: every product gets splits in proportion to its k-steps, at least 4 k-steps per workgroup
+  int per = (int)((work + 255) / 256);
+  if (per < 4) per = 4;
+  g.n = n;
+  g.first[0] = 0;
+  int Ksum = 0, Nmax = 0;
+  for (int i = 0; i < n; ++i) {
+    KArgs& k = g.a[i];
+    const size_t mn = (size_t)d[i]->M * d[i]->N;
+    int splits = ssc_cdiv(k.steps_total, per);
+    const int cap = (int)(caps[i] / mn);
+    if (cap < 1) return SSC_EWORKSPACE;
+    if (splits > cap) splits = cap;
+    const int p2 = ssc_cdiv(k.steps_total, splits);
+    splits = ssc_cdiv(k.steps_total, p2);
+    k.steps_per_split = p2;
+    k.out = regions[i];
+    k.ldo = d[i]->N;
+    k.slab_stride = mn;
+    k.bias = nullptr;
+    k.accumulate = 0;
+    k.crows = nullptr;
+    {
+      static const int dbg = getenv("SSC_GEMM_DBG") ? atoi(getenv("SSC_GEMM_DBG")) : 0;
+      k.dbg = dbg;
+    }
+    g.gx[i] = ssc_cdiv(d[i]->N, 256);
+    g.gy[i] = 1;
+    g.gz[i] = splits;
+    g.first[i + 1] = g.first[i] + g.gx[i] * splits;
+    nslab[i] = splits;
+    for (int s = 0; s < d[i]->nseg; ++s) Ksum += d[i]->seg[s].K;
+    if (d[i]->N > Nmax) Nmax = d[i]->N;
+  }
+  for (int i = n; i < SSC_GROUP_MAX; ++i) { g.first[i + 1] = g.first[n]; g.gx[i] = 1; g.gy[i] = 1; g.gz[i] = 1; }
+  SSC_TRY(x3w_prepare());
+  ProfRec* rec = nullptr;
+  if (g_prof_on && g_prof && g_prof_n < PROF_MAX) {  // one record for the group: the weight bytes add up exactly (same N)
+    rec = &g_prof[g_prof_n++];
+    rec->kind = d[0]->b_kc ? 0 : 1;
+    rec->M = d[0]->M; rec->N = Nmax; rec->splits = nslab[0]; rec->K = Ksum;
+    (void)hipEventRecord(rec->e0, st);
+  }
+  if (d[0]->b_kc) hipLaunchKernelGGL((gemm_x3w_kernel<true, true, false, 64, 256, 2>), dim3(g.first[n]), dim3(512), (x3w_lds_bytes<64, 256>()), st, g);
+  else hipLaunchKernelGGL((gemm_x3w_kernel<true, false, false, 64, 256, 2>), dim3(g.first[n]), dim3(512), (x3w_lds_bytes<64, 256>()), st, g);
+  if (rec) (void)hipEventRecord(rec->e1, st);
+  SSC_CHECK_LAUNCH();
   return SSC_OK;
 }
 

@@ -566,11 +566,17 @@ static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const s
     // 10. gradients carried to step t-1 (left as slabs for their consumers)
     if (t > 0) {
       const float* wr = p->att_w_ih + E + F;
-      SSC_TRY(gemm_to_slabs(c, W + l.sl_gh1, l.small_floats, true, false, {{dga, H4, W + l.wsum_att, l.Hp, H4}}, B, H, &n_gh1));
-      SSC_TRY(gemm_to_slabs(c, W + l.sl_ghd, l.small_floats, true, false,
-                            {{dga, H4, wr + H, p->ld_att_w_ih, H4}, {dgd, H4, p->dec_w_hh, p->ld_dec_w_hh, H4}}, B, H, &n_ghd));
-      SSC_TRY(gemm_to_slabs(c, W + l.sl_ghe, l.small_floats, true, false, {{dge, H4, p->enc_w_hh, p->ld_enc_w_hh, H4}}, B, H,
-                            &n_ghe));
+      // three independent products: one grouped launch (each alone covers 150 of the 256 CUs and pays its own ramp)
+      ssc_gemm_desc d3[3];
+      fill_desc(d3[0], true, false, {{dga, H4, W + l.wsum_att, l.Hp, H4}}, B, H);
+      fill_desc(d3[1], true, false, {{dga, H4, wr + H, p->ld_att_w_ih, H4}, {dgd, H4, p->dec_w_hh, p->ld_dec_w_hh, H4}}, B, H);
+      fill_desc(d3[2], true, false, {{dge, H4, p->enc_w_hh, p->ld_enc_w_hh, H4}}, B, H);
+      const ssc_gemm_desc* dp[3] = {&d3[0], &d3[1], &d3[2]};
+      float* regions[3] = {W + l.sl_gh1, W + l.sl_ghd, W + l.sl_ghe};
+      const size_t caps[3] = {l.small_floats, l.small_floats, l.small_floats};
+      int ns3[3] = {0, 0, 0};
+      SSC_TRY(ssc_gemm_slabs_group(dp, 3, regions, caps, ns3, st));
+      n_gh1 = ns3[0]; n_ghd = ns3[1]; n_ghe = ns3[2];
     }
   }
 
