@@ -1789,7 +1789,7 @@ int ssc_gemm_slabs_auto(const ssc_gemm_desc* d, float* slabs, size_t cap_floats,
 }
 
 int ssc_gemm_slabs_group(const ssc_gemm_desc* const* d, int n, float* const* regions, const size_t* caps, int* nslab,
-                         hipStream_t st, int* grouped) {
+                         hipStream_t st) {
   if (!d || n < 1 || n > SSC_GROUP_MAX || !regions || !caps || !nslab) return SSC_EINVAL;
   static const bool group_on = !(getenv("SSC_GEMM_GROUP") && atoi(getenv("SSC_GEMM_GROUP")) == 0);   // A/B switch (tools)
   KGroup g;
@@ -1805,19 +1805,12 @@ int ssc_gemm_slabs_group(const ssc_gemm_desc* const* d, int n, float* const* reg
     work += (long)ssc_cdiv(d[i]->N, 256) * k.steps_total;
   }
   if (!ok) {
-    if (grouped) { *grouped = 0; return SSC_OK; }   // the caller has its own ungrouped schedule
     for (int i = 0; i < n; ++i) SSC_TRY(ssc_gemm_slabs_auto(d[i], regions[i], caps[i], &nslab[i], st));
     return SSC_OK;
   }
-  if (grouped) *grouped = 1;
   // one workgroup per CU in total: every product gets splits in proportion to its k-steps, at least 4 k-steps per workgroup
   int per = (int)((work + 255) / 256);
   if (per < 4) per = 4;
-  for (;; ++per) {  // the whole group in one round of 256 workgroups (a few stragglers in a second round double the time)
-    long wgs = 0;
-    for (int i = 0; i < n; ++i) wgs += (long)ssc_cdiv(d[i]->N, 256) * ssc_cdiv(g.a[i].steps_total, per);
-    if (wgs <= 256 || per >= 4096) break;
-  }
   g.n = n;
   g.first[0] = 0;
   int Ksum = 0, Nmax = 0;

@@ -28,7 +28,7 @@ struct Layout {
   size_t act;  // int32: [0] = number of active (t, b) rows, [4 ...] = their row numbers t*B+b in ascending order
   size_t tok, w, nvalid, sent_all, wcol_e, wcol_d, mask, avg, pv, emb, ga_static, ga_avg;
   size_t h1, c1, he, ce, hd, cd, gates_a, gates_e, gates_d, q, attn_logits, alpha, att, mu, lv, z, mulv;
-  size_t slabs, slab_floats, slabs_e, slabs_d, skinny_floats, logits, lse, proj;
+  size_t slabs, slab_floats, logits, lse, proj;
   size_t sl_q, sl_mulv, sl_gh1, sl_ghd, sl_ghe, sl_dqw, sl_dhe, sl_dz, small_floats, wsum_att, wsum_dec, wz;
   // backward
   size_t dhdv, dga, dge, dgd, dga_sum, g_h1, g_c1, g_he, g_ce, g_cd, dz, dmulv, dx, dalpha, dq, dpv, dwa, demb, dproj;
@@ -74,10 +74,6 @@ Layout make_layout(const ssc_model_cfg* c, int B, int R, int L) {
   size_t full = (size_t)16 * 1024 * 1024;  // 64 MB: split-K slabs of the large GEMMs
   l.slab_floats = skinny > full ? skinny : full;
   l.slabs = l.take(l.slab_floats);
-  // encoder / decoder gate slabs of the forward step: their recurrent terms (h_dec', h_enc') are issued at the start of
-  // the step, grouped with the attention-LSTM product, and wait here for the terms that need the attention output
-  l.skinny_floats = skinny;
-  l.slabs_e = l.take(skinny); l.slabs_d = l.take(skinny);
   // per-consumer slab regions of the small per-step GEMMs whose split-K reduction is fused into their consumer
   {
     size_t w = (size_t)(l.Hp > l.Ap ? l.Hp : l.Ap);
@@ -340,7 +336,6 @@ extern "C" int ssc_train_fwd(const ssc_model_cfg* cfg, const ssc_params* p, cons
     float* qt = W + l.q + (size_t)t * B * l.Ap;
     float* zt = W + l.z + (size_t)t * B * l.Zp;
     int ns = 0;
-    int early = 0, ns_e0 = 0, ns_d0 = 0;   // recurrent gate terms already issued (grouped launch) and their slab counts
 
     // (i) attention LSTM: x_a = [emb, avg, h1', hd'] (updown_cell.py:143-148)
     {
@@ -348,20 +343,7 @@ extern "C" int ssc_train_fwd(const ssc_model_cfg* cfg, const ssc_params* p, cons
       d.B = B; d.H = H;
       if (t > 0) {  // all recurrent inputs are zero at t = 0; h1' meets the pre-summed W_ih[:,h1]+W_hh block
         const float* wr = p->att_w_ih + E + F;
-        // The three products that only need last step's states - this one and the recurrent terms of the encoder and
-        // decoder gates - go out as ONE grouped launch; the encoder / decoder products later in the step then stream
-        // only the weight columns of the attention output and the new h1.
-        ssc_gemm_desc d3[3];
-        fill_desc(d3[0], true, true, {{h1p, l.Hp, W + l.wsum_att, l.Hp, H}, {hdp, l.Hp, wr + H, p->ld_att_w_ih, H}}, B, H4);
-        fill_desc(d3[1], true, true, {{hdp, l.Hp, p->enc_w_ih + F + H, p->ld_enc_w_ih, H}, {hep, l.Hp, p->enc_w_hh, p->ld_enc_w_hh, H}}, B, H4);
-        fill_desc(d3[2], true, true, {{hdp, l.Hp, W + l.wsum_dec, l.Hp, H}}, B, H4);
-        const ssc_gemm_desc* dp[3] = {&d3[0], &d3[1], &d3[2]};
-        float* regions[3] = {c.slabs, W + l.slabs_e, W + l.slabs_d};
-        const size_t caps[3] = {c.slab_floats, l.skinny_floats / 2, l.skinny_floats / 2};
-        int ns3[3] = {0, 0, 0};
-        SSC_TRY(ssc_gemm_slabs_group(dp, 3, regions, caps, ns3, st, &early));
-        if (early) { ns = ns3[0]; ns_e0 = ns3[1]; ns_d0 = ns3[2]; }
-        else SSC_TRY(gemm_to_slabs(c, {{h1p, l.Hp, W + l.wsum_att, l.Hp, H}, {hdp, l.Hp, wr + H, p->ld_att_w_ih, H}}, B, H4, &ns));
+        SSC_TRY(gemm_to_slabs(c, {{h1p, l.Hp, W + l.wsum_att, l.Hp, H}, {hdp, l.Hp, wr + H, p->ld_att_w_ih, H}}, B, H4, &ns));
         d.slabs = c.slabs; d.nslab = ns; d.slab_stride = (size_t)B * H4;
       }
       d.add0 = W + l.ga_static + (size_t)t * B * H4; d.ld_add0 = H4;
@@ -379,20 +361,12 @@ extern "C" int ssc_train_fwd(const ssc_model_cfg* cfg, const ssc_params* p, cons
                                 W + l.attn_logits, W + l.alpha + (size_t)t * B * R, att, l.Fp, st));
     // (iv) encoder LSTM: x_e = [att, h1, hd', (s)] (updown_cell.py:176-194)
     {
+      SSC_TRY(gemm_to_slabs(c, {{att, l.Fp, p->enc_w_ih, p->ld_enc_w_ih, F}, {h1n, l.Hp, p->enc_w_ih + F, p->ld_enc_w_ih, H},
+                                {hdp, l.Hp, p->enc_w_ih + F + H, p->ld_enc_w_ih, t > 0 ? H : 0},
+                                {hep, l.Hp, p->enc_w_hh, p->ld_enc_w_hh, t > 0 ? H : 0}}, B, H4, &ns));
       ssc_lstm_fwd_desc d{};
       d.B = B; d.H = H;
-      if (early) {  // the h_dec' / h_enc' terms wait in slabs_e: append the terms of the attention output and the new h1
-        const size_t mn = (size_t)B * H4;
-        SSC_TRY(gemm_to_slabs(c, W + l.slabs_e + ns_e0 * mn, l.skinny_floats - ns_e0 * mn, true, true,
-                              {{att, l.Fp, p->enc_w_ih, p->ld_enc_w_ih, F}, {h1n, l.Hp, p->enc_w_ih + F, p->ld_enc_w_ih, H}}, B, H4, &ns));
-        d.slabs = W + l.slabs_e; d.nslab = ns_e0 + ns;
-      } else {
-        SSC_TRY(gemm_to_slabs(c, {{att, l.Fp, p->enc_w_ih, p->ld_enc_w_ih, F}, {h1n, l.Hp, p->enc_w_ih + F, p->ld_enc_w_ih, H},
-                                  {hdp, l.Hp, p->enc_w_ih + F + H, p->ld_enc_w_ih, t > 0 ? H : 0},
-                                  {hep, l.Hp, p->enc_w_hh, p->ld_enc_w_hh, t > 0 ? H : 0}}, B, H4, &ns));
-        d.slabs = c.slabs; d.nslab = ns;
-      }
-      d.slab_stride = (size_t)B * H4;
+      d.slabs = c.slabs; d.nslab = ns; d.slab_stride = (size_t)B * H4;
       d.b_ih = p->enc_b_ih; d.b_hh = p->enc_b_hh;
       if (S) { d.sent = bt->sentiment; d.wcol = W + l.wcol_e; d.ldwcol = 1; }
       d.c_prev = cep; d.ld_cprev = l.Hp;
@@ -426,20 +400,11 @@ extern "C" int ssc_train_fwd(const ssc_model_cfg* cfg, const ssc_params* p, cons
     // (vi) decoder LSTM: x_d = [att, h1, hd', (s), z] (updown_cell.py:211-229)
     {
       // hd' meets the pre-summed W_ih[:,hd]+W_hh block; z meets the aligned copy of its weight block
+      SSC_TRY(gemm_to_slabs(c, {{att, l.Fp, p->dec_w_ih, p->ld_dec_w_ih, F}, {h1n, l.Hp, p->dec_w_ih + F, p->ld_dec_w_ih, H},
+                                {hdp, l.Hp, W + l.wsum_dec, l.Hp, t > 0 ? H : 0}, {zt, l.Zp, W + l.wz, l.Zp, Z}}, B, H4, &ns));
       ssc_lstm_fwd_desc d{};
       d.B = B; d.H = H;
-      if (early) {
-        const size_t mn = (size_t)B * H4;
-        SSC_TRY(gemm_to_slabs(c, W + l.slabs_d + ns_d0 * mn, l.skinny_floats - ns_d0 * mn, true, true,
-                              {{att, l.Fp, p->dec_w_ih, p->ld_dec_w_ih, F}, {h1n, l.Hp, p->dec_w_ih + F, p->ld_dec_w_ih, H},
-                               {zt, l.Zp, W + l.wz, l.Zp, Z}}, B, H4, &ns));
-        d.slabs = W + l.slabs_d; d.nslab = ns_d0 + ns;
-      } else {
-        SSC_TRY(gemm_to_slabs(c, {{att, l.Fp, p->dec_w_ih, p->ld_dec_w_ih, F}, {h1n, l.Hp, p->dec_w_ih + F, p->ld_dec_w_ih, H},
-                                  {hdp, l.Hp, W + l.wsum_dec, l.Hp, t > 0 ? H : 0}, {zt, l.Zp, W + l.wz, l.Zp, Z}}, B, H4, &ns));
-        d.slabs = c.slabs; d.nslab = ns;
-      }
-      d.slab_stride = (size_t)B * H4;
+      d.slabs = c.slabs; d.nslab = ns; d.slab_stride = (size_t)B * H4;
       d.b_ih = p->dec_b_ih; d.b_hh = p->dec_b_hh;
       if (S) { d.sent = bt->sentiment; d.wcol = W + l.wcol_d; d.ldwcol = 1; }
       d.c_prev = cdp; d.ld_cprev = l.Hp;

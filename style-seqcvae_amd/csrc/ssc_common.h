@@ -49,7 +49,6 @@ int ssc_attn_fwd_qslabs(const float* qslabs, int nslab, size_t slab_stride, floa
                         int rows_per_image, float* logits, float* alpha, float* att, int ldatt, hipStream_t st);
 int ssc_gemm_slabs_auto(const ssc_gemm_desc* d, float* slabs, size_t cap_floats, int* nslab, hipStream_t st);
 // n <= 3 independent minibatch products (M <= 64, same operand layout) in ONE launch, each left as split-K slabs in its
-// own region.  When they do not qualify for the 64x256 wave-specialised kernel: with `grouped` == NULL one launch per
-// product, otherwise nothing is launched and *grouped = 0 (the caller keeps its ungrouped schedule).
+// own region; falls back to one launch per product when they do not qualify for the 64x256 wave-specialised kernel
 int ssc_gemm_slabs_group(const ssc_gemm_desc* const* d, int n, float* const* regions, const size_t* caps, int* nslab,
-                         hipStream_t st, int* grouped = nullptr);
+                         hipStream_t st);
