@@ -1811,6 +1811,11 @@ int ssc_gemm_slabs_group(const ssc_gemm_desc* const* d, int n, float* const* reg
   // one workgroup per CU in total: every product gets splits in proportion to its k-steps, at least 4 k-steps per workgroup
   int per = (int)((work + 255) / 256);
   if (per < 4) per = 4;
+  for (;; ++per) {  // the whole group in one round of 256 workgroups (a few stragglers in a second round double the time)
+    long wgs = 0;
+    for (int i = 0; i < n; ++i) wgs += (long)ssc_cdiv(d[i]->N, 256) * ssc_cdiv(g.a[i].steps_total, per);
+    if (wgs <= 256 || per >= 4096) break;
+  }
   g.n = n;
   g.first[0] = 0;
   int Ksum = 0, Nmax = 0;
