@@ -113,3 +113,85 @@ def test_stress_shape_c5_like_regions_and_length():
     got = eng.grad_dict()
     for k, v in p.items():
         assert maxdiff(got[k], v.grad) < TOL, k
+
+
+# ---- BASELINE configs[1] (C2) at FULL size: properties that need no CPU oracle run ------------------------------------
+def _c2_engine_and_batch(seed=1234):
+    from ssc_runtime.vocab import Vocabulary
+    from var_updown.models import UpDownCaptioner
+    V, F, E, H, A, Z, L, B, R = 10000, 2048, 1000, 1200, 768, 128, 20, 64, 36
+    torch.manual_seed(2)
+    model = UpDownCaptioner(Vocabulary.synthetic(V), image_feature_size=F, embedding_size=E, hidden_size=H,
+                            attention_projection_size=A, max_caption_length=L, beam_size=5, z_space=Z, prior_std=1.0,
+                            simple_vae=False, latent_embedding="glove", sentiment_vae=1, senti_prior_multip=0.5,
+                            device=torch.device("cuda")).to("cuda")
+    eng = model._engine()
+    g = torch.Generator().manual_seed(seed)
+    feats = torch.randn(B, R, F, generator=g)
+    lens = torch.randint(8, L + 1, (B,), generator=g)
+    caps = torch.zeros(B, L, dtype=torch.long)
+    ids = torch.randint(2, V, (B, L), generator=g)
+    for b in range(B):
+        caps[b, : lens[b]] = ids[b, : lens[b]]
+    senti = torch.randint(-1, 2, (B, 1), generator=g).float()
+    eps = torch.randn(L + 1, B, Z, generator=g)
+    return eng, (feats.cuda(), caps.cuda(), senti.cuda(), eps.cuda()), lens
+
+
+def _step(eng, batch):
+    B = batch[0].shape[0]
+    loss, kld = eng.forward(*batch)
+    eng.backward(torch.full((B,), 1.0 / B, device="cuda"), torch.full((B,), 1.0 / (B * 750.0), device="cuda"))
+    return loss.clone(), kld.clone(), {k: v.clone() for k, v in eng.grad_dict().items()}
+
+
+def test_full_size_c2_two_independent_kernel_paths_agree():
+    """C2 at full size (B=64, 36x2048 regions, T=21, V=10k, E/H/A=1000/1200/768).  The default path (3xBF16 kernels, padded
+    rows skipped on the device, grouped launches) against the exact-fp32-MFMA mode, which shares none of those kernels and
+    computes every padded row: losses and every gradient agree to fp32 level; and the default path is deterministic."""
+    from ssc_runtime import lib as L
+    eng, batch, _ = _c2_engine_and_batch()
+    lib = L.load()
+    l1, k1, g1 = _step(eng, batch)
+    l1b, k1b, g1b = _step(eng, batch)
+    assert torch.equal(l1, l1b) and torch.equal(k1, k1b)
+    for k in g1:   # fixed summation orders everywhere: bit-identical reruns - except the embedding gradient, whose rows are
+        if k == "_embedding_layer.weight":        # scatter-added with float atomics (the path's only atomics)
+            assert maxdiff(g1[k], g1b[k]) <= 1e-6 * max(g1[k].abs().max().item(), 1e-6), k
+        else:
+            assert torch.equal(g1[k], g1b[k]), k
+    lib.ssc_set_gemm_mode(0)
+    try:
+        l0, k0, g0 = _step(eng, batch)
+    finally:
+        lib.ssc_set_gemm_mode(1)
+    assert maxdiff(l1, l0) < 2e-3 and maxdiff(k1, k0) < 2e-3          # loss ~ O(150)
+    for k in g1:
+        scale = max(g0[k].abs().max().item(), 1e-6)
+        assert maxdiff(g1[k], g0[k]) <= 2e-4 * scale + 1e-7, (k, maxdiff(g1[k], g0[k]), scale)
+
+
+def test_full_size_c2_batch_permutation_and_padding_invariance():
+    """Permuting the minibatch permutes loss / kld and leaves the weight gradients unchanged (to summation order); token
+    ids written behind a caption's padding boundary are never read."""
+    eng, batch, lens = _c2_engine_and_batch(seed=77)
+    feats, caps, senti, eps = batch
+    l1, k1, g1 = _step(eng, batch)
+    perm = torch.randperm(feats.shape[0], generator=torch.Generator().manual_seed(5)).cuda()
+    l2, k2, g2 = _step(eng, (feats[perm].contiguous(), caps[perm].contiguous(), senti[perm].contiguous(), eps[:, perm].contiguous()))
+    assert maxdiff(l2, l1[perm]) < 1e-3 and maxdiff(k2, k1[perm]) < 1e-3
+    for k in g1:
+        scale = max(g1[k].abs().max().item(), 1e-6)
+        assert maxdiff(g1[k], g2[k]) <= 2e-4 * scale + 1e-7, k
+    # eps rows of padded steps: change the noise wherever the step is padding -> nothing may change
+    eps2 = eps.clone()
+    T = eps.shape[0]
+    for b in range(feats.shape[0]):
+        eps2[int(lens[b]) + 1:, b] = 7.0
+    l3, k3, g3 = _step(eng, (feats, caps, senti, eps2))
+    assert torch.equal(l3, l1) and torch.equal(k3, k1)
+    for k in g1:
+        if k == "_embedding_layer.weight":
+            assert maxdiff(g1[k], g3[k]) <= 1e-6 * max(g1[k].abs().max().item(), 1e-6), k
+        else:
+            assert torch.equal(g1[k], g3[k]), k
