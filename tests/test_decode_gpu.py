@@ -105,3 +105,49 @@ def test_batched_diverse_decode_matches_oracle_per_sample():
     got, calls = diverse_decode(m._dec, dev(feats), dev(senti), ns, beam, cfg.max_caption_length, 1,
                                 eps_steps=[e.clone() for e in eps])
     assert torch.equal(got.cpu().view(B, -1), want["predictions"])
+
+
+def test_full_size_c4_decode_steps_two_kernel_paths_agree():
+    """BASELINE configs[3] (C4) row counts at full width: two consecutive decode steps for 50 images x 20 latent samples x
+    5 beams = 5000 rows (V=10k, H=1200, 36x2048 regions) on the default kernels (3xBF16, wave-specialised at this grid
+    size) and in the exact-fp32-MFMA mode: log-probs, states and attention weights agree to fp32 level; log-probs are
+    normalised; reruns are bit-identical."""
+    from ssc_runtime import lib as L
+    from ssc_runtime.vocab import Vocabulary
+    from var_updown.models import UpDownCaptioner
+    V, F, E, H, A, Z, R = 10000, 2048, 1000, 1200, 768, 128, 36
+    torch.manual_seed(2)
+    m = UpDownCaptioner(Vocabulary.synthetic(V), image_feature_size=F, embedding_size=E, hidden_size=H,
+                        attention_projection_size=A, max_caption_length=20, beam_size=5, z_space=Z, prior_std=1.0,
+                        simple_vae=False, latent_embedding="glove", sentiment_vae=1, senti_prior_multip=0.5,
+                        device=torch.device("cuda")).to("cuda")
+    m.eval()
+    m._engine()
+    dec = m._dec
+    g = torch.Generator().manual_seed(3)
+    nimg, G = 50, 5000
+    feats = torch.randn(nimg, R, F, generator=g).cuda()
+    ctx = dec.prepare(feats)
+    tok = torch.randint(2, V, (G,), generator=g).cuda()
+    tok2 = torch.randint(2, V, (G,), generator=g).cuda()
+    sent = torch.ones(G).cuda()
+    eps1, eps2 = torch.randn(G, Z, generator=g).cuda(), torch.randn(G, Z, generator=g).cuda()
+
+    def two_steps():
+        lp1, st1, a1 = dec.step(ctx, tok, None, sent, eps1)
+        lp2, st2, a2 = dec.step(ctx, tok2, st1, sent, eps2)
+        return lp1.clone(), lp2.clone(), {k: v.clone() for k, v in st2.items()}, a2.clone()
+
+    lib = L.load()
+    x = two_steps()
+    y = two_steps()
+    assert torch.equal(x[0], y[0]) and torch.equal(x[1], y[1]) and torch.equal(x[3], y[3])
+    lib.ssc_set_gemm_mode(0)
+    try:
+        z = two_steps()
+    finally:
+        lib.ssc_set_gemm_mode(1)
+    assert maxdiff(x[0], z[0]) < 1e-4 and maxdiff(x[1], z[1]) < 1e-4 and maxdiff(x[3], z[3]) < 1e-5
+    for k in x[2]:
+        assert maxdiff(x[2][k], z[2][k]) < 1e-4, k
+    assert maxdiff(torch.logsumexp(x[1], 1), torch.zeros(G)) < 1e-4
