@@ -18,8 +18,8 @@ inline size_t r4(size_t x) { return (x + 3) & ~(size_t)3; }
 inline size_t r64(size_t x) { return (x + 63) & ~(size_t)63; }
 
 struct ImgLayout {
-  size_t mask, avg, pv, ga_avg, scratch, scratch_floats, total;
-  int Fp;
+  size_t mask, avg, pv, ga_avg, wsum_att, wsum_dec, wz, scratch, scratch_floats, total;
+  int Fp, Hp, Zp;
 };
 ImgLayout img_layout(const ssc_model_cfg* c, int nimg, int R) {
   ImgLayout l;
@@ -29,6 +29,13 @@ ImgLayout img_layout(const ssc_model_cfg* c, int nimg, int R) {
   l.avg = o; o += r64((size_t)nimg * l.Fp);
   l.pv = o; o += r64((size_t)nimg * R * c->A);
   l.ga_avg = o; o += r64((size_t)nimg * 4 * c->H);
+  // weight views that stay fixed for the whole decode (prepared with the image context): the pre-summed recurrent blocks
+  // W_ih[:, h-block] + W_hh of the attention / decoder LSTM (both multiply the same state) and a 16-B aligned copy of the
+  // z-block of W_ih^dec (it starts at an odd column when the sentiment column is present)
+  l.Hp = (int)r4(c->H); l.Zp = (int)r4(c->Z);
+  l.wsum_att = o; o += r64((size_t)4 * c->H * l.Hp);
+  l.wsum_dec = o; o += r64((size_t)4 * c->H * l.Hp);
+  l.wz = o; o += r64((size_t)4 * c->H * l.Zp);
   size_t a = (size_t)nimg * R * c->A, b = (size_t)nimg * 4 * c->H;
   l.scratch_floats = 33 * (a > b ? a : b);
   l.scratch = o; o += r64(l.scratch_floats);
@@ -240,6 +247,12 @@ __global__ void gather_rows_kernel(const float* __restrict__ src, int ld, const 
   dst[(size_t)row * ld + x] = src[srow * ld + x];
 }
 
+__global__ void dec_add2d_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb, int cols,
+                                 float* __restrict__ o, int ldo) {
+  int r = blockIdx.y, x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x < cols) o[(size_t)r * ldo + x] = a[(size_t)r * lda + x] + b[(size_t)r * ldb + x];
+}
+
 }  // namespace
 
 extern "C" size_t ssc_decode_image_bytes(const ssc_model_cfg* cfg, int nimg, int R) {
@@ -259,6 +272,19 @@ extern "C" int ssc_decode_prepare(const ssc_model_cfg* cfg, const ssc_params* p,
   SSC_TRY(gemm_nt(st, W + l.scratch, l.scratch_floats, {{feats, F, p->wv, p->ld_wv, F}}, nimg * R, A, W + l.pv, A));
   SSC_TRY(gemm_nt(st, W + l.scratch, l.scratch_floats, {{W + l.avg, F, p->att_w_ih + E, p->ld_att_w_ih, F}}, nimg, H4,
                   W + l.ga_avg, H4));
+  {
+    const int H = cfg->H, Z = cfg->Z, S = cfg->S;
+    dim3 grid(ssc_cdiv(H, 256), H4);
+    hipLaunchKernelGGL(dec_add2d_kernel, grid, dim3(256), 0, st, p->att_w_ih + E + F, p->ld_att_w_ih, p->att_w_hh, p->ld_att_w_hh, H,
+                       W + l.wsum_att, l.Hp);
+    SSC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(dec_add2d_kernel, grid, dim3(256), 0, st, p->dec_w_ih + F + H, p->ld_dec_w_ih, p->dec_w_hh, p->ld_dec_w_hh, H,
+                       W + l.wsum_dec, l.Hp);
+    SSC_CHECK_LAUNCH();
+    if (hipMemcpy2DAsync(W + l.wz, (size_t)l.Zp * sizeof(float), p->dec_w_ih + F + 2 * H + S, (size_t)p->ld_dec_w_ih * sizeof(float),
+                         (size_t)Z * sizeof(float), H4, hipMemcpyDeviceToDevice, st) != hipSuccess)
+      return SSC_EHIP;
+  }
   return SSC_OK;
 }
 
@@ -292,8 +318,8 @@ extern "C" int ssc_decode_step(const ssc_model_cfg* cfg, const ssc_params* p, co
   {
     const float* wr = p->att_w_ih + E + F;
     SSC_TRY(gemm_slabs(st, slabs, l.slab_floats,
-                       {{W + l.emb, l.Ep, p->att_w_ih, p->ld_att_w_ih, E}, {d->h1, H, wr, p->ld_att_w_ih, H},
-                        {d->hd, H, wr + H, p->ld_att_w_ih, H}, {d->h1, H, p->att_w_hh, p->ld_att_w_hh, H}}, G, H4, &ns));
+                       {{W + l.emb, l.Ep, p->att_w_ih, p->ld_att_w_ih, E}, {d->h1, H, I + il.wsum_att, il.Hp, H},
+                        {d->hd, H, wr + H, p->ld_att_w_ih, H}}, G, H4, &ns));
     ssc_lstm_fwd_desc f{};
     f.B = G; f.H = H;
     f.slabs = slabs; f.nslab = ns; f.slab_stride = (size_t)G * H4;
@@ -312,11 +338,9 @@ extern "C" int ssc_decode_step(const ssc_model_cfg* cfg, const ssc_params* p, co
                                   G, Z, W + l.z, l.Zp, st));
   // decoder LSTM (updown_cell.py:211-229)
   {
-    const float* wz = p->dec_w_ih + F + 2 * H + S;
     SSC_TRY(gemm_slabs(st, slabs, l.slab_floats,
                        {{W + l.att, l.Fp, p->dec_w_ih, p->ld_dec_w_ih, F}, {d->h1_out, H, p->dec_w_ih + F, p->ld_dec_w_ih, H},
-                        {d->hd, H, p->dec_w_ih + F + H, p->ld_dec_w_ih, H}, {W + l.z, l.Zp, wz, p->ld_dec_w_ih, Z},
-                        {d->hd, H, p->dec_w_hh, p->ld_dec_w_hh, H}}, G, H4, &ns));
+                        {d->hd, H, I + il.wsum_dec, il.Hp, H}, {W + l.z, l.Zp, I + il.wz, il.Zp, Z}}, G, H4, &ns));
     ssc_lstm_fwd_desc f{};
     f.B = G; f.H = H;
     f.slabs = slabs; f.nslab = ns; f.slab_stride = (size_t)G * H4;
