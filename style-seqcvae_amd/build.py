@@ -26,6 +26,25 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def check_staged_loads(verbose=True):
+    """Gate: the GEMM kernels' hand-scheduled register prefetch must survive code generation (tools/check_staged_loads.py:
+    no instruction may touch a staged load's destination registers before the hand-counted wait).  Same flags, ISA only."""
+    import tempfile
+    tool = os.path.join(os.path.dirname(HERE), "tools", "check_staged_loads.py")
+    if not os.path.exists(tool):
+        return
+    with tempfile.TemporaryDirectory() as td:
+        isa = os.path.join(td, "gemm.s")
+        cmd = [_hipcc()] + [f for f in FLAGS if f != "-fPIC"] + ["-S", "--cuda-device-only", os.path.join(CSRC, "gemm.hip"), "-o", isa]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
+        rc = subprocess.call([sys.executable, tool, isa])
+        if rc != 0:
+            raise RuntimeError("gemm.hip: a staged-load destination register is touched before its wait in the generated ISA "
+                               "(see the findings above); the library is NOT built")
+
+
 def build(force=False, verbose=True):
     if not force and not needs_build():
         return LIB
@@ -44,6 +63,7 @@ def build(force=False, verbose=True):
     for p, s in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {s}")
+    check_staged_loads(verbose)
     cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd), flush=True)

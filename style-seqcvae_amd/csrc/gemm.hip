@@ -58,7 +58,8 @@ struct KArgs {
             // the loop, 2 = no LDS stores, 4 = no barriers
 };
 
-__device__ long long g_clk[8];  // SSC_GEMM_DBG=64 clock probe: {shader cycles, 100 MHz ticks, k-steps} of one workgroup's main loop
+__device__ long long g_clk[8];
+__device__ int g_oob[8];  // SSC_GEMM_DBG=128 pointer audit of gemm_x3w_kernel: {violations, first: blk_x, blk_y, step, chunk, tid, offset/4, k0}  // SSC_GEMM_DBG=64 clock probe: {shader cycles, 100 MHz ticks, k-steps} of one workgroup's main loop
 
 // ---- global -> register staging of one ROWS x 32 operand tile (ROWS/8 floats per thread) --------------
 // Loads are UNCONDITIONAL: out-of-range rows / k are clamped to a valid address and (for k) zeroed with a select
@@ -1191,6 +1192,25 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
       const bool full = cur.k0 + BK <= cur.K;
       if (full) {
         ma = mb = 0xffu;
+        if (a.dbg & 128) {  // diagnostic: the stepped pointers must lie inside their operands (ssc_debug_gemm_oob)
+          const size_t ea = (size_t)(A_KC ? a.M : a.seg[cur.seg].K) * cur.lda, eb = (size_t)(B_KC ? a.N : a.seg[cur.seg].K) * cur.ldb;
+#pragma unroll
+          for (int u = 0; u < NA; ++u) {
+            const ptrdiff_t off = pa[u] - cur.A;
+            if (!a.arows && (off < 0 || (size_t)off + 4 > ea)) {
+              if (atomicAdd(&g_oob[0], 1) == 0) { g_oob[1] = blk_x; g_oob[2] = blk_y; g_oob[3] = s_ld; g_oob[4] = u; g_oob[5] = tid; g_oob[6] = (int)(off >> 2); g_oob[7] = cur.k0; }
+              pa[u] = cur.A;
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < NB; ++u) {
+            const ptrdiff_t off = pb[u] - cur.B;
+            if (off < 0 || (size_t)off + 4 > eb) {
+              if (atomicAdd(&g_oob[0], 1) == 0) { g_oob[1] = blk_x; g_oob[2] = blk_y; g_oob[3] = s_ld; g_oob[4] = 100 + u; g_oob[5] = tid; g_oob[6] = (int)(off >> 2); g_oob[7] = cur.k0; }
+              pb[u] = cur.B;
+            }
+          }
+        }
 #pragma unroll
         for (int u = 0; u < NA; ++u) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(xa[u]) : "v"(pa[u]) : "memory");
 #pragma unroll
@@ -1542,7 +1562,7 @@ inline int gemm_mode() {
   return g_gemm_mode;
 }
 inline bool use_x3(const ssc_gemm_desc* d, bool vec) { return gemm_mode() == 1 && d->a_kc && d->b_kc && vec; }
-int g_x3b = getenv("SSC_X3B") ? atoi(getenv("SSC_X3B")) : 1;  // large products (M, N >= 512): 0 = 64x64 kernels, 1 = 128x128 3xBF16 kernels, form chosen by grid size, 2 / 3 = always the wave-specialised / the 4-wave form (hooks -8, -14, -10, -9)
+int g_x3b = getenv("SSC_X3B") ? atoi(getenv("SSC_X3B")) : 3;  // large products (M, N >= 512): 0 = 64x64 kernels, 3 (default) = the 4-wave 128x128 3xBF16 kernel, 2 = its wave-specialised form, 1 = chosen by grid size (hooks -8, -9, -10, -14).  The wave-specialised 128x128 form is opt-in: it is ~5-10 % faster on grids several rounds deep (decode), but one long decode run ended in an unexplained GPU memory fault with it
 int g_x3_nbuf = 1;  // single LDS stage: 31 KB per workgroup -> four resident workgroups per CU (rocprof r01: 37 vs 43 us)
 int g_x3_wide = 0;
 int g_x3_pf = 2;  // tuning hook: 1 = 64x128 block tile for skinny (M <= 64, N >= 1024) 3xBF16 products
@@ -1956,11 +1976,20 @@ extern "C" int ssc_set_gemm_wide_min_n(int n) {
   if (n == -8) g_x3b = 0;       // large products back on the 64x64 3xBF16 (NT) / fp32 MFMA (NN, TN) kernels
   if (n == -9) g_x3b = 3;   // (tests: the 4-wave form regardless of the grid)
   if (n == -10) g_x3b = 2;
-  if (n == -14) g_x3b = 1;
+  if (n == -14) g_x3b = 3;   // (tests: back to the default)
+  if (n == -17) g_x3b = 1;
   if (n == -11) g_x3w_skinny = 0;
   if (n == -12) g_x3w_skinny = 1;
   if (n == -13) g_x3w_skinny = 2;      // ... on the wave-specialised (producer / consumer) form of that kernel
   return prev;
+}
+
+// diagnostic: read and clear the SSC_GEMM_DBG=128 pointer-audit record
+extern "C" int ssc_debug_gemm_oob(int* out8) {
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_oob), 8 * sizeof(int)) != hipSuccess) return SSC_EHIP;
+  int z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_oob), z, sizeof(z)) != hipSuccess) return SSC_EHIP;
+  return SSC_OK;
 }
 
 // diagnostic: in-kernel clock probe of gemm_x3w_kernel (SSC_GEMM_DBG=64): {shader cycles, 100 MHz ticks, k-steps}

@@ -60,3 +60,18 @@ def test_missing_extension_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(L, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(ImportError, match="no CPU fallback"):
         L.load()
+
+
+def test_staged_load_hazard_checker_flags_copies_of_inflight_registers(tmp_path):
+    """tools/check_staged_loads.py (the build gate of the GEMM kernels' inline-asm register prefetch): a copy of a
+    load's destination before the wait is reported, the same code with the wait first is clean."""
+    import subprocess
+    import sys
+    tool = os.path.join(ROOT, "tools", "check_staged_loads.py")
+    bad = tmp_path / "bad.s"
+    good = tmp_path / "good.s"
+    body = "_ZN12_GLOBAL__N_111gemm_kernelILb1EEEvNS_5KArgsE:\n\tglobal_load_dwordx4 v[2:5], v[10:11], off\n{A}\tglobal_load_dwordx4 v[6:9], v[12:13], off\n{B}\ts_endpgm\n.end_amdhsa_kernel\n"
+    bad.write_text(body.format(A="\tv_mov_b32_e32 v20, v3\n", B="\ts_waitcnt vmcnt(0)\n"))
+    good.write_text(body.format(A="", B="\ts_waitcnt vmcnt(1)\n\tv_mov_b32_e32 v20, v3\n\ts_waitcnt vmcnt(0)\n\tv_mov_b32_e32 v21, v7\n"))
+    assert subprocess.call([sys.executable, tool, str(bad)], stdout=subprocess.DEVNULL) == 1
+    assert subprocess.call([sys.executable, tool, str(good)], stdout=subprocess.DEVNULL) == 0
