@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libssc_hip.so")
+LIB_PATH = os.environ.get("SSC_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "libssc_hip.so")   # override: A/B of builds (tools)
 SSC_MAX_SEG = 6
 
 c_float_p = C.POINTER(C.c_float)
