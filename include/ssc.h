@@ -346,6 +346,7 @@ typedef struct {
   float* h1_out; float* c1_out; float* hd_out; float* cd_out;
   float* alpha;              /* (G,R) */
   float* log_probs;          /* (G,V) ld V; NULL: stop after the cell (UpDownCell.forward) */
+  int raw_logits;            /* 1: leave the vocabulary logits un-normalised in log_probs (for ssc_beam_*_logits) */
 } ssc_decode_step_desc;
 size_t ssc_decode_step_workspace_bytes(const ssc_model_cfg* cfg, int G, int R);
 int ssc_decode_step(const ssc_model_cfg* cfg, const ssc_params* p, const ssc_decode_step_desc* d, void* workspace,
@@ -365,6 +366,14 @@ int ssc_beam_first(const float* log_probs, int ldlp, const uint8_t* fsm, int B, 
 int ssc_beam_step(const float* log_probs, int ldlp, const uint8_t* fsm, const int64_t* last_pred, const float* last_lp,
                   int B, int S, int V, int beam, int per_node, int end_index, int64_t* pred, float* lp_out,
                   int64_t* backptr, float* scratch_val, int64_t* scratch_idx, void* stream);
+/* Same selections from UN-normalised vocabulary logits: every row's log-sum-exp is taken inside the selection kernel
+ * (row staged in LDS, same arithmetic and summation order as ssc_log_softmax followed by the calls above, so the results
+ * are bit-identical) - saves a full write + read of the (G,V) log-probability matrix per step. */
+int ssc_beam_first_logits(const float* logits, int ldlp, const uint8_t* fsm, int B, int S, int V, int beam,
+                          int64_t* pred, float* lp_out, void* stream);
+int ssc_beam_step_logits(const float* logits, int ldlp, const uint8_t* fsm, const int64_t* last_pred, const float* last_lp,
+                         int B, int S, int V, int beam, int per_node, int end_index, int64_t* pred, float* lp_out,
+                         int64_t* backptr, float* scratch_val, int64_t* scratch_idx, void* stream);
 int ssc_gather_rows(const float* src, int ld, const int64_t* backptr, int B, int rows_per_batch, int W, float* dst,
                     void* stream);
 /* back-trace (cbs.py:252-277): preds (steps,B,SB) int64, backptrs (steps-1,B,SB) int64 -> out (B,SB,steps). */

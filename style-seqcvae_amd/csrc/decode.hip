@@ -130,25 +130,56 @@ __device__ __forceinline__ Cand block_best(Cand c, Cand* sh) {
   return r;
 }
 
-// value of vocabulary entry v for a source row, as cbs.py builds it
-__device__ __forceinline__ float row_value(const float* __restrict__ lp, int v, bool ended, int end_index) {
-  if (ended) return v == end_index ? 0.f : -INFINITY;
-  return lp[v];
+// NORM: `lp` holds un-normalised logits; the row's log-sum-exp is taken here with exactly the arithmetic of
+// log_softmax_kernel (256 threads, strided partial maxima / sums, block_reduce order), so lp[v] - lse is bit-identical to
+// what ssc_log_softmax would have stored.  The row is staged in LDS when it fits (`staged`), so HBM sees it once.
+__device__ __forceinline__ float dec_block_reduce(float v, float* sh, bool is_max) {
+  int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  v = is_max ? ssc_wave_max(v) : ssc_wave_sum(v);
+  __syncthreads();
+  if (lane == 0) sh[wv] = v;
+  __syncthreads();
+  float r = sh[0];
+  for (int i = 1; i < nw; ++i) r = is_max ? fmaxf(r, sh[i]) : r + sh[i];
+  return r;
+}
+template <bool NORM>
+__device__ __forceinline__ const float* row_prepare(const float* __restrict__ row, int V, bool staged, float* srow, float* shr,
+                                                    float& lse) {
+  lse = 0.f;
+  if (!NORM) return row;
+  float mx = -INFINITY;
+  for (int v = threadIdx.x; v < V; v += blockDim.x) {
+    const float x = row[v];
+    if (staged) srow[v] = x;
+    mx = fmaxf(mx, x);
+  }
+  mx = dec_block_reduce(mx, shr, true);   // (its barriers also publish srow)
+  const float* src = staged ? srow : row;
+  float s = 0.f;
+  for (int v = threadIdx.x; v < V; v += blockDim.x) s += expf(src[v] - mx);
+  s = dec_block_reduce(s, shr, false);
+  lse = mx + logf(s);
+  return src;
 }
 
 // first step: per (b, s): top-`beam` over v of (fsm[b,0,s,v] ? lp[b,v] : -inf)       cbs.py:127-145
+template <bool NORM>
 __global__ __launch_bounds__(256) void beam_first_kernel(const float* __restrict__ lp, int ldlp,
                                                          const uint8_t* __restrict__ fsm, int S, int V, int beam,
-                                                         int64_t* __restrict__ pred, float* __restrict__ lp_out) {
+                                                         int64_t* __restrict__ pred, float* __restrict__ lp_out, int staged) {
+  extern __shared__ float srow[];
   __shared__ Cand sh[4];
+  __shared__ float shr[16];
   int b = blockIdx.x / S, s = blockIdx.x % S;
-  const float* row = lp + (size_t)b * ldlp;
+  float lse;
+  const float* row = row_prepare<NORM>(lp + (size_t)b * ldlp, V, staged != 0, srow, shr, lse);
   const uint8_t* m = fsm + (((size_t)b * S + 0) * S + s) * V;
   Cand prev{INFINITY, -1};
   for (int k = 0; k < beam; ++k) {
     Cand best{-INFINITY, -1};
     for (int v = threadIdx.x; v < V; v += blockDim.x) {
-      float x = m[v] ? row[v] : -INFINITY;
+      float x = m[v] ? (NORM ? row[v] - lse : row[v]) : -INFINITY;
       bool after_prev = (prev.i < 0) || (x < prev.v) || (x == prev.v && v > prev.i);
       if (after_prev && (best.i < 0 || better(x, v, best))) best = Cand{x, v};
     }
@@ -162,24 +193,32 @@ __global__ __launch_bounds__(256) void beam_first_kernel(const float* __restrict
 }
 
 // later steps, part A: per (source row g=(b,s,k), target state i): masked top-`per_node`     cbs.py:177-209
+template <bool NORM>
 __global__ __launch_bounds__(256) void beam_row_topk_kernel(const float* __restrict__ lp, int ldlp,
                                                             const uint8_t* __restrict__ fsm,
                                                             const int64_t* __restrict__ last_pred, int S, int V, int beam,
                                                             int per_node, int end_index, float* __restrict__ sval,
-                                                            int64_t* __restrict__ sidx) {
+                                                            int64_t* __restrict__ sidx, int staged) {
+  extern __shared__ float srow[];
   __shared__ Cand sh[4];
+  __shared__ float shr[16];
   int g = blockIdx.x, i = blockIdx.y;
   int b = g / (S * beam), s = (g / beam) % S, k = g % beam;
-  const float* row = lp + (size_t)g * ldlp;
   const uint8_t* m = fsm + (((size_t)b * S + s) * S + i) * V;
-  bool ended = last_pred[g] == end_index;
+  bool ended = last_pred[g] == end_index;   // workgroup-uniform; an ended beam never looks at its row
+  float lse = 0.f;
+  const float* row = lp + (size_t)g * ldlp;
+  if (!ended) row = row_prepare<NORM>(row, V, staged != 0, srow, shr, lse);
   // scratch layout (b, i, s, k, n)
   size_t base = ((((size_t)b * S + i) * S + s) * beam + k) * per_node;
   Cand prev{INFINITY, -1};
   for (int n = 0; n < per_node; ++n) {
     Cand best{-INFINITY, -1};
     for (int v = threadIdx.x; v < V; v += blockDim.x) {
-      float x = m[v] ? row_value(row, v, ended, end_index) : -1e20f;
+      float x;
+      if (!m[v]) x = -1e20f;
+      else if (ended) x = v == end_index ? 0.f : -INFINITY;
+      else x = NORM ? row[v] - lse : row[v];
       bool after_prev = (prev.i < 0) || (x < prev.v) || (x == prev.v && v > prev.i);
       if (after_prev && (best.i < 0 || better(x, v, best))) best = Cand{x, v};
     }
@@ -362,37 +401,67 @@ extern "C" int ssc_decode_step(const ssc_model_cfg* cfg, const ssc_params* p, co
   } else {
     SSC_TRY(gemm_nt(st, slabs, l.slab_floats, {{d->hd_out, H, p->out_w, p->ld_out_w, H}}, G, V, d->log_probs, V, p->out_b));
   }
-  SSC_TRY(ssc_log_softmax(d->log_probs, V, G, V, d->log_probs, V, st));
+  if (!d->raw_logits) SSC_TRY(ssc_log_softmax(d->log_probs, V, G, V, d->log_probs, V, st));
   return SSC_OK;
 }
 
-extern "C" int ssc_beam_first(const float* log_probs, int ldlp, const uint8_t* fsm, int B, int S, int V, int beam,
-                              int64_t* pred, float* lp_out, void* stream) {
-  if (!log_probs || !fsm || !pred || !lp_out || B <= 0 || S <= 0 || V <= 0 || beam <= 0 || beam > V || ldlp < V)
-    return SSC_EINVAL;
-  hipLaunchKernelGGL(beam_first_kernel, dim3(B * S), dim3(256), 0, (hipStream_t)stream, log_probs, ldlp, fsm, S, V, beam,
-                     pred, lp_out);
+namespace {
+constexpr size_t BEAM_STAGE_MAX = 64 * 1024;   // a vocabulary row is staged in LDS up to this size
+int beam_first_impl(bool norm, const float* lp, int ldlp, const uint8_t* fsm, int B, int S, int V, int beam, int64_t* pred,
+                    float* lp_out, hipStream_t st) {
+  if (!lp || !fsm || !pred || !lp_out || B <= 0 || S <= 0 || V <= 0 || beam <= 0 || beam > V || ldlp < V) return SSC_EINVAL;
+  const int staged = norm && (size_t)V * sizeof(float) <= BEAM_STAGE_MAX;
+  const size_t lds = staged ? (size_t)V * sizeof(float) : 0;
+  if (norm) hipLaunchKernelGGL(beam_first_kernel<true>, dim3(B * S), dim3(256), lds, st, lp, ldlp, fsm, S, V, beam, pred, lp_out, staged);
+  else hipLaunchKernelGGL(beam_first_kernel<false>, dim3(B * S), dim3(256), 0, st, lp, ldlp, fsm, S, V, beam, pred, lp_out, 0);
   SSC_CHECK_LAUNCH();
   return SSC_OK;
+}
+int beam_step_impl(bool norm, const float* lp, int ldlp, const uint8_t* fsm, const int64_t* last_pred, const float* last_lp, int B,
+                   int S, int V, int beam, int per_node, int end_index, int64_t* pred, float* lp_out, int64_t* backptr,
+                   float* scratch_val, int64_t* scratch_idx, hipStream_t st) {
+  if (!lp || !fsm || !last_pred || !last_lp || !pred || !lp_out || !backptr || !scratch_val || !scratch_idx) return SSC_EINVAL;
+  if (B <= 0 || S <= 0 || V <= 0 || beam <= 0 || per_node <= 0 || per_node > V || ldlp < V || end_index < 0 ||
+      end_index >= V || beam > S * beam * per_node)
+    return SSC_EINVAL;
+  const int staged = norm && (size_t)V * sizeof(float) <= BEAM_STAGE_MAX;
+  const size_t lds = staged ? (size_t)V * sizeof(float) : 0;
+  if (norm)
+    hipLaunchKernelGGL(beam_row_topk_kernel<true>, dim3(B * S * beam, S), dim3(256), lds, st, lp, ldlp, fsm, last_pred, S, V, beam,
+                       per_node, end_index, scratch_val, scratch_idx, staged);
+  else
+    hipLaunchKernelGGL(beam_row_topk_kernel<false>, dim3(B * S * beam, S), dim3(256), 0, st, lp, ldlp, fsm, last_pred, S, V, beam,
+                       per_node, end_index, scratch_val, scratch_idx, 0);
+  SSC_CHECK_LAUNCH();
+  hipLaunchKernelGGL(beam_merge_kernel, dim3(B * S), dim3(64), 0, st, scratch_val, scratch_idx, last_lp, S, beam, per_node,
+                     pred, lp_out, backptr);
+  SSC_CHECK_LAUNCH();
+  return SSC_OK;
+}
+}  // namespace
+
+extern "C" int ssc_beam_first(const float* log_probs, int ldlp, const uint8_t* fsm, int B, int S, int V, int beam,
+                              int64_t* pred, float* lp_out, void* stream) {
+  return beam_first_impl(false, log_probs, ldlp, fsm, B, S, V, beam, pred, lp_out, (hipStream_t)stream);
+}
+extern "C" int ssc_beam_first_logits(const float* logits, int ldlp, const uint8_t* fsm, int B, int S, int V, int beam,
+                                     int64_t* pred, float* lp_out, void* stream) {
+  return beam_first_impl(true, logits, ldlp, fsm, B, S, V, beam, pred, lp_out, (hipStream_t)stream);
 }
 
 extern "C" int ssc_beam_step(const float* log_probs, int ldlp, const uint8_t* fsm, const int64_t* last_pred,
                              const float* last_lp, int B, int S, int V, int beam, int per_node, int end_index,
                              int64_t* pred, float* lp_out, int64_t* backptr, float* scratch_val, int64_t* scratch_idx,
                              void* stream) {
-  if (!log_probs || !fsm || !last_pred || !last_lp || !pred || !lp_out || !backptr || !scratch_val || !scratch_idx)
-    return SSC_EINVAL;
-  if (B <= 0 || S <= 0 || V <= 0 || beam <= 0 || per_node <= 0 || per_node > V || ldlp < V || end_index < 0 ||
-      end_index >= V || beam > S * beam * per_node)
-    return SSC_EINVAL;
-  hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(beam_row_topk_kernel, dim3(B * S * beam, S), dim3(256), 0, st, log_probs, ldlp, fsm, last_pred, S, V,
-                     beam, per_node, end_index, scratch_val, scratch_idx);
-  SSC_CHECK_LAUNCH();
-  hipLaunchKernelGGL(beam_merge_kernel, dim3(B * S), dim3(64), 0, st, scratch_val, scratch_idx, last_lp, S, beam, per_node,
-                     pred, lp_out, backptr);
-  SSC_CHECK_LAUNCH();
-  return SSC_OK;
+  return beam_step_impl(false, log_probs, ldlp, fsm, last_pred, last_lp, B, S, V, beam, per_node, end_index, pred, lp_out,
+                        backptr, scratch_val, scratch_idx, (hipStream_t)stream);
+}
+extern "C" int ssc_beam_step_logits(const float* logits, int ldlp, const uint8_t* fsm, const int64_t* last_pred,
+                                    const float* last_lp, int B, int S, int V, int beam, int per_node, int end_index,
+                                    int64_t* pred, float* lp_out, int64_t* backptr, float* scratch_val,
+                                    int64_t* scratch_idx, void* stream) {
+  return beam_step_impl(true, logits, ldlp, fsm, last_pred, last_lp, B, S, V, beam, per_node, end_index, pred, lp_out,
+                        backptr, scratch_val, scratch_idx, (hipStream_t)stream);
 }
 
 extern "C" int ssc_gather_rows(const float* src, int ld, const int64_t* backptr, int B, int rows_per_batch, int Wd,

@@ -49,10 +49,12 @@ class DecodeEngine:
 
     def step(self, ctx: ImageContext, tokens: torch.Tensor, states: Optional[Dict[str, torch.Tensor]],
              sentiment: Optional[torch.Tensor], eps: torch.Tensor, want_log_probs: bool = True,
-             emb_table: Optional[torch.Tensor] = None
+             emb_table: Optional[torch.Tensor] = None, raw_logits: bool = False
              ) -> Tuple[Optional[torch.Tensor], Dict[str, torch.Tensor], torch.Tensor]:
         """One eval decode step for G rows (row g -> image g // (G / nimg)).  Returns (log_probs (G,V) or None,
-        new states, alpha (G,R)).  h_encoder / c_encoder are carried through untouched (updown_cell.py:176-203)."""
+        new states, alpha (G,R)).  h_encoder / c_encoder are carried through untouched (updown_cell.py:176-203).
+        raw_logits: return the un-normalised vocabulary logits instead (for cbs_search(raw_logits=True), which takes the
+        log-sum-exp inside its selection kernel: one pass over the (G,V) matrix less per step)."""
         d = self.dims
         G = tokens.numel()
         assert G % ctx.nimg == 0, (G, ctx.nimg)
@@ -77,7 +79,7 @@ class DecodeEngine:
                                    st["h1"].data_ptr(), st["c1"].data_ptr(), st["h_decoder"].data_ptr(),
                                    st["c_decoder"].data_ptr(), new["h1"].data_ptr(), new["c1"].data_ptr(),
                                    new["h_decoder"].data_ptr(), new["c_decoder"].data_ptr(), alpha.data_ptr(),
-                                   lp.data_ptr() if lp is not None else None)
+                                   lp.data_ptr() if lp is not None else None, 1 if raw_logits else 0)
         p = self._params()
         if emb_table is not None:  # rows of `emb_table` are the token embeddings themselves (UpDownCell.forward API)
             p.emb = emb_table.data_ptr()
@@ -101,11 +103,15 @@ DecodeEngine.step_from_embedding = DecodeEngine._step_from_embedding
 
 def cbs_search(start_predictions: torch.Tensor, start_state, step: Callable, fsm: torch.Tensor, end_index: int,
                max_steps: int, beam_size: int, per_node_beam_size: int, early_stop: bool = True,
-               early_stop_every: int = 1):
+               early_stop_every: int = 1, raw_logits: bool = False):
     """Constrained beam search with on-device bookkeeping (ssc_beam_first / ssc_beam_step / ssc_gather_rows /
     ssc_beam_backtrace).  `step(tokens (G,), state) -> (log_probs (G,V), state, ...)` as in cbs.py:127,170.
-    Returns (predictions (B,S,beam,steps) int64, log_probs (B,S,beam))."""
+    Returns (predictions (B,S,beam,steps) int64, log_probs (B,S,beam)).
+    raw_logits: `step` returns un-normalised logits; the selection kernels normalise each row themselves (bit-identical
+    selections and log-probs)."""
     lib = _lib.load()
+    beam_first = lib.ssc_beam_first_logits if raw_logits else lib.ssc_beam_first
+    beam_step = lib.ssc_beam_step_logits if raw_logits else lib.ssc_beam_step
     st = _lib.stream_ptr
     B, S, _, V = fsm.shape
     dev = start_predictions.device
@@ -119,7 +125,7 @@ def cbs_search(start_predictions: torch.Tensor, start_state, step: Callable, fsm
     lp0, state = out[0], out[1]
     lp0 = lp0.contiguous()
     assert lp0.shape == (B, V), lp0.shape
-    lib.ssc_beam_first(_lib.ptr(lp0), lp0.stride(0), _lib.ptr(fsm), B, S, V, beam_size, _lib.ptr(preds[0]), _lib.ptr(last_lp),
+    beam_first(_lib.ptr(lp0), lp0.stride(0), _lib.ptr(fsm), B, S, V, beam_size, _lib.ptr(preds[0]), _lib.ptr(last_lp),
                        st())
     # enlarge states to (B*S*beam, *) batch-major (cbs.py:10-17,152-155)
     def enlarge(t):
@@ -140,7 +146,7 @@ def cbs_search(start_predictions: torch.Tensor, start_state, step: Callable, fsm
         out = step(last, state)
         lp, state = out[0].contiguous(), out[1]
         new_lp = torch.empty_like(last_lp)
-        lib.ssc_beam_step(_lib.ptr(lp), lp.stride(0), _lib.ptr(fsm), _lib.ptr(last), _lib.ptr(last_lp), B, S, V, beam_size,
+        beam_step(_lib.ptr(lp), lp.stride(0), _lib.ptr(fsm), _lib.ptr(last), _lib.ptr(last_lp), B, S, V, beam_size,
                           per_node_beam_size, end_index, _lib.ptr(preds[t]), _lib.ptr(new_lp), _lib.ptr(backs[t - 1]),
                           _lib.ptr(sval), _lib.ptr(sidx), st())
         last_lp = new_lp

@@ -6,12 +6,16 @@ the batch entries of ONE constrained beam search (rows ordered image, sample, fs
 computed once per image and shared by its N_Z * beam rows; the result per (image, sample) equals the reference's
 per-call result given the same per-row noise.
 """
+import os
 from typing import List, Optional
 
 import torch
 
 from .decode import DecodeEngine, cbs_search
 from .decoding import select_best_beam_with_constraints
+
+
+_RAW = os.environ.get("SSC_RAW_LOGITS", "1") != "0"   # A/B switch (tools): 0 = log_softmax kernel + selection on log-probs
 
 
 def diverse_decode(dec: DecodeEngine, feats: torch.Tensor, sentiment: Optional[torch.Tensor], n_samples: int, beam: int,
@@ -40,12 +44,12 @@ def diverse_decode(dec: DecodeEngine, feats: torch.Tensor, sentiment: Optional[t
         else:
             eps = torch.randn(G, d.Z, device=dev)
         calls["k"] += 1
-        lp, st, alpha = dec.step(ctx, tokens, state, sent_rows, eps)
+        lp, st, alpha = dec.step(ctx, tokens, state, sent_rows, eps, raw_logits=_RAW)
         return lp, st
 
     start = torch.full((B,), boundary_index, dtype=torch.long, device=dev)
     beams, lps = cbs_search(start, None, step, fsm, boundary_index, max_steps, beam, per_node or (beam // 2) or beam,
-                            early_stop=early_stop, early_stop_every=4)
+                            early_stop=early_stop, early_stop_every=4, raw_logits=_RAW)
     if fsm.size(1) == 1:
         best = beams[:, 0, 0, :]
     else:

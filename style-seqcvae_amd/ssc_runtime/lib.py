@@ -95,7 +95,8 @@ class Batch(C.Structure):
 class DecodeStepDesc(C.Structure):
     _fields_ = [("G", C.c_int), ("R", C.c_int), ("rows_per_image", C.c_int), ("feats", vp), ("imgbuf", vp),
                 ("tokens", vp), ("sentiment", vp), ("eps", vp), ("h1", vp), ("c1", vp), ("hd", vp), ("cd", vp),
-                ("h1_out", vp), ("c1_out", vp), ("hd_out", vp), ("cd_out", vp), ("alpha", vp), ("log_probs", vp)]
+                ("h1_out", vp), ("c1_out", vp), ("hd_out", vp), ("cd_out", vp), ("alpha", vp), ("log_probs", vp),
+                ("raw_logits", C.c_int)]
 
 
 # name -> (restype, argtypes).  Every symbol include/ssc.h declares is listed; tests check they all resolve.
@@ -145,6 +146,8 @@ SYMBOLS = {
     "ssc_decode_step": (_i, [C.POINTER(ModelCfg), C.POINTER(Params), C.POINTER(DecodeStepDesc), vp, _sz, vp]),
     "ssc_beam_first": (_i, [vp, _i, vp, _i, _i, _i, _i, vp, vp, vp]),
     "ssc_beam_step": (_i, [vp, _i, vp, vp, vp, _i, _i, _i, _i, _i, _i, vp, vp, vp, vp, vp, vp]),
+    "ssc_beam_first_logits": (_i, [vp, _i, vp, _i, _i, _i, _i, vp, vp, vp]),
+    "ssc_beam_step_logits": (_i, [vp, _i, vp, vp, vp, _i, _i, _i, _i, _i, _i, vp, vp, vp, vp, vp, vp]),
     "ssc_gather_rows": (_i, [vp, _i, vp, _i, _i, _i, vp, vp]),
     "ssc_beam_backtrace": (_i, [vp, vp, _i, _i, _i, vp, vp]),
 }

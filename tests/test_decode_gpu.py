@@ -151,3 +151,44 @@ def test_full_size_c4_decode_steps_two_kernel_paths_agree():
     for k in x[2]:
         assert maxdiff(x[2][k], z[2][k]) < 1e-4, k
     assert maxdiff(torch.logsumexp(x[1], 1), torch.zeros(G)) < 1e-4
+
+
+@pytest.mark.parametrize("B,S,V,beam,per_node", [(3, 1, 50, 3, 2), (2, 3, 200, 2, 2), (2, 2, 20000, 3, 1)])
+def test_beam_selection_from_raw_logits_is_bit_identical(B, S, V, beam, per_node):
+    """ssc_beam_first_logits / ssc_beam_step_logits (log-sum-exp inside the selection kernel; the V = 20000 case does not
+    fit the LDS staging and reads the row from HBM) against ssc_log_softmax followed by ssc_beam_first / ssc_beam_step."""
+    from ssc_runtime import lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(B * 100 + V)
+    dev_ = "cuda"
+    fsm = (torch.rand(B, S, S, V, generator=g) < 0.8).to(torch.uint8).to(dev_)
+    fsm[:, :, :, :4] = 1
+    logits0 = (torch.randn(B, V, generator=g) * 3).to(dev_)
+    lp0 = torch.empty_like(logits0)
+    lib.ssc_log_softmax(L.ptr(logits0), V, B, V, L.ptr(lp0), V, L.stream_ptr())
+    outs = []
+    for fn, src in ((lib.ssc_beam_first, lp0), (lib.ssc_beam_first_logits, logits0)):
+        pred = torch.empty(B, S * beam, dtype=torch.int64, device=dev_)
+        lpo = torch.empty(B, S, beam, device=dev_)
+        fn(L.ptr(src), V, L.ptr(fsm), B, S, V, beam, L.ptr(pred), L.ptr(lpo), L.stream_ptr())
+        outs.append((pred.clone(), lpo.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    G = B * S * beam
+    logits = (torch.randn(G, V, generator=g) * 3).to(dev_)
+    lp = torch.empty_like(logits)
+    lib.ssc_log_softmax(L.ptr(logits), V, G, V, L.ptr(lp), V, L.stream_ptr())
+    last = outs[0][0].reshape(G).clone()
+    last[1] = 1                      # one ended beam (end_index = 1)
+    last_lp = outs[0][1]
+    res = []
+    for fn, src in ((lib.ssc_beam_step, lp), (lib.ssc_beam_step_logits, logits)):
+        pred = torch.empty(B, S * beam, dtype=torch.int64, device=dev_)
+        nlp = torch.empty(B, S, beam, device=dev_)
+        back = torch.empty(B, S * beam, dtype=torch.int64, device=dev_)
+        sval = torch.empty(B * S * S * beam * per_node, device=dev_)
+        sidx = torch.empty(B * S * S * beam * per_node, dtype=torch.int64, device=dev_)
+        fn(L.ptr(src), V, L.ptr(fsm), L.ptr(last), L.ptr(last_lp), B, S, V, beam, per_node, 1, L.ptr(pred), L.ptr(nlp), L.ptr(back),
+           L.ptr(sval), L.ptr(sidx), L.stream_ptr())
+        res.append((pred.clone(), nlp.clone(), back.clone()))
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)
