@@ -172,6 +172,12 @@ def bench_decode(args, model, eng, c, rank, world, device):
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             el, tokens, rows_steps = float(tmax[0]), float(t[1]), float(t[2])
         results[early] = (el, tokens, rows_steps)
+    if rank == 0 and os.environ.get("SSC_SHADOW"):   # wave-specialised vs 4-wave kernel on every large product (diagnostic)
+        import ctypes as _C
+        from ssc_runtime import lib as _L
+        rec = (_C.c_ulonglong * 4)()
+        _C.CDLL(_L.LIB_PATH).ssc_debug_gemm_shadow(rec)
+        print("gemm shadow compare {compared, mismatches, non-finite, first bad index}:", list(rec), file=sys.stderr, flush=True)
     if rank == 0 and os.environ.get("SSC_GEMM_DBG") == "128":   # pointer audit of the wave-specialised kernels (diagnostic)
         import ctypes as _C
         from ssc_runtime import lib as _L

@@ -1481,6 +1481,21 @@ __global__ __launch_bounds__(512) void gemm_x3w_kernel(const KGroup g) {
   x3w_body<A_KC, B_KC, KG, TM, TN, PF>(g.a[p], x, yz % gy, yz / gy, gx, gy, gz);
 }
 
+__device__ unsigned long long g_shadow[4];   // SSC_SHADOW diagnostic: {elements compared, mismatches, NaN/Inf in x3w, first bad index}
+__global__ void shadow_compare_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb, int M, int N) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)M * N) return;
+  const int r = (int)(i / N), c = (int)(i % N);
+  const float x = a[(size_t)r * lda + c], y = b[(size_t)r * ldb + c];
+  const bool bad_num = !(fabsf(x) < 3e38f);
+  const bool diff = !(fabsf(x - y) <= 1e-3f * (fabsf(x) + fabsf(y)) + 1e-3f);
+  if (threadIdx.x == 0) atomicAdd(&g_shadow[0], (unsigned long long)min((size_t)256, (size_t)M * N - i));
+  if (bad_num) atomicAdd(&g_shadow[2], 1ull);
+  if (diff) {
+    if (atomicAdd(&g_shadow[1], 1ull) == 0) g_shadow[3] = i;
+  }
+}
+
 __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int nslab, size_t slab_stride, int M, int N,
                                     float* __restrict__ C, int ldc, const float* __restrict__ bias, int accumulate,
                                     const int* __restrict__ mcount, const int* __restrict__ crows) {
@@ -1666,6 +1681,23 @@ int launch(const ssc_gemm_desc* d, KArgs& k, int splits, hipStream_t st) {
       KGroup g1;
       group_of_one(g1, k, grid);
       hipLaunchKernelGGL(fn, dim3(g1.first[1]), dim3(512), (x3w_lds_bytes<128, 128>()), st, g1);
+      static const bool shadow = getenv("SSC_SHADOW") != nullptr;   // diagnostic: recompute with the 4-wave kernel and compare
+      if (shadow && !compact && splits == 1 && !k.accumulate) {
+        static float* scratch = nullptr;
+        static size_t cap = 0;
+        const size_t need = (size_t)d->M * d->N;
+        if (need > cap) {
+          if (scratch) (void)hipFree(scratch);
+          if (hipMalloc(&scratch, need * sizeof(float)) != hipSuccess) return SSC_EHIP;
+          cap = need;
+        }
+        KArgs k2 = k;
+        k2.out = scratch; k2.ldo = d->N; k2.slab_stride = 0;
+        if (d->a_kc && d->b_kc) hipLaunchKernelGGL((gemm_x3b_kernel<true, true, false>), grid, dim3(256), 0, st, k2);
+        else if (d->a_kc) hipLaunchKernelGGL((gemm_x3b_kernel<true, false, false>), grid, dim3(256), 0, st, k2);
+        else hipLaunchKernelGGL((gemm_x3b_kernel<false, false, false>), grid, dim3(256), 0, st, k2);
+        hipLaunchKernelGGL(shadow_compare_kernel, dim3((unsigned)((need + 255) / 256)), dim3(256), 0, st, k.out, k.ldo, scratch, d->N, d->M, d->N);
+      }
     } else
     if (d->a_kc && d->b_kc) hipLaunchKernelGGL((gemm_x3b_kernel<true, true, false>), grid, dim3(256), 0, st, k);
     else if (d->a_kc) hipLaunchKernelGGL((gemm_x3b_kernel<true, false, false>), grid, dim3(256), 0, st, k);
@@ -1982,6 +2014,12 @@ extern "C" int ssc_set_gemm_wide_min_n(int n) {
   if (n == -12) g_x3w_skinny = 1;
   if (n == -13) g_x3w_skinny = 2;      // ... on the wave-specialised (producer / consumer) form of that kernel
   return prev;
+}
+
+// diagnostic: SSC_SHADOW record {elements compared, mismatches, non-finite, first bad index}
+extern "C" int ssc_debug_gemm_shadow(unsigned long long* out4) {
+  if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_shadow), 4 * sizeof(unsigned long long)) != hipSuccess) return SSC_EHIP;
+  return SSC_OK;
 }
 
 // diagnostic: read and clear the SSC_GEMM_DBG=128 pointer-audit record
