@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void attn_bwd_apply_kernel(const float* __rest
 extern "C" int ssc_attn_logits(const float* q, int ldq, const float* pv, const float* wa, int G, int R, int A,
                                int rows_per_image, float* logits, void* stream) {
   if (!q || !pv || !wa || !logits || G <= 0 || R <= 0 || A <= 0 || rows_per_image <= 0 || ldq < A) return SSC_EINVAL;
-  hipLaunchKernelGGL(attn_logits_kernel, dim3(ssc_cdiv(G * R, 4)), dim3(256), 0, (hipStream_t)stream, q, ldq, 1, (size_t)0,
+  SSC_LAUNCH(attn_logits_kernel, dim3(ssc_cdiv(G * R, 4)), dim3(256), 0, (hipStream_t)stream, q, ldq, 1, (size_t)0,
                      (float*)nullptr, 0, pv, wa, G, R, A, rows_per_image, logits);
   SSC_CHECK_LAUNCH();
   return SSC_OK;
@@ -283,7 +283,7 @@ extern "C" int ssc_attn_fwd(const float* q, int ldq, const float* pv, const floa
   if (!mask || !feats || !alpha || !att || !logits || F <= 0 || ldatt < F) return SSC_EINVAL;
   if (R > 64 * MAXR_LANE) return SSC_EINVAL;
   SSC_TRY(ssc_attn_logits(q, ldq, pv, wa, G, R, A, rows_per_image, logits, stream));
-  hipLaunchKernelGGL(attn_apply_kernel, dim3(ssc_cdiv(F, 256), G), dim3(64), 0, (hipStream_t)stream, logits, mask, feats,
+  SSC_LAUNCH(attn_apply_kernel, dim3(ssc_cdiv(F, 256), G), dim3(64), 0, (hipStream_t)stream, logits, mask, feats,
                      G, R, F, rows_per_image, alpha, att, ldatt);
   SSC_CHECK_LAUNCH();
   return SSC_OK;
@@ -295,10 +295,10 @@ int ssc_attn_fwd_qslabs(const float* qslabs, int nslab, size_t slab_stride, floa
                         int rows_per_image, float* logits, float* alpha, float* att, int ldatt, hipStream_t st) {
   if (!qslabs || nslab < 1 || !q_out || !pv || !wa || !mask || !feats || !alpha || !att || !logits) return SSC_EINVAL;
   if (G <= 0 || R <= 0 || A <= 0 || F <= 0 || ldatt < F || ldqo < A || R > 64 * MAXR_LANE) return SSC_EINVAL;
-  hipLaunchKernelGGL(attn_logits_kernel, dim3(ssc_cdiv(G * R, 4)), dim3(256), 0, st, qslabs, A, nslab, slab_stride, q_out,
+  SSC_LAUNCH(attn_logits_kernel, dim3(ssc_cdiv(G * R, 4)), dim3(256), 0, st, qslabs, A, nslab, slab_stride, q_out,
                      ldqo, pv, wa, G, R, A, rows_per_image, logits);
   SSC_CHECK_LAUNCH();
-  hipLaunchKernelGGL(attn_apply_kernel, dim3(ssc_cdiv(F, 256), G), dim3(64), 0, st, logits, mask, feats, G, R, F,
+  SSC_LAUNCH(attn_apply_kernel, dim3(ssc_cdiv(F, 256), G), dim3(64), 0, st, logits, mask, feats, G, R, F,
                      rows_per_image, alpha, att, ldatt);
   SSC_CHECK_LAUNCH();
   return SSC_OK;
@@ -309,10 +309,10 @@ extern "C" int ssc_attn_bwd(const float* datt, int lddatt, const float* q, int l
                             float* dpv_acc, float* dwa_acc, float* scratch_dalpha, void* stream) {
   if (!datt || !q || !pv || !wa || !alpha || !feats || !dq || !dpv_acc || !dwa_acc || !scratch_dalpha) return SSC_EINVAL;
   if (G <= 0 || R <= 0 || A <= 0 || F <= 0 || R > 64 * MAXR_LANE || lddatt < F || ldq < A || lddq < A) return SSC_EINVAL;
-  hipLaunchKernelGGL(attn_dalpha_kernel, dim3(ssc_cdiv(G * R, 4)), dim3(256), 0, (hipStream_t)stream, datt, lddatt, feats,
+  SSC_LAUNCH(attn_dalpha_kernel, dim3(ssc_cdiv(G * R, 4)), dim3(256), 0, (hipStream_t)stream, datt, lddatt, feats,
                      G, R, F, scratch_dalpha);
   SSC_CHECK_LAUNCH();
-  hipLaunchKernelGGL(attn_bwd_apply_kernel, dim3(ssc_cdiv(A, 256), G), dim3(256), 0, (hipStream_t)stream, q, ldq, pv, wa,
+  SSC_LAUNCH(attn_bwd_apply_kernel, dim3(ssc_cdiv(A, 256), G), dim3(256), 0, (hipStream_t)stream, q, ldq, pv, wa,
                      alpha, scratch_dalpha, G, R, A, dq, lddq, dpv_acc, dwa_acc);
   SSC_CHECK_LAUNCH();
   return SSC_OK;

@@ -314,10 +314,10 @@ extern "C" int ssc_decode_prepare(const ssc_model_cfg* cfg, const ssc_params* p,
   {
     const int H = cfg->H, Z = cfg->Z, S = cfg->S;
     dim3 grid(ssc_cdiv(H, 256), H4);
-    hipLaunchKernelGGL(dec_add2d_kernel, grid, dim3(256), 0, st, p->att_w_ih + E + F, p->ld_att_w_ih, p->att_w_hh, p->ld_att_w_hh, H,
+    SSC_LAUNCH(dec_add2d_kernel, grid, dim3(256), 0, st, p->att_w_ih + E + F, p->ld_att_w_ih, p->att_w_hh, p->ld_att_w_hh, H,
                        W + l.wsum_att, l.Hp);
     SSC_CHECK_LAUNCH();
-    hipLaunchKernelGGL(dec_add2d_kernel, grid, dim3(256), 0, st, p->dec_w_ih + F + H, p->ld_dec_w_ih, p->dec_w_hh, p->ld_dec_w_hh, H,
+    SSC_LAUNCH(dec_add2d_kernel, grid, dim3(256), 0, st, p->dec_w_ih + F + H, p->ld_dec_w_ih, p->dec_w_hh, p->ld_dec_w_hh, H,
                        W + l.wsum_dec, l.Hp);
     SSC_CHECK_LAUNCH();
     if (hipMemcpy2DAsync(W + l.wz, (size_t)l.Zp * sizeof(float), p->dec_w_ih + F + 2 * H + S, (size_t)p->ld_dec_w_ih * sizeof(float),
@@ -412,8 +412,8 @@ int beam_first_impl(bool norm, const float* lp, int ldlp, const uint8_t* fsm, in
   if (!lp || !fsm || !pred || !lp_out || B <= 0 || S <= 0 || V <= 0 || beam <= 0 || beam > V || ldlp < V) return SSC_EINVAL;
   const int staged = norm && (size_t)V * sizeof(float) <= BEAM_STAGE_MAX;
   const size_t lds = staged ? (size_t)V * sizeof(float) : 0;
-  if (norm) hipLaunchKernelGGL(beam_first_kernel<true>, dim3(B * S), dim3(256), lds, st, lp, ldlp, fsm, S, V, beam, pred, lp_out, staged);
-  else hipLaunchKernelGGL(beam_first_kernel<false>, dim3(B * S), dim3(256), 0, st, lp, ldlp, fsm, S, V, beam, pred, lp_out, 0);
+  if (norm) SSC_LAUNCH(beam_first_kernel<true>, dim3(B * S), dim3(256), lds, st, lp, ldlp, fsm, S, V, beam, pred, lp_out, staged);
+  else SSC_LAUNCH(beam_first_kernel<false>, dim3(B * S), dim3(256), 0, st, lp, ldlp, fsm, S, V, beam, pred, lp_out, 0);
   SSC_CHECK_LAUNCH();
   return SSC_OK;
 }
@@ -427,13 +427,13 @@ int beam_step_impl(bool norm, const float* lp, int ldlp, const uint8_t* fsm, con
   const int staged = norm && (size_t)V * sizeof(float) <= BEAM_STAGE_MAX;
   const size_t lds = staged ? (size_t)V * sizeof(float) : 0;
   if (norm)
-    hipLaunchKernelGGL(beam_row_topk_kernel<true>, dim3(B * S * beam, S), dim3(256), lds, st, lp, ldlp, fsm, last_pred, S, V, beam,
+    SSC_LAUNCH(beam_row_topk_kernel<true>, dim3(B * S * beam, S), dim3(256), lds, st, lp, ldlp, fsm, last_pred, S, V, beam,
                        per_node, end_index, scratch_val, scratch_idx, staged);
   else
-    hipLaunchKernelGGL(beam_row_topk_kernel<false>, dim3(B * S * beam, S), dim3(256), 0, st, lp, ldlp, fsm, last_pred, S, V, beam,
+    SSC_LAUNCH(beam_row_topk_kernel<false>, dim3(B * S * beam, S), dim3(256), 0, st, lp, ldlp, fsm, last_pred, S, V, beam,
                        per_node, end_index, scratch_val, scratch_idx, 0);
   SSC_CHECK_LAUNCH();
-  hipLaunchKernelGGL(beam_merge_kernel, dim3(B * S), dim3(64), 0, st, scratch_val, scratch_idx, last_lp, S, beam, per_node,
+  SSC_LAUNCH(beam_merge_kernel, dim3(B * S), dim3(64), 0, st, scratch_val, scratch_idx, last_lp, S, beam, per_node,
                      pred, lp_out, backptr);
   SSC_CHECK_LAUNCH();
   return SSC_OK;
@@ -467,7 +467,7 @@ extern "C" int ssc_beam_step_logits(const float* logits, int ldlp, const uint8_t
 extern "C" int ssc_gather_rows(const float* src, int ld, const int64_t* backptr, int B, int rows_per_batch, int Wd,
                                float* dst, void* stream) {
   if (!src || !backptr || !dst || B <= 0 || rows_per_batch <= 0 || Wd <= 0 || ld < Wd || src == dst) return SSC_EINVAL;
-  hipLaunchKernelGGL(gather_rows_kernel, dim3(ssc_cdiv(Wd, 256), B * rows_per_batch), dim3(256), 0, (hipStream_t)stream, src,
+  SSC_LAUNCH(gather_rows_kernel, dim3(ssc_cdiv(Wd, 256), B * rows_per_batch), dim3(256), 0, (hipStream_t)stream, src,
                      ld, backptr, rows_per_batch, Wd, dst);
   SSC_CHECK_LAUNCH();
   return SSC_OK;
@@ -476,7 +476,7 @@ extern "C" int ssc_gather_rows(const float* src, int ld, const int64_t* backptr,
 extern "C" int ssc_beam_backtrace(const int64_t* preds, const int64_t* backptrs, int steps, int B, int SB, int64_t* out,
                                   void* stream) {
   if (!preds || !out || steps <= 0 || B <= 0 || SB <= 0 || (steps > 1 && !backptrs)) return SSC_EINVAL;
-  hipLaunchKernelGGL(beam_backtrace_kernel, dim3(ssc_cdiv(B * SB, 64)), dim3(64), 0, (hipStream_t)stream, preds, backptrs,
+  SSC_LAUNCH(beam_backtrace_kernel, dim3(ssc_cdiv(B * SB, 64)), dim3(64), 0, (hipStream_t)stream, preds, backptrs,
                      steps, B, SB, out);
   SSC_CHECK_LAUNCH();
   return SSC_OK;

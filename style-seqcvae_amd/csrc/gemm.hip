@@ -1651,8 +1651,8 @@ int launch(const ssc_gemm_desc* d, KArgs& k, int splits, hipStream_t st) {
     SSC_TRY(x3w_prepare());
     KGroup g1;
     group_of_one(g1, k, grid);
-    if (d->b_kc) hipLaunchKernelGGL((gemm_x3w_kernel<true, true, false, 64, 256, 2>), dim3(g1.first[1]), dim3(512), (x3w_lds_bytes<64, 256>()), st, g1);
-    else hipLaunchKernelGGL((gemm_x3w_kernel<true, false, false, 64, 256, 2>), dim3(g1.first[1]), dim3(512), (x3w_lds_bytes<64, 256>()), st, g1);
+    if (d->b_kc) SSC_LAUNCH((gemm_x3w_kernel<true, true, false, 64, 256, 2>), dim3(g1.first[1]), dim3(512), (x3w_lds_bytes<64, 256>()), st, g1);
+    else SSC_LAUNCH((gemm_x3w_kernel<true, false, false, 64, 256, 2>), dim3(g1.first[1]), dim3(512), (x3w_lds_bytes<64, 256>()), st, g1);
     if (rec) (void)hipEventRecord(rec->e1, st);
     SSC_CHECK_LAUNCH();
     return SSC_OK;
@@ -1680,7 +1680,7 @@ int launch(const ssc_gemm_desc* d, KArgs& k, int splits, hipStream_t st) {
       SSC_TRY(x3w_prepare());
       KGroup g1;
       group_of_one(g1, k, grid);
-      hipLaunchKernelGGL(fn, dim3(g1.first[1]), dim3(512), (x3w_lds_bytes<128, 128>()), st, g1);
+      SSC_LAUNCH(fn, dim3(g1.first[1]), dim3(512), (x3w_lds_bytes<128, 128>()), st, g1);
       static const bool shadow = getenv("SSC_SHADOW") != nullptr;   // diagnostic: recompute with the 4-wave kernel and compare
       if (shadow && !compact && splits == 1 && !k.accumulate) {
         static float* scratch = nullptr;
@@ -1693,16 +1693,16 @@ int launch(const ssc_gemm_desc* d, KArgs& k, int splits, hipStream_t st) {
         }
         KArgs k2 = k;
         k2.out = scratch; k2.ldo = d->N; k2.slab_stride = 0;
-        if (d->a_kc && d->b_kc) hipLaunchKernelGGL((gemm_x3b_kernel<true, true, false>), grid, dim3(256), 0, st, k2);
-        else if (d->a_kc) hipLaunchKernelGGL((gemm_x3b_kernel<true, false, false>), grid, dim3(256), 0, st, k2);
-        else hipLaunchKernelGGL((gemm_x3b_kernel<false, false, false>), grid, dim3(256), 0, st, k2);
-        hipLaunchKernelGGL(shadow_compare_kernel, dim3((unsigned)((need + 255) / 256)), dim3(256), 0, st, k.out, k.ldo, scratch, d->N, d->M, d->N);
+        if (d->a_kc && d->b_kc) SSC_LAUNCH((gemm_x3b_kernel<true, true, false>), grid, dim3(256), 0, st, k2);
+        else if (d->a_kc) SSC_LAUNCH((gemm_x3b_kernel<true, false, false>), grid, dim3(256), 0, st, k2);
+        else SSC_LAUNCH((gemm_x3b_kernel<false, false, false>), grid, dim3(256), 0, st, k2);
+        SSC_LAUNCH(shadow_compare_kernel, dim3((unsigned)((need + 255) / 256)), dim3(256), 0, st, k.out, k.ldo, scratch, d->N, d->M, d->N);
       }
     } else
-    if (d->a_kc && d->b_kc) hipLaunchKernelGGL((gemm_x3b_kernel<true, true, false>), grid, dim3(256), 0, st, k);
-    else if (d->a_kc) hipLaunchKernelGGL((gemm_x3b_kernel<true, false, false>), grid, dim3(256), 0, st, k);
-    else if (kg) hipLaunchKernelGGL((gemm_x3b_kernel<false, false, true>), grid, dim3(256), 0, st, k);
-    else hipLaunchKernelGGL((gemm_x3b_kernel<false, false, false>), grid, dim3(256), 0, st, k);
+    if (d->a_kc && d->b_kc) SSC_LAUNCH((gemm_x3b_kernel<true, true, false>), grid, dim3(256), 0, st, k);
+    else if (d->a_kc) SSC_LAUNCH((gemm_x3b_kernel<true, false, false>), grid, dim3(256), 0, st, k);
+    else if (kg) SSC_LAUNCH((gemm_x3b_kernel<false, false, true>), grid, dim3(256), 0, st, k);
+    else SSC_LAUNCH((gemm_x3b_kernel<false, false, false>), grid, dim3(256), 0, st, k);
     if (rec) (void)hipEventRecord(rec->e1, st);
     SSC_CHECK_LAUNCH();
     return SSC_OK;
@@ -1717,12 +1717,12 @@ int launch(const ssc_gemm_desc* d, KArgs& k, int splits, hipStream_t st) {
       for (int i = 0; i < d->nseg; ++i) rec->K += d->seg[i].K;
       (void)hipEventRecord(rec->e0, st);
     }
-    if (wide && g_x3_nbuf == 1) hipLaunchKernelGGL((gemm_x3_kernel<2, 2, 1>), grid, dim3(256), 0, st, k);
-    else if (wide) hipLaunchKernelGGL((gemm_x3_kernel<2, 2, 2>), grid, dim3(256), 0, st, k);
-    else if (g_x3_nbuf == 1 && g_x3_pf == 4) hipLaunchKernelGGL((gemm_x3_kernel<4, 1, 1>), grid, dim3(256), 0, st, k);
-    else if (g_x3_nbuf == 1 && g_x3_pf == 1) hipLaunchKernelGGL((gemm_x3_kernel<1, 1, 1>), grid, dim3(256), 0, st, k);
-    else if (g_x3_nbuf == 1) hipLaunchKernelGGL((gemm_x3_kernel<2, 1, 1>), grid, dim3(256), 0, st, k);
-    else hipLaunchKernelGGL((gemm_x3_kernel<2, 1, 2>), grid, dim3(256), 0, st, k);
+    if (wide && g_x3_nbuf == 1) SSC_LAUNCH((gemm_x3_kernel<2, 2, 1>), grid, dim3(256), 0, st, k);
+    else if (wide) SSC_LAUNCH((gemm_x3_kernel<2, 2, 2>), grid, dim3(256), 0, st, k);
+    else if (g_x3_nbuf == 1 && g_x3_pf == 4) SSC_LAUNCH((gemm_x3_kernel<4, 1, 1>), grid, dim3(256), 0, st, k);
+    else if (g_x3_nbuf == 1 && g_x3_pf == 1) SSC_LAUNCH((gemm_x3_kernel<1, 1, 1>), grid, dim3(256), 0, st, k);
+    else if (g_x3_nbuf == 1) SSC_LAUNCH((gemm_x3_kernel<2, 1, 1>), grid, dim3(256), 0, st, k);
+    else SSC_LAUNCH((gemm_x3_kernel<2, 1, 2>), grid, dim3(256), 0, st, k);
     if (rec) (void)hipEventRecord(rec->e1, st);
     SSC_CHECK_LAUNCH();
     return SSC_OK;
@@ -1743,7 +1743,7 @@ int launch(const ssc_gemm_desc* d, KArgs& k, int splits, hipStream_t st) {
     for (int i = 0; i < d->nseg; ++i) rec->K += d->seg[i].K;
     (void)hipEventRecord(rec->e0, st);
   }
-  hipLaunchKernelGGL(fn, grid, dim3(256), 0, st, k);
+  SSC_LAUNCH(fn, grid, dim3(256), 0, st, k);
   if (rec) (void)hipEventRecord(rec->e1, st);
   SSC_CHECK_LAUNCH();
   return SSC_OK;
@@ -1908,8 +1908,8 @@ int ssc_gemm_slabs_group(const ssc_gemm_desc* const* d, int n, float* const* reg
     rec->M = d[0]->M; rec->N = Nmax; rec->splits = nslab[0]; rec->K = Ksum;
     (void)hipEventRecord(rec->e0, st);
   }
-  if (d[0]->b_kc) hipLaunchKernelGGL((gemm_x3w_kernel<true, true, false, 64, 256, 2>), dim3(g.first[n]), dim3(512), (x3w_lds_bytes<64, 256>()), st, g);
-  else hipLaunchKernelGGL((gemm_x3w_kernel<true, false, false, 64, 256, 2>), dim3(g.first[n]), dim3(512), (x3w_lds_bytes<64, 256>()), st, g);
+  if (d[0]->b_kc) SSC_LAUNCH((gemm_x3w_kernel<true, true, false, 64, 256, 2>), dim3(g.first[n]), dim3(512), (x3w_lds_bytes<64, 256>()), st, g);
+  else SSC_LAUNCH((gemm_x3w_kernel<true, false, false, 64, 256, 2>), dim3(g.first[n]), dim3(512), (x3w_lds_bytes<64, 256>()), st, g);
   if (rec) (void)hipEventRecord(rec->e1, st);
   SSC_CHECK_LAUNCH();
   return SSC_OK;
@@ -1951,7 +1951,7 @@ extern "C" int ssc_gemm(const ssc_gemm_desc* d, void* stream) {
   k.crows = nullptr;   // slabs hold compact rows; reduce_slabs_kernel scatters
   SSC_TRY(launch(d, k, splits, st));
   size_t total = (size_t)d->M * d->N;
-  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d->workspace, splits,
+  SSC_LAUNCH(reduce_slabs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d->workspace, splits,
                      k.slab_stride, d->M, d->N, d->C, d->ldc, d->bias, d->accumulate, d->m_count, d->c_rows);
   SSC_CHECK_LAUNCH();
   return SSC_OK;

@@ -499,9 +499,9 @@ inline hipStream_t S(void* s) { return (hipStream_t)s; }
 extern "C" int ssc_feat_prep(const float* feats, int B, int R, int F, float* mask, float* avg, void* stream) {
   if (!feats || !mask || !avg || B <= 0 || R <= 0 || F <= 0) return SSC_EINVAL;
   int BR = B * R;
-  hipLaunchKernelGGL(feat_mask_kernel, dim3(ssc_cdiv(BR, 4)), dim3(256), 0, S(stream), feats, BR, F, mask);
+  SSC_LAUNCH(feat_mask_kernel, dim3(ssc_cdiv(BR, 4)), dim3(256), 0, S(stream), feats, BR, F, mask);
   SSC_CHECK_LAUNCH();
-  hipLaunchKernelGGL(feat_avg_kernel, dim3(ssc_cdiv(F, 256), B), dim3(256), 0, S(stream), feats, mask, R, F, avg);
+  SSC_LAUNCH(feat_avg_kernel, dim3(ssc_cdiv(F, 256), B), dim3(256), 0, S(stream), feats, mask, R, F, avg);
   SSC_CHECK_LAUNCH();
   return SSC_OK;
 }
@@ -509,7 +509,7 @@ extern "C" int ssc_feat_prep(const float* feats, int B, int R, int F, float* mas
 extern "C" int ssc_prep_tokens(const int64_t* caps, int B, int L, int pad, int boundary, int64_t* tokens_tm, float* w_tm,
                                float* nvalid, void* stream) {
   if (!caps || !tokens_tm || !w_tm || !nvalid || B <= 0 || L <= 0) return SSC_EINVAL;
-  hipLaunchKernelGGL(prep_tokens_kernel, dim3(ssc_cdiv(B, 64)), dim3(64), 0, S(stream), caps, B, L, pad, boundary,
+  SSC_LAUNCH(prep_tokens_kernel, dim3(ssc_cdiv(B, 64)), dim3(64), 0, S(stream), caps, B, L, pad, boundary,
                      tokens_tm, w_tm, nvalid);
   SSC_CHECK_LAUNCH();
   return SSC_OK;
@@ -518,7 +518,7 @@ extern "C" int ssc_prep_tokens(const int64_t* caps, int B, int L, int pad, int b
 extern "C" int ssc_embed_gather(const float* table, int ldt, const int64_t* ids, int n, int E, float* out, int ldo,
                                 void* stream) {
   if (!table || !ids || !out || n <= 0 || E <= 0 || ldt < E || ldo < E) return SSC_EINVAL;
-  hipLaunchKernelGGL(embed_gather_kernel, dim3(ssc_cdiv(E, 256), n), dim3(256), 0, S(stream), table, ldt, ids, n, E, out,
+  SSC_LAUNCH(embed_gather_kernel, dim3(ssc_cdiv(E, 256), n), dim3(256), 0, S(stream), table, ldt, ids, n, E, out,
                      ldo);
   SSC_CHECK_LAUNCH();
   return SSC_OK;
@@ -527,7 +527,7 @@ extern "C" int ssc_embed_gather(const float* table, int ldt, const int64_t* ids,
 extern "C" int ssc_embed_scatter_add(float* dtable, int ldt, const int64_t* ids, int n, int E, const float* d, int ldd,
                                      int pad, void* stream) {
   if (!dtable || !ids || !d || n <= 0 || E <= 0 || ldt < E || ldd < E) return SSC_EINVAL;
-  hipLaunchKernelGGL(embed_scatter_kernel, dim3(ssc_cdiv(E, 256), n), dim3(256), 0, S(stream), dtable, ldt, ids, n, E, d,
+  SSC_LAUNCH(embed_scatter_kernel, dim3(ssc_cdiv(E, 256), n), dim3(256), 0, S(stream), dtable, ldt, ids, n, E, d,
                      ldd, pad);
   SSC_CHECK_LAUNCH();
   return SSC_OK;
@@ -538,7 +538,7 @@ extern "C" int ssc_lstm_fwd(const ssc_lstm_fwd_desc* d, void* stream) {
   if (d->nslab > 0 && !d->slabs) return SSC_EINVAL;
   if (d->sent && !d->wcol) return SSC_EINVAL;
   if (d->add1 && d->rows_per_add1 <= 0) return SSC_EINVAL;
-  hipLaunchKernelGGL(lstm_fwd_kernel, dim3(ssc_cdiv(d->H, 128), d->B), dim3(128), 0, S(stream), *d);
+  SSC_LAUNCH(lstm_fwd_kernel, dim3(ssc_cdiv(d->H, 128), d->B), dim3(128), 0, S(stream), *d);
   SSC_CHECK_LAUNCH();
   return SSC_OK;
 }
@@ -546,7 +546,7 @@ extern "C" int ssc_lstm_fwd(const ssc_lstm_fwd_desc* d, void* stream) {
 extern "C" int ssc_lstm_bwd(const ssc_lstm_bwd_desc* d, void* stream) {
   if (!d || d->B <= 0 || d->H <= 0 || !d->gates || !d->c_prev || !d->c_new || !d->dG || !d->dc_prev) return SSC_EINVAL;
   if ((d->nA > 0 && !d->slabsA) || (d->nB > 0 && !d->slabsB) || d->nA < 0 || d->nB < 0) return SSC_EINVAL;
-  hipLaunchKernelGGL(lstm_bwd_kernel, dim3(ssc_cdiv(d->H, 128), d->B), dim3(128), 0, S(stream), *d);
+  SSC_LAUNCH(lstm_bwd_kernel, dim3(ssc_cdiv(d->H, 128), d->B), dim3(128), 0, S(stream), *d);
   SSC_CHECK_LAUNCH();
   return SSC_OK;
 }
@@ -555,7 +555,7 @@ extern "C" int ssc_latent_fwd(const ssc_latent_fwd_desc* d, void* stream) {
   if (!d || d->B <= 0 || d->Z <= 0 || !d->mulv || d->nslab < 1 || !d->bmu || !d->blv || !d->eps || !d->w || !d->mu ||
       !d->lv || !d->z || !d->kld_acc)
     return SSC_EINVAL;
-  hipLaunchKernelGGL(latent_fwd_kernel, dim3(ssc_cdiv(d->B, 4)), dim3(256), 0, S(stream), *d);
+  SSC_LAUNCH(latent_fwd_kernel, dim3(ssc_cdiv(d->B, 4)), dim3(256), 0, S(stream), *d);
   SSC_CHECK_LAUNCH();
   return SSC_OK;
 }
@@ -563,7 +563,7 @@ extern "C" int ssc_latent_fwd(const ssc_latent_fwd_desc* d, void* stream) {
 extern "C" int ssc_latent_prior_sample(const float* eps, int ldeps, const float* sent, float pm_scale, float prior_var,
                                        int G, int Z, float* z, int ldz, void* stream) {
   if (!eps || !z || G <= 0 || Z <= 0) return SSC_EINVAL;
-  hipLaunchKernelGGL(latent_prior_sample_kernel, dim3(ssc_cdiv(Z, 64), G), dim3(64), 0, S(stream), eps, ldeps, sent,
+  SSC_LAUNCH(latent_prior_sample_kernel, dim3(ssc_cdiv(Z, 64), G), dim3(64), 0, S(stream), eps, ldeps, sent,
                      pm_scale, sqrtf(prior_var), G, Z, z, ldz);
   SSC_CHECK_LAUNCH();
   return SSC_OK;
@@ -572,7 +572,7 @@ extern "C" int ssc_latent_prior_sample(const float* eps, int ldeps, const float*
 extern "C" int ssc_latent_bwd(const ssc_latent_bwd_desc* d, void* stream) {
   if (!d || d->B <= 0 || d->Z <= 0 || !d->dz || !d->eps || !d->mu || !d->lv || !d->w || !d->gk || !d->dmulv)
     return SSC_EINVAL;
-  hipLaunchKernelGGL(latent_bwd_kernel, dim3(ssc_cdiv(d->Z, 64), d->B), dim3(64), 0, S(stream), *d);
+  SSC_LAUNCH(latent_bwd_kernel, dim3(ssc_cdiv(d->Z, 64), d->B), dim3(64), 0, S(stream), *d);
   SSC_CHECK_LAUNCH();
   return SSC_OK;
 }
@@ -582,9 +582,9 @@ extern "C" int ssc_ce_fwd(const float* logits, int ldl, const int64_t* targets, 
                           int B, int V, float* lse, float* loss, void* stream) {
   if (!logits || !targets || !w || !nvalid || !lse || !loss || T <= 0 || B <= 0 || V <= 0 || ldl < V) return SSC_EINVAL;
   int rows = T * B;
-  hipLaunchKernelGGL(ce_fwd_kernel, dim3(rows), dim3(256), 0, S(stream), logits, ldl, targets, w, V, lse, lse + rows);
+  SSC_LAUNCH(ce_fwd_kernel, dim3(rows), dim3(256), 0, S(stream), logits, ldl, targets, w, V, lse, lse + rows);
   SSC_CHECK_LAUNCH();
-  hipLaunchKernelGGL(ce_loss_kernel, dim3(ssc_cdiv(B, 64)), dim3(64), 0, S(stream), lse + rows, nvalid, T, B, loss);
+  SSC_LAUNCH(ce_loss_kernel, dim3(ssc_cdiv(B, 64)), dim3(64), 0, S(stream), lse + rows, nvalid, T, B, loss);
   SSC_CHECK_LAUNCH();
   return SSC_OK;
 }
@@ -592,14 +592,14 @@ extern "C" int ssc_ce_fwd(const float* logits, int ldl, const int64_t* targets, 
 extern "C" int ssc_ce_bwd(float* logits, int ldl, const int64_t* targets, const float* w, const float* nvalid,
                           const float* lse, const float* gl, int T, int B, int V, void* stream) {
   if (!logits || !targets || !w || !nvalid || !lse || !gl || T <= 0 || B <= 0 || V <= 0 || ldl < V) return SSC_EINVAL;
-  hipLaunchKernelGGL(ce_bwd_kernel, dim3(T * B), dim3(256), 0, S(stream), logits, ldl, targets, w, nvalid, lse, gl, B, V);
+  SSC_LAUNCH(ce_bwd_kernel, dim3(T * B), dim3(256), 0, S(stream), logits, ldl, targets, w, nvalid, lse, gl, B, V);
   SSC_CHECK_LAUNCH();
   return SSC_OK;
 }
 
 extern "C" int ssc_log_softmax(const float* logits, int ldl, int rows, int V, float* out, int ldo, void* stream) {
   if (!logits || !out || rows <= 0 || V <= 0 || ldl < V || ldo < V) return SSC_EINVAL;
-  hipLaunchKernelGGL(log_softmax_kernel, dim3(rows), dim3(256), 0, S(stream), logits, ldl, V, out, ldo);
+  SSC_LAUNCH(log_softmax_kernel, dim3(rows), dim3(256), 0, S(stream), logits, ldl, V, out, ldo);
   SSC_CHECK_LAUNCH();
   return SSC_OK;
 }
@@ -609,15 +609,15 @@ extern "C" int ssc_colsum2(const float* X, int ldx, int rows, int N, const float
                            float* out2, int accumulate, float* scratch, void* stream) {
   if (!X || !out || rows <= 0 || N <= 0 || ldx < N || out_stride < 1) return SSC_EINVAL;
   if (rows >= 64 && scratch) {
-    hipLaunchKernelGGL(colsum_stage1_kernel, dim3(ssc_cdiv(N, 256), COLSUM_CHUNKS), dim3(256), 0, S(stream), X, ldx, rows, N,
+    SSC_LAUNCH(colsum_stage1_kernel, dim3(ssc_cdiv(N, 256), COLSUM_CHUNKS), dim3(256), 0, S(stream), X, ldx, rows, N,
                        wrow, scratch);
     SSC_CHECK_LAUNCH();
-    hipLaunchKernelGGL(colsum_stage2_kernel, dim3(ssc_cdiv(N, 64)), dim3(256), 0, S(stream), scratch, N, out, out_stride,
+    SSC_LAUNCH(colsum_stage2_kernel, dim3(ssc_cdiv(N, 64)), dim3(256), 0, S(stream), scratch, N, out, out_stride,
                        out2, accumulate);
     SSC_CHECK_LAUNCH();
     return SSC_OK;
   }
-  hipLaunchKernelGGL(colsum_kernel, dim3(ssc_cdiv(N, 256)), dim3(256), 0, S(stream), X, ldx, rows, N, wrow, out, out_stride,
+  SSC_LAUNCH(colsum_kernel, dim3(ssc_cdiv(N, 256)), dim3(256), 0, S(stream), X, ldx, rows, N, wrow, out, out_stride,
                      out2, accumulate);
   SSC_CHECK_LAUNCH();
   return SSC_OK;
@@ -630,21 +630,21 @@ extern "C" int ssc_colsum(const float* X, int ldx, int rows, int N, const float*
 
 extern "C" int ssc_copy_strided(const float* src, size_t stride, int n, float* dst, void* stream) {
   if (!src || !dst || n <= 0) return SSC_EINVAL;
-  hipLaunchKernelGGL(copy_strided_kernel, dim3(ssc_cdiv(n, 256)), dim3(256), 0, S(stream), src, stride, n, dst);
+  SSC_LAUNCH(copy_strided_kernel, dim3(ssc_cdiv(n, 256)), dim3(256), 0, S(stream), src, stride, n, dst);
   SSC_CHECK_LAUNCH();
   return SSC_OK;
 }
 
 extern "C" int ssc_bias_tanh(float* x, int ldx, int rows, int N, const float* bias, void* stream) {
   if (!x || rows <= 0 || N <= 0 || ldx < N) return SSC_EINVAL;
-  hipLaunchKernelGGL(bias_tanh_kernel, dim3(ssc_cdiv(N, 256), rows), dim3(256), 0, S(stream), x, ldx, N, bias);
+  SSC_LAUNCH(bias_tanh_kernel, dim3(ssc_cdiv(N, 256), rows), dim3(256), 0, S(stream), x, ldx, N, bias);
   SSC_CHECK_LAUNCH();
   return SSC_OK;
 }
 
 extern "C" int ssc_tanh_bwd(float* dy, int lddy, const float* y, int ldy, int rows, int N, void* stream) {
   if (!dy || !y || rows <= 0 || N <= 0) return SSC_EINVAL;
-  hipLaunchKernelGGL(tanh_bwd_kernel, dim3(ssc_cdiv(N, 256), rows), dim3(256), 0, S(stream), dy, lddy, y, ldy, N);
+  SSC_LAUNCH(tanh_bwd_kernel, dim3(ssc_cdiv(N, 256), rows), dim3(256), 0, S(stream), dy, lddy, y, ldy, N);
   SSC_CHECK_LAUNCH();
   return SSC_OK;
 }
@@ -654,7 +654,7 @@ extern "C" int ssc_fill(float* p, size_t n, float v, void* stream) {
   if (n == 0) return SSC_OK;
   size_t blocks = (n + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(fill_kernel, dim3((unsigned)blocks), dim3(256), 0, S(stream), p, n, v);
+  SSC_LAUNCH(fill_kernel, dim3((unsigned)blocks), dim3(256), 0, S(stream), p, n, v);
   SSC_CHECK_LAUNCH();
   return SSC_OK;
 }
@@ -662,9 +662,9 @@ extern "C" int ssc_fill(float* p, size_t n, float v, void* stream) {
 extern "C" int ssc_sq_norm(const float* g, size_t n, float* scratch, float* out, void* stream) {
   if (!g || !scratch || !out) return SSC_EINVAL;
   const int nb = 1024;
-  hipLaunchKernelGGL(sq_norm_partial_kernel, dim3(nb), dim3(256), 0, S(stream), g, n, scratch);
+  SSC_LAUNCH(sq_norm_partial_kernel, dim3(nb), dim3(256), 0, S(stream), g, n, scratch);
   SSC_CHECK_LAUNCH();
-  hipLaunchKernelGGL(sq_norm_final_kernel, dim3(1), dim3(256), 0, S(stream), scratch, nb, out);
+  SSC_LAUNCH(sq_norm_final_kernel, dim3(1), dim3(256), 0, S(stream), scratch, nb, out);
   SSC_CHECK_LAUNCH();
   return SSC_OK;
 }
@@ -675,7 +675,7 @@ extern "C" int ssc_sgd_step(float* p, const float* g, float* buf, size_t n, cons
   if (n == 0) return SSC_OK;
   size_t blocks = (n + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)blocks), dim3(256), 0, S(stream), p, g, buf, n, sqnorm, gscale, max_norm,
+  SSC_LAUNCH(sgd_kernel, dim3((unsigned)blocks), dim3(256), 0, S(stream), p, g, buf, n, sqnorm, gscale, max_norm,
                      lr, momentum, weight_decay, first);
   SSC_CHECK_LAUNCH();
   return SSC_OK;

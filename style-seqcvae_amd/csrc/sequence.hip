@@ -221,7 +221,7 @@ __global__ void add2d_kernel(const float* __restrict__ a, int lda, const float* 
   if (x < cols) o[(size_t)r * ldo + x] = a[(size_t)r * lda + x] + b[(size_t)r * ldb + x];
 }
 int add2d(const float* a, int lda, const float* b, int ldb, int rows, int cols, float* o, int ldo, hipStream_t st) {
-  hipLaunchKernelGGL(add2d_kernel, dim3(ssc_cdiv(cols, 256), rows), dim3(256), 0, st, a, lda, b, ldb, cols, o, ldo);
+  SSC_LAUNCH(add2d_kernel, dim3(ssc_cdiv(cols, 256), rows), dim3(256), 0, st, a, lda, b, ldb, cols, o, ldo);
   SSC_CHECK_LAUNCH();
   return SSC_OK;
 }
@@ -301,7 +301,7 @@ extern "C" int ssc_train_fwd(const ssc_model_cfg* cfg, const ssc_params* p, cons
   // ---- per-sequence precompute --------------------------------------------------------------
   SSC_TRY(ssc_prep_tokens(bt->caps, B, l.L, cfg->pad, cfg->boundary, tok, W + l.w, W + l.nvalid, st));
   int* act = (int*)(W + l.act);
-  hipLaunchKernelGGL(build_active_rows_kernel, dim3(1), dim3(1024), 0, st, W + l.w, TB, act);
+  SSC_LAUNCH(build_active_rows_kernel, dim3(1), dim3(1024), 0, st, W + l.w, TB, act);
   SSC_CHECK_LAUNCH();
   c.act_count = act; c.act_rows = act + 4;
   SSC_TRY(ssc_feat_prep(bt->feats, B, R, F, W + l.mask, W + l.avg, st));
@@ -581,7 +581,7 @@ static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const s
   }
 
   if (S) {  // sentiment replicated over time (row = t*B+b) for the rank-1 column gradients
-    hipLaunchKernelGGL(repeat_kernel, dim3(ssc_cdiv(TB, 256)), dim3(256), 0, st, bt->sentiment, B, T, W + l.sent_all);
+    SSC_LAUNCH(repeat_kernel, dim3(ssc_cdiv(TB, 256)), dim3(256), 0, st, bt->sentiment, B, T, W + l.sent_all);
     SSC_CHECK_LAUNCH();
   }
   }  // phase 1

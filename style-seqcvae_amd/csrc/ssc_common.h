@@ -8,6 +8,15 @@
 
 extern thread_local int ssc_tls_hip_error;
 
+// Every kernel launch goes through SSC_LAUNCH: the thread's sticky HIP error is cleared first, so that SSC_CHECK_LAUNCH
+// reports THIS launch and not an error some earlier, unrelated HIP call of the process left behind (seen: hipError 100
+// from the host framework's device probing made the first launch of a process "fail").
+#define SSC_LAUNCH(...)              \
+  do {                               \
+    (void)hipGetLastError();         \
+    hipLaunchKernelGGL(__VA_ARGS__); \
+  } while (0)
+
 #define SSC_CHECK_LAUNCH()                         \
   do {                                             \
     hipError_t e__ = hipGetLastError();            \

@@ -187,6 +187,10 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} not found: build it with `python style-seqcvae_amd/build.py` "
                               "(the HIP extension is mandatory; there is no CPU fallback)")
+        # PyTorch-ROCm ships its own HIP runtime.  It must be in the process BEFORE this library is loaded, so that both
+        # resolve to the same runtime instance; loaded the other way round the library binds the system runtime and every
+        # launch on a torch stream fails with hipErrorNoDevice (100).
+        import torch  # noqa: F401
         _lib = _Lib(C.CDLL(LIB_PATH))
     return _lib
 
