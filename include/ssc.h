@@ -359,7 +359,8 @@ int ssc_decode_step(const ssc_model_cfg* cfg, const ssc_params* p, const ssc_dec
  *                    masked (-1e20) top-`per_node` per row, + running log-prob, top-`beam` over S*beam*per_node;
  *                    backpointer = idx / per_node (floor).  Ties resolve to the lowest index.
  *   ssc_gather_rows: state re-ordering by backpointer (:236-250).
- * fsm (B,S,S,V) uint8.  Row order (batch, fsm_state, beam).
+ * fsm (B,S,S,V) uint8, or NULL with S = 1 for the trivial one-state machine (every transition allowed; what
+ * MAX_GIVEN_CONSTRAINTS: 0 produces).  Row order (batch, fsm_state, beam).
  * ---------------------------------------------------------------------------------------------- */
 int ssc_beam_first(const float* log_probs, int ldlp, const uint8_t* fsm, int B, int S, int V, int beam,
                    int64_t* pred, float* lp_out, void* stream);

@@ -174,12 +174,12 @@ __global__ __launch_bounds__(256) void beam_first_kernel(const float* __restrict
   int b = blockIdx.x / S, s = blockIdx.x % S;
   float lse;
   const float* row = row_prepare<NORM>(lp + (size_t)b * ldlp, V, staged != 0, srow, shr, lse);
-  const uint8_t* m = fsm + (((size_t)b * S + 0) * S + s) * V;
+  const uint8_t* m = fsm ? fsm + (((size_t)b * S + 0) * S + s) * V : nullptr;   // nullptr: the trivial one-state machine
   Cand prev{INFINITY, -1};
   for (int k = 0; k < beam; ++k) {
     Cand best{-INFINITY, -1};
     for (int v = threadIdx.x; v < V; v += blockDim.x) {
-      float x = m[v] ? (NORM ? row[v] - lse : row[v]) : -INFINITY;
+      float x = (!m || m[v]) ? (NORM ? row[v] - lse : row[v]) : -INFINITY;
       bool after_prev = (prev.i < 0) || (x < prev.v) || (x == prev.v && v > prev.i);
       if (after_prev && (best.i < 0 || better(x, v, best))) best = Cand{x, v};
     }
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void beam_row_topk_kernel(const float* __restr
   __shared__ float shr[16];
   int g = blockIdx.x, i = blockIdx.y;
   int b = g / (S * beam), s = (g / beam) % S, k = g % beam;
-  const uint8_t* m = fsm + (((size_t)b * S + s) * S + i) * V;
+  const uint8_t* m = fsm ? fsm + (((size_t)b * S + s) * S + i) * V : nullptr;
   bool ended = last_pred[g] == end_index;   // workgroup-uniform; an ended beam never looks at its row
   float lse = 0.f;
   const float* row = lp + (size_t)g * ldlp;
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void beam_row_topk_kernel(const float* __restr
     Cand best{-INFINITY, -1};
     for (int v = threadIdx.x; v < V; v += blockDim.x) {
       float x;
-      if (!m[v]) x = -1e20f;
+      if (m && !m[v]) x = -1e20f;
       else if (ended) x = v == end_index ? 0.f : -INFINITY;
       else x = NORM ? row[v] - lse : row[v];
       bool after_prev = (prev.i < 0) || (x < prev.v) || (x == prev.v && v > prev.i);
@@ -409,7 +409,7 @@ namespace {
 constexpr size_t BEAM_STAGE_MAX = 64 * 1024;   // a vocabulary row is staged in LDS up to this size
 int beam_first_impl(bool norm, const float* lp, int ldlp, const uint8_t* fsm, int B, int S, int V, int beam, int64_t* pred,
                     float* lp_out, hipStream_t st) {
-  if (!lp || !fsm || !pred || !lp_out || B <= 0 || S <= 0 || V <= 0 || beam <= 0 || beam > V || ldlp < V) return SSC_EINVAL;
+  if (!lp || (!fsm && S != 1) || !pred || !lp_out || B <= 0 || S <= 0 || V <= 0 || beam <= 0 || beam > V || ldlp < V) return SSC_EINVAL;
   const int staged = norm && (size_t)V * sizeof(float) <= BEAM_STAGE_MAX;
   const size_t lds = staged ? (size_t)V * sizeof(float) : 0;
   if (norm) SSC_LAUNCH(beam_first_kernel<true>, dim3(B * S), dim3(256), lds, st, lp, ldlp, fsm, S, V, beam, pred, lp_out, staged);
@@ -420,7 +420,7 @@ int beam_first_impl(bool norm, const float* lp, int ldlp, const uint8_t* fsm, in
 int beam_step_impl(bool norm, const float* lp, int ldlp, const uint8_t* fsm, const int64_t* last_pred, const float* last_lp, int B,
                    int S, int V, int beam, int per_node, int end_index, int64_t* pred, float* lp_out, int64_t* backptr,
                    float* scratch_val, int64_t* scratch_idx, hipStream_t st) {
-  if (!lp || !fsm || !last_pred || !last_lp || !pred || !lp_out || !backptr || !scratch_val || !scratch_idx) return SSC_EINVAL;
+  if (!lp || (!fsm && S != 1) || !last_pred || !last_lp || !pred || !lp_out || !backptr || !scratch_val || !scratch_idx) return SSC_EINVAL;
   if (B <= 0 || S <= 0 || V <= 0 || beam <= 0 || per_node <= 0 || per_node > V || ldlp < V || end_index < 0 ||
       end_index >= V || beam > S * beam * per_node)
     return SSC_EINVAL;

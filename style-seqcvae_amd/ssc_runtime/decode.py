@@ -113,10 +113,13 @@ def cbs_search(start_predictions: torch.Tensor, start_state, step: Callable, fsm
     beam_first = lib.ssc_beam_first_logits if raw_logits else lib.ssc_beam_first
     beam_step = lib.ssc_beam_step_logits if raw_logits else lib.ssc_beam_step
     st = _lib.stream_ptr
-    B, S, _, V = fsm.shape
     dev = start_predictions.device
-    assert fsm.is_cuda and fsm.dtype == torch.uint8
-    fsm = fsm.contiguous()
+    if fsm is None:   # the trivial one-state machine (every transition allowed): no mask is read on the device
+        B, S, V = start_predictions.numel(), 1, None
+    else:
+        B, S, _, V = fsm.shape
+        assert fsm.is_cuda and fsm.dtype == torch.uint8
+        fsm = fsm.contiguous()
     SB = S * beam_size
     preds = torch.empty(max_steps, B, SB, dtype=torch.int64, device=dev)
     backs = torch.empty(max(max_steps - 1, 1), B, SB, dtype=torch.int64, device=dev)
@@ -124,6 +127,8 @@ def cbs_search(start_predictions: torch.Tensor, start_state, step: Callable, fsm
     out = step(start_predictions, start_state)
     lp0, state = out[0], out[1]
     lp0 = lp0.contiguous()
+    if V is None:
+        V = lp0.shape[1]
     assert lp0.shape == (B, V), lp0.shape
     beam_first(_lib.ptr(lp0), lp0.stride(0), _lib.ptr(fsm), B, S, V, beam_size, _lib.ptr(preds[0]), _lib.ptr(last_lp),
                        st())

@@ -30,8 +30,8 @@ def diverse_decode(dec: DecodeEngine, feats: torch.Tensor, sentiment: Optional[t
     d = dec.dims
     B = nimg * n_samples
     ctx = dec.prepare(feats)
-    if fsm is None:
-        fsm = torch.ones(B, 1, 1, d.V, dtype=torch.uint8, device=dev)
+    trivial = fsm is None   # one-state machine: cbs_search(fsm=None) reads no mask at all
+    if trivial:
         num_constraints = torch.zeros(B, dtype=torch.long)
     sent_b = sentiment.reshape(nimg, 1).expand(nimg, n_samples).reshape(B) if sentiment is not None else None
     calls = {"k": 0}
@@ -50,7 +50,7 @@ def diverse_decode(dec: DecodeEngine, feats: torch.Tensor, sentiment: Optional[t
     start = torch.full((B,), boundary_index, dtype=torch.long, device=dev)
     beams, lps = cbs_search(start, None, step, fsm, boundary_index, max_steps, beam, per_node or (beam // 2) or beam,
                             early_stop=early_stop, early_stop_every=4, raw_logits=_RAW)
-    if fsm.size(1) == 1:
+    if trivial or fsm.size(1) == 1:
         best = beams[:, 0, 0, :]
     else:
         best, _ = select_best_beam_with_constraints(beams, lps, num_constraints, None, None, min_constraints_to_satisfy, True)

@@ -192,3 +192,21 @@ def test_beam_selection_from_raw_logits_is_bit_identical(B, S, V, beam, per_node
         res.append((pred.clone(), nlp.clone(), back.clone()))
     for a, b in zip(res[0], res[1]):
         assert torch.equal(a, b)
+
+
+def test_trivial_fsm_none_equals_all_ones_mask():
+    """cbs_search(fsm=None) - the trivial one-state machine, no mask read on the device - gives exactly the result of an
+    explicit all-ones (B,1,1,V) mask."""
+    from ssc_runtime.decode import cbs_search
+    B, V, beam, steps = 4, 300, 3, 6
+    g = torch.Generator().manual_seed(21)
+    table = (torch.randn(V, V, generator=g) * 2).cuda()     # next-token logits as a function of the previous token
+
+    def step(tokens, state):
+        return torch.log_softmax(table[tokens], dim=1), {"h": torch.zeros(tokens.numel(), 2, device="cuda")}
+
+    start = torch.full((B,), 1, dtype=torch.long, device="cuda")
+    ones = torch.ones(B, 1, 1, V, dtype=torch.uint8, device="cuda")
+    a, alp = cbs_search(start, None, step, ones, 1, steps, beam, 2)
+    b, blp = cbs_search(start, None, step, None, 1, steps, beam, 2)
+    assert torch.equal(a, b) and torch.equal(alp, blp)
