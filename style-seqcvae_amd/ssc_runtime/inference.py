@@ -45,7 +45,9 @@ def diverse_decode(dec: DecodeEngine, feats: torch.Tensor, sentiment: Optional[t
             eps = torch.randn(G, d.Z, device=dev)
         calls["k"] += 1
         lp, st, alpha = dec.step(ctx, tokens, state, sent_rows, eps, raw_logits=_RAW)
-        return lp, st
+        # the eval cell never touches the encoder-LSTM states (updown_cell.py:200-203): do not carry (and re-order by
+        # backpointer) two (G,H) tensors the next step will not read
+        return lp, {k: v for k, v in st.items() if k not in ("h_encoder", "c_encoder")}
 
     start = torch.full((B,), boundary_index, dtype=torch.long, device=dev)
     beams, lps = cbs_search(start, None, step, fsm, boundary_index, max_steps, beam, per_node or (beam // 2) or beam,
