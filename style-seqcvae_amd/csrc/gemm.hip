@@ -1461,7 +1461,7 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
 // the three hidden-state gradients BPTT carries to step t-1 (each alone covers 150 of the 256 CUs and pays its own
 // ramp); a single product is a group of one.  Workgroup w belongs to the product p with first[p] <= w < first[p+1];
 // inside it the usual (tile, split) decomposition applies.
-constexpr int SSC_GROUP_MAX = 3;
+constexpr int SSC_GROUP_MAX = 6;
 struct KGroup {
   KArgs a[SSC_GROUP_MAX];
   int n;
@@ -1912,6 +1912,67 @@ int ssc_gemm_slabs_group(const ssc_gemm_desc* const* d, int n, float* const* reg
   else SSC_LAUNCH((gemm_x3w_kernel<true, false, false, 64, 256, 2>), dim3(g.first[n]), dim3(512), (x3w_lds_bytes<64, 256>()), st, g);
   if (rec) (void)hipEventRecord(rec->e1, st);
   SSC_CHECK_LAUNCH();
+  return SSC_OK;
+}
+
+// n independent LARGE products C_i = A_i^T B_i (the weight gradients of one backward phase) with direct outputs: the
+// eligible ones (3xBF16 mode, 16-B operands, m/n-contiguous single segment, all with or all without k-row gather lists)
+// go out as grouped launches of the wave-specialised 128x128 kernel - several rounds of workgroups per launch, so its one
+// workgroup per CU no longer loses to tile quantisation (380 tiles on 256 CUs) - the others one by one.
+int ssc_gemm_dw_group(const ssc_gemm_desc* const* d, int n, hipStream_t st) {
+  if (!d || n < 1) return SSC_EINVAL;
+  static const bool group_on = !(getenv("SSC_GEMM_GROUP") && atoi(getenv("SSC_GEMM_GROUP")) == 0);   // A/B switch (tools)
+  int i = 0;
+  while (i < n) {
+    KGroup g;
+    int m = 0;
+    bool kg0 = false;
+    long Ksum = 0, MN = 0;
+    int j = i;
+    for (; j < n && m < SSC_GROUP_MAX; ++j) {
+      const ssc_gemm_desc* dj = d[j];
+      KArgs& k = g.a[m];
+      SSC_TRY(build_args(dj, k));
+      const bool vec = k.nseg == 1 && k.seg[0].avec && k.seg[0].bvec;
+      const bool kg = k.karows || k.kbrows;
+      const bool ok = group_on && gemm_mode() == 1 && vec && !dj->a_kc && !dj->b_kc && dj->C && dj->ldc >= dj->N && !k.mcount &&
+                      !k.arows && !k.crows && (kg ? (k.kcount && k.karows && k.kbrows) : !k.kcount) && (m == 0 || kg == kg0);
+      if (!ok) break;
+      kg0 = kg;
+      k.steps_per_split = k.steps_total;
+      k.out = dj->C; k.ldo = dj->ldc; k.slab_stride = 0; k.bias = dj->bias; k.accumulate = dj->accumulate;
+      {
+        static const int dbg = getenv("SSC_GEMM_DBG") ? atoi(getenv("SSC_GEMM_DBG")) : 0;
+        k.dbg = dbg;
+      }
+      g.gx[m] = ssc_cdiv(dj->N, 128); g.gy[m] = ssc_cdiv(dj->M, 128); g.gz[m] = 1;
+      if (m == 0) g.first[0] = 0;
+      g.first[m + 1] = g.first[m] + g.gx[m] * g.gy[m];
+      Ksum = dj->seg[0].K; MN += (long)dj->M * dj->N;
+      ++m;
+    }
+    if (m >= 2) {
+      g.n = m;
+      g.first[0] = 0;
+      for (int q = m; q < SSC_GROUP_MAX; ++q) { g.first[q + 1] = g.first[m]; g.gx[q] = g.gy[q] = g.gz[q] = 1; }
+      SSC_TRY(x3w_prepare());
+      ProfRec* rec = nullptr;
+      if (g_prof_on && g_prof && g_prof_n < PROF_MAX) {  // one record: 2*K*sum(M_i N_i) flops
+        rec = &g_prof[g_prof_n++];
+        rec->kind = 3;
+        rec->M = (int)(MN / d[i]->N); rec->N = d[i]->N; rec->splits = 1; rec->K = (int)Ksum;
+        (void)hipEventRecord(rec->e0, st);
+      }
+      if (kg0) SSC_LAUNCH((gemm_x3w_kernel<false, false, true, 128, 128, 1>), dim3(g.first[m]), dim3(512), (x3w_lds_bytes<128, 128>()), st, g);
+      else SSC_LAUNCH((gemm_x3w_kernel<false, false, false, 128, 128, 2>), dim3(g.first[m]), dim3(512), (x3w_lds_bytes<128, 128>()), st, g);
+      if (rec) (void)hipEventRecord(rec->e1, st);
+      SSC_CHECK_LAUNCH();
+      i += m;
+    } else {  // a single eligible product gains nothing from the group form; ineligible ones take the usual path
+      SSC_TRY(ssc_gemm(d[i], (void*)st));
+      ++i;
+    }
+  }
   return SSC_OK;
 }
 

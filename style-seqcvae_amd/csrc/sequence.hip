@@ -12,6 +12,7 @@
 //  * torch.cat inputs never built: each K-segment of a gate GEMM reads its own source buffer;
 //  * vocabulary projection + CE over all T steps at once (M = T*B);
 //  * every weight gradient is one GEMM with K = T*B after the time loop.
+#include <cstdlib>
 #include <initializer_list>
 
 #include "ssc_common.h"
@@ -165,19 +166,58 @@ int gemm_rows(const Ctx& c, bool b_kc, std::initializer_list<Seg> segs, int M, i
   }
   return ssc_gemm(&d, c.st);
 }
-int gemm_dw(const Ctx& c, const float* A, int lda, const float* Bm, int ldb, int K, int M, int N, float* C, int ldc) {
-  ssc_gemm_desc d;
+// The weight-gradient products of a backward phase are independent of each other: they are queued and issued together
+// (ssc_gemm_dw_group: grouped launches of the wave-specialised kernel, several rounds of workgroups each).
+struct DwBatch {
+  static constexpr int MAX = 16;
+  ssc_gemm_desc d[MAX];
+  int n = 0;
+};
+int queue_dw(const Ctx& c, DwBatch& q, const float* A, int lda, const float* Bm, int ldb, int K, int M, int N, float* C, int ldc) {
+  if (q.n >= DwBatch::MAX) return SSC_EINVAL;
+  ssc_gemm_desc& d = q.d[q.n++];
   fill_desc(d, false, false, {{A, lda, Bm, ldb, K}}, M, N);
   d.C = C; d.ldc = ldc;
   d.splits = 0;
   d.workspace = c.slabs; d.workspace_floats = c.slab_floats;
-  if (c.act_rows) {
-    d.k_count = c.act_count; d.ka_rows = c.act_rows; d.kb_rows = c.act_rows;
-    const int rc = ssc_gemm(&d, c.st);
-    if (rc != SSC_EALIGN && rc != SSC_EINVAL) return rc;
-    d.k_count = d.ka_rows = d.kb_rows = nullptr;
+  if (c.act_rows) { d.k_count = c.act_count; d.ka_rows = c.act_rows; d.kb_rows = c.act_rows; }
+  return SSC_OK;
+}
+int flush_dw(const Ctx& c, DwBatch& q) {
+  if (!q.n) return SSC_OK;
+  const ssc_gemm_desc* dp[DwBatch::MAX];
+  for (int i = 0; i < q.n; ++i) dp[i] = &q.d[i];
+  // row compaction needs the 3xBF16 kernels and 16-B operands: a product that does not qualify runs over all rows
+  for (int i = 0; i < q.n; ++i) {
+    ssc_gemm_desc& d = q.d[i];
+    const bool al = ssc_aligned16(d.seg[0].A) && ssc_aligned16(d.seg[0].B) && !(d.seg[0].lda & 3) && !(d.seg[0].ldb & 3) && !(d.M & 3) && !(d.N & 3);
+    if (!al) d.k_count = d.ka_rows = d.kb_rows = nullptr;
   }
-  return ssc_gemm(&d, c.st);
+  static const bool grouped = !(getenv("SSC_DW_GROUP") && atoi(getenv("SSC_DW_GROUP")) == 0);   // A/B switch (tools)
+  if (!grouped) {
+    int rc1 = SSC_OK;
+    for (int i = 0; i < q.n && rc1 == SSC_OK; ++i) {
+      rc1 = ssc_gemm(&q.d[i], c.st);
+      if (rc1 == SSC_EINVAL || rc1 == SSC_EALIGN) {
+        q.d[i].k_count = q.d[i].ka_rows = q.d[i].kb_rows = nullptr;
+        rc1 = ssc_gemm(&q.d[i], c.st);
+      }
+    }
+    q.n = 0;
+    return rc1;
+  }
+  int rc = ssc_gemm_dw_group(dp, q.n, c.st);
+  if (rc == SSC_EINVAL || rc == SSC_EALIGN) {  // e.g. the exact-fp32 mode refuses compaction: whole sums instead
+    for (int i = 0; i < q.n; ++i) q.d[i].k_count = q.d[i].ka_rows = q.d[i].kb_rows = nullptr;
+    rc = ssc_gemm_dw_group(dp, q.n, c.st);
+  }
+  q.n = 0;
+  return rc;
+}
+int gemm_dw(const Ctx& c, const float* A, int lda, const float* Bm, int ldb, int K, int M, int N, float* C, int ldc) {
+  DwBatch q;
+  SSC_TRY(queue_dw(c, q, A, lda, Bm, ldb, K, M, N, C, ldc));
+  return flush_dw(c, q);
 }
 
 // ascending list of the rows t*B+b whose target token is not padding (w = 1); one workgroup, ordered block scan
@@ -593,13 +633,23 @@ static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const s
   const float* hd_prev = W + l.hd; const float* he_prev = W + l.he; const float* he_new = W + l.he + sH;
   const float* att = W + l.att;
   if (phases & 2u) {
+  {  // all weight-gradient products of this phase at once (grouped launches)
+    DwBatch q;
+    if (g->att_w_ih) {
+      float* gw = g->att_w_ih; int ld = g->ld_att_w_ih;
+      SSC_TRY(queue_dw(c, q, dga, H4, W + l.emb, l.Ep, TB, H4, E, gw, ld));
+      SSC_TRY(queue_dw(c, q, dga, H4, h1_prev, l.Hp, TB, H4, H, gw + E + F, ld));
+      SSC_TRY(queue_dw(c, q, dga, H4, hd_prev, l.Hp, TB, H4, H, gw + E + F + H, ld));
+    } else if (g->att_w_hh) {
+      SSC_TRY(queue_dw(c, q, dga, H4, h1_prev, l.Hp, TB, H4, H, g->att_w_hh, g->ld_att_w_hh));
+    }
+    if (g->wq) SSC_TRY(queue_dw(c, q, W + l.dq, l.Ap, h1_new, l.Hp, TB, A, H, g->wq, g->ld_wq));
+    SSC_TRY(flush_dw(c, q));
+  }
   // attention LSTM
   if (g->att_w_ih) {
     float* gw = g->att_w_ih; int ld = g->ld_att_w_ih;
-    SSC_TRY(gemm_dw(c, dga, H4, W + l.emb, l.Ep, TB, H4, E, gw, ld));
     SSC_TRY(gemm(c, false, false, {{W + l.dga_sum, H4, W + l.avg, F, B}}, H4, F, gw + E, ld));
-    SSC_TRY(gemm_dw(c, dga, H4, h1_prev, l.Hp, TB, H4, H, gw + E + F, ld));
-    SSC_TRY(gemm_dw(c, dga, H4, hd_prev, l.Hp, TB, H4, H, gw + E + F + H, ld));
   }
   if (g->att_w_hh) {
     // dW_hh^att = dGa^T H1_prev is the same product as the h1' block of dW_ih^att (both multiply h1'): copy, do not recompute
@@ -608,8 +658,6 @@ static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const s
                            (size_t)g->ld_att_w_ih * sizeof(float), (size_t)H * sizeof(float), H4, hipMemcpyDeviceToDevice,
                            st) != hipSuccess)
         return SSC_EHIP;
-    } else {
-      SSC_TRY(gemm_dw(c, dga, H4, h1_prev, l.Hp, TB, H4, H, g->att_w_hh, g->ld_att_w_hh));
     }
   }
   if (g->att_b_ih && g->att_b_hh) {
@@ -627,20 +675,28 @@ static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const s
     SSC_TRY(ssc_embed_scatter_add(g->emb, g->ld_emb, tok, TB, E, W + l.demb, l.Ep, cfg->pad, st));
   }
   // attention projections
-  if (g->wq) SSC_TRY(gemm_dw(c, W + l.dq, l.Ap, h1_new, l.Hp, TB, A, H, g->wq, g->ld_wq));
   if (g->wv) SSC_TRY(gemm(c, false, false, {{W + l.dpv, A, bt->feats, F, B * R}}, A, F, g->wv, g->ld_wv));
   if (g->wa) SSC_TRY(ssc_colsum(W + l.dwa, A, B, A, nullptr, g->wa, 1, 0, st));
   }  // phase 2
   if (phases & 4u) {
+  {
+    DwBatch q;
+    if (g->enc_w_ih) {
+      float* gw = g->enc_w_ih; int ld = g->ld_enc_w_ih;
+      SSC_TRY(queue_dw(c, q, dge, H4, att, l.Fp, TB, H4, F, gw, ld));
+      SSC_TRY(queue_dw(c, q, dge, H4, h1_new, l.Hp, TB, H4, H, gw + F, ld));
+      SSC_TRY(queue_dw(c, q, dge, H4, hd_prev, l.Hp, TB, H4, H, gw + F + H, ld));
+    }
+    if (g->enc_w_hh) SSC_TRY(queue_dw(c, q, dge, H4, he_prev, l.Hp, TB, H4, H, g->enc_w_hh, g->ld_enc_w_hh));
+    if (g->fc_mean_w) SSC_TRY(queue_dw(c, q, W + l.dmulv, 2 * Z, he_new, l.Hp, TB, Z, H, g->fc_mean_w, g->ld_fc_mean_w));
+    if (g->fc_lv_w) SSC_TRY(queue_dw(c, q, W + l.dmulv + Z, 2 * Z, he_new, l.Hp, TB, Z, H, g->fc_lv_w, g->ld_fc_lv_w));
+    SSC_TRY(flush_dw(c, q));
+  }
   // encoder LSTM
   if (g->enc_w_ih) {
     float* gw = g->enc_w_ih; int ld = g->ld_enc_w_ih;
-    SSC_TRY(gemm_dw(c, dge, H4, att, l.Fp, TB, H4, F, gw, ld));
-    SSC_TRY(gemm_dw(c, dge, H4, h1_new, l.Hp, TB, H4, H, gw + F, ld));
-    SSC_TRY(gemm_dw(c, dge, H4, hd_prev, l.Hp, TB, H4, H, gw + F + H, ld));
     if (S) SSC_TRY(ssc_colsum2(dge, H4, TB, H4, W + l.sent_all, gw + F + 2 * H, ld, nullptr, 0, c.slabs, st));
   }
-  if (g->enc_w_hh) SSC_TRY(gemm_dw(c, dge, H4, he_prev, l.Hp, TB, H4, H, g->enc_w_hh, g->ld_enc_w_hh));
   if (g->enc_b_ih && g->enc_b_hh) {
     SSC_TRY(ssc_colsum2(dge, H4, TB, H4, nullptr, g->enc_b_ih, 1, g->enc_b_hh, 0, c.slabs, st));
   } else {
@@ -649,20 +705,27 @@ static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const s
   }
   // latent heads
   const float* dmulv = W + l.dmulv;
-  if (g->fc_mean_w) SSC_TRY(gemm_dw(c, dmulv, 2 * Z, he_new, l.Hp, TB, Z, H, g->fc_mean_w, g->ld_fc_mean_w));
-  if (g->fc_lv_w) SSC_TRY(gemm_dw(c, dmulv + Z, 2 * Z, he_new, l.Hp, TB, Z, H, g->fc_lv_w, g->ld_fc_lv_w));
   if (g->fc_mean_b) SSC_TRY(ssc_colsum2(dmulv, 2 * Z, TB, Z, nullptr, g->fc_mean_b, 1, nullptr, 0, c.slabs, st));
   if (g->fc_lv_b) SSC_TRY(ssc_colsum2(dmulv + Z, 2 * Z, TB, Z, nullptr, g->fc_lv_b, 1, nullptr, 0, c.slabs, st));
   }  // phase 4
   if (phases & 8u) {
+  {
+    DwBatch q;
+    if (g->dec_w_ih) {
+      float* gw = g->dec_w_ih; int ld = g->ld_dec_w_ih;
+      SSC_TRY(queue_dw(c, q, dgd, H4, att, l.Fp, TB, H4, F, gw, ld));
+      SSC_TRY(queue_dw(c, q, dgd, H4, h1_new, l.Hp, TB, H4, H, gw + F, ld));
+      SSC_TRY(queue_dw(c, q, dgd, H4, hd_prev, l.Hp, TB, H4, H, gw + F + H, ld));
+      SSC_TRY(queue_dw(c, q, dgd, H4, W + l.z, l.Zp, TB, H4, Z, gw + zcol, ld));
+    } else if (g->dec_w_hh) {
+      SSC_TRY(queue_dw(c, q, dgd, H4, hd_prev, l.Hp, TB, H4, H, g->dec_w_hh, g->ld_dec_w_hh));
+    }
+    SSC_TRY(flush_dw(c, q));
+  }
   // decoder LSTM (skipped while frozen: train.py:156-161)
   if (g->dec_w_ih) {
     float* gw = g->dec_w_ih; int ld = g->ld_dec_w_ih;
-    SSC_TRY(gemm_dw(c, dgd, H4, att, l.Fp, TB, H4, F, gw, ld));
-    SSC_TRY(gemm_dw(c, dgd, H4, h1_new, l.Hp, TB, H4, H, gw + F, ld));
-    SSC_TRY(gemm_dw(c, dgd, H4, hd_prev, l.Hp, TB, H4, H, gw + F + H, ld));
     if (S) SSC_TRY(ssc_colsum2(dgd, H4, TB, H4, W + l.sent_all, gw + F + 2 * H, ld, nullptr, 0, c.slabs, st));
-    SSC_TRY(gemm_dw(c, dgd, H4, W + l.z, l.Zp, TB, H4, Z, gw + zcol, ld));
   }
   if (g->dec_w_hh) {
     // dW_hh^dec = dGd^T HD_prev is the same product as the hd' block of dW_ih^dec
@@ -671,8 +734,6 @@ static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const s
                            (size_t)g->ld_dec_w_ih * sizeof(float), (size_t)H * sizeof(float), H4, hipMemcpyDeviceToDevice,
                            st) != hipSuccess)
         return SSC_EHIP;
-    } else {
-      SSC_TRY(gemm_dw(c, dgd, H4, hd_prev, l.Hp, TB, H4, H, g->dec_w_hh, g->ld_dec_w_hh));
     }
   }
   if (g->dec_b_ih && g->dec_b_hh) {

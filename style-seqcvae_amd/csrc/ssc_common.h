@@ -61,3 +61,5 @@ int ssc_gemm_slabs_auto(const ssc_gemm_desc* d, float* slabs, size_t cap_floats,
 // own region; falls back to one launch per product when they do not qualify for the 64x256 wave-specialised kernel
 int ssc_gemm_slabs_group(const ssc_gemm_desc* const* d, int n, float* const* regions, const size_t* caps, int* nslab,
                          hipStream_t st);
+// the independent weight-gradient products of one backward phase (C_i = A_i^T B_i, direct outputs) as grouped launches
+int ssc_gemm_dw_group(const ssc_gemm_desc* const* d, int n, hipStream_t st);
