@@ -178,12 +178,6 @@ def bench_decode(args, model, eng, c, rank, world, device):
         rec = (_C.c_ulonglong * 4)()
         _C.CDLL(_L.LIB_PATH).ssc_debug_gemm_shadow(rec)
         print("gemm shadow compare {compared, mismatches, non-finite, first bad index}:", list(rec), file=sys.stderr, flush=True)
-    if rank == 0 and os.environ.get("SSC_GEMM_DBG") == "128":   # pointer audit of the wave-specialised kernels (diagnostic)
-        import ctypes as _C
-        from ssc_runtime import lib as _L
-        rec = (_C.c_int * 8)()
-        _C.CDLL(_L.LIB_PATH).ssc_debug_gemm_oob(rec)
-        print("gemm pointer audit:", list(rec), file=sys.stderr, flush=True)
     if rank == 0:
         el, tokens, rows_steps = results[True]
         el2, tokens2, rows_steps2 = results[False]

@@ -54,12 +54,7 @@ struct KArgs {
   const int* kcount;  // K = min(K, *kcount)            (single segment, m/n-contiguous operands)
   const int* karows;  // A's k-row k is read from row karows[k]
   const int* kbrows;  // B's k-row k is read from row kbrows[k]
-  int dbg;  // timing-only ablation switches (SSC_GEMM_DBG env; results are wrong when set): 1 = no global loads in
-            // the loop, 2 = no LDS stores, 4 = no barriers
 };
-
-__device__ long long g_clk[8];
-__device__ int g_oob[8];  // SSC_GEMM_DBG=128 pointer audit of gemm_x3w_kernel: {violations, first: blk_x, blk_y, step, chunk, tid, offset/4, k0}  // SSC_GEMM_DBG=64 clock probe: {shader cycles, 100 MHz ticks, k-steps} of one workgroup's main loop
 
 // ---- global -> register staging of one ROWS x 32 operand tile (ROWS/8 floats per thread) --------------
 // Loads are UNCONDITIONAL: out-of-range rows / k are clamped to a valid address and (for k) zeroed with a select
@@ -266,9 +261,8 @@ struct Stage<A_KC, B_KC, RA, RB, true> {
   }
 
   __device__ __forceinline__ void load(const KArgs& g, const Cursor& c, int m0, int n0, int tid) {
-    // timing-only ablations (SSC_GEMM_DBG): 16 / 32 make every A / B load hit one cached line (no memory traffic)
-    oka = issue<A_KC, RA, NVA>(a, c.A, (g.dbg & 16) ? 0 : c.lda, g.M, c.K, (g.dbg & 16) ? 0 : m0, (g.dbg & 16) ? 0 : c.k0, tid);
-    okb = issue<B_KC, RB, NVB>(b, c.B, (g.dbg & 32) ? 0 : c.ldb, g.N, c.K, (g.dbg & 32) ? 0 : n0, (g.dbg & 32) ? 0 : c.k0, tid);
+    oka = issue<A_KC, RA, NVA>(a, c.A, c.lda, g.M, c.K, m0, c.k0, tid);
+    okb = issue<B_KC, RB, NVB>(b, c.B, c.ldb, g.N, c.K, n0, c.k0, tid);
   }
 
   // NT fast path: per-thread chunk pointers kept across k-steps (advanced by 32 floats per step, recomputed on a
@@ -294,19 +288,13 @@ struct Stage<A_KC, B_KC, RA, RB, true> {
     }
     return okm;
   }
-  // `full` = the whole 32-wide k-step lies inside the segment (no clamp, every chunk valid)
-  __device__ __forceinline__ void load_ptrs(const float* const (&pa)[NVA], const float* const (&pb)[NVB], bool full, int k0,
-                                            int K, int lda, int ldb, int tid) {
-    if (full) {
-      oka = okb = 0xffffffffu;
-#pragma unroll
-      for (int u = 0; u < NVA; ++u) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(a[u]) : "v"(pa[u]) : "memory");
-#pragma unroll
-      for (int u = 0; u < NVB; ++u) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(b[u]) : "v"(pb[u]) : "memory");
-    } else {  // tail step of a segment: clamp into range, remember which chunks are out of range
-      oka = tail_issue<A_KC, RA, NVA>(a, pa, k0, K, lda, tid);
-      okb = tail_issue<B_KC, RB, NVB>(b, pb, k0, K, ldb, tid);
-    }
+  // Branch-free: every k-step takes the clamped form (a k-step that lies inside its segment clamps nothing).  No branch
+  // may surround a staged load: the hand-counted waits rely on every path issuing the same loads in the same order, and
+  // tools/check_staged_loads.py proves the register discipline path by path only under that condition.
+  __device__ __forceinline__ void load_ptrs(const float* const (&pa)[NVA], const float* const (&pb)[NVB], int k0, int K, int lda,
+                                            int ldb, int tid) {
+    oka = tail_issue<A_KC, RA, NVA>(a, pa, k0, K, lda, tid);
+    okb = tail_issue<B_KC, RB, NVB>(b, pb, k0, K, ldb, tid);
   }
 
   template <int YOUNGER>
@@ -429,7 +417,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const KArgs a) {
   int s_ld = s_lo;  // step the cursor points at (the newest tile requested)
   ThreadPtrs<A_KC, B_KC, RA, RB> tp;
   auto issue_loads = [&](StageT& x) {
-    if constexpr (VEC) x.load_ptrs(tp.pa, tp.pb, cur.k0 + BK <= cur.K, cur.k0, cur.K, cur.lda, cur.ldb, tid);
+    if constexpr (VEC) x.load_ptrs(tp.pa, tp.pb, cur.k0, cur.K, cur.lda, cur.ldb, tid);
     else x.load(a, cur, m0, n0, tid);
   };
   auto advance = [&]() {
@@ -484,18 +472,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(const KArgs a) {
   // steady state, unrolled so that stage and LDS-buffer indices are static: in sub-iteration j tile s+j is in
   // LDS[j&1], stage j%PF holds tile s+j+1 (the OLDEST loads in flight; the other PF-1 stages are younger).
   constexpr int U = PF > 2 ? PF : 2;
+  // Every sub-iteration runs the same load / wait / store / barrier sequence; only the MFMA work is skipped in the
+  // sub-iterations past the end of the k-range (the trip count is rounded up to a multiple of U).  A store past the end
+  // goes to the LDS buffer whose last readers finished before the previous barrier; loads past the end re-read the last
+  // tile (clamped cursor).
   for (int s = s_lo; s < s_hi; s += U) {
 #pragma unroll
     for (int j = 0; j < U; ++j) {
-      if (s + j < s_hi) {
-        StageT& x = st[(j + 1) % PF];
-        compute(j & 1);
-        x.template wait<(PF - 1) * NL>();
-        if (s + j + 1 < s_hi && !(a.dbg & 2)) x.store(As + ((j + 1) & 1) * TA, Bs + ((j + 1) & 1) * TB, tid);
-        cur.advance(a, s_ld >= s_last); s_ld = min(s_ld + 1, s_last);
-        x.load(a, cur, m0, n0, tid);
-        __syncthreads();
-      }
+      StageT& x = st[(j + 1) % PF];
+      if (s + j < s_hi) compute(j & 1);
+      x.template wait<(PF - 1) * NL>();
+      x.store(As + ((j + 1) & 1) * TA, Bs + ((j + 1) & 1) * TB, tid);
+      cur.advance(a, s_ld >= s_last); s_ld = min(s_ld + 1, s_last);
+      x.load(a, cur, m0, n0, tid);
+      __syncthreads();
     }
   }
   // Drain the clamped tail loads.  Their results are never used, but the wait must still PIN the staged registers
@@ -650,7 +640,7 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const KArgs a) {
   Cursor cur;
   int s_ld = s_lo;
   ThreadPtrs<true, true, 64, RB> tp;
-  auto issue_loads = [&](StageT& x) { x.load_ptrs(tp.pa, tp.pb, cur.k0 + BK <= cur.K, cur.k0, cur.K, cur.lda, cur.ldb, tid); };
+  auto issue_loads = [&](StageT& x) { x.load_ptrs(tp.pa, tp.pb, cur.k0, cur.K, cur.lda, cur.ldb, tid); };
   if (s_lo < s_hi) {
     cur.init(a, s_lo);
     tp.recompute(a, cur, m0, n0, tid);
@@ -694,17 +684,19 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const KArgs a) {
   };
 
   constexpr int U = PF > 2 ? PF : 2;
+  // uniform sub-iterations (see gemm_kernel): only the MFMA work is skipped past the end of the k-range
   for (int s = s_lo; s < s_hi; s += U) {
 #pragma unroll
     for (int j = 0; j < U; ++j) {
-      if (s + j < s_hi) {
-        StageT& x = st[(j + 1) % PF];
-        // One basic block: this step's MFMA chain and the NEXT tile's fp32 -> 3xbf16 split (VALU) + plane stores.  A wave
-        // issues in order and a dependent MFMA blocks everything behind it, so the split must sit BETWEEN the MFMAs to
-        // run in their shadow (sched_group_barrier below); the store is unconditional (past the end it re-stores the
-        // clamped last tile into the stage nobody reads again).
-        x.template wait<(PF - 1) * NL>();
-        if constexpr (NBUF == 2) {
+      StageT& x = st[(j + 1) % PF];
+      const bool live = s + j < s_hi;
+      // One basic block: this step's MFMA chain and the NEXT tile's fp32 -> 3xbf16 split (VALU) + plane stores.  A wave
+      // issues in order and a dependent MFMA blocks everything behind it, so the split must sit BETWEEN the MFMAs to
+      // run in their shadow (sched_group_barrier below); the store is unconditional (past the end it re-stores the
+      // clamped last tile into the stage nobody reads again).
+      x.template wait<(PF - 1) * NL>();
+      if constexpr (NBUF == 2) {
+        if (live) {
           compute(j & 1);
           put_planes(lds + ((j + 1) & 1) * STAGE_B, x);
 #pragma unroll
@@ -713,14 +705,16 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const KArgs a) {
             __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);  // up to 7 VALU in its shadow
           }
         } else {
-          compute(0);
-          __syncthreads();  // every wave is done reading the single stage
-          put_planes(lds, x);
+          put_planes(lds + ((j + 1) & 1) * STAGE_B, x);
         }
-        tp.step(a, cur, cur.advance(a, s_ld >= s_last), m0, n0, tid); s_ld = min(s_ld + 1, s_last);
-        issue_loads(x);
-        __syncthreads();
+      } else {
+        if (live) compute(0);
+        __syncthreads();  // every wave is done reading the single stage
+        put_planes(lds, x);
       }
+      tp.step(a, cur, cur.advance(a, s_ld >= s_last), m0, n0, tid); s_ld = min(s_ld + 1, s_last);
+      issue_loads(x);
+      __syncthreads();
     }
   }
   // drain the clamped tail loads with the staged registers pinned (see gemm_kernel)
@@ -873,45 +867,38 @@ __global__ __launch_bounds__(256, 2) void gemm_x3b_kernel(const KArgs a) {
       prefetch_rows();
     }
   };
+  // Branch-free (no branch may surround a staged load: see Stage::load_ptrs): every k-step takes the clamped form - a step
+  // inside its segment clamps nothing - and remembers which chunks lie past the end of K.
   auto issue_loads = [&]() {
-    const bool full = cur.k0 + BK <= cur.K;
-    if (full) {
-      oka = okb = 0xfu;
+    oka = okb = 0;
+    const float* qa[4];
+    const float* qb[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(ra[u]) : "v"(pa[u]) : "memory");
-#pragma unroll
-      for (int u = 0; u < 4; ++u) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(rb[u]) : "v"(pb[u]) : "memory");
-    } else {  // last k-step of a segment: clamp into range, remember which chunks are past the end
-      oka = okb = 0;
-      const float* qa[4];
-      const float* qb[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int idx = tid + 256 * u;
-        if constexpr (A_KC) {
-          const int k = cur.k0 + 4 * (idx & 7);
-          qa[u] = pa[u] + (min(k, cur.K - 4) - k);
-          oka |= (k < cur.K ? 1u : 0u) << u;
-        } else {
-          const int gk = cur.k0 + (idx >> 5);
-          qa[u] = KG ? pa[u] : pa[u] + (ptrdiff_t)(min(gk, cur.K - 1) - gk) * cur.lda;
-          oka |= (gk < cur.K ? 1u : 0u) << u;
-        }
-        if constexpr (B_KC) {
-          const int k = cur.k0 + 4 * (idx & 7);
-          qb[u] = pb[u] + (min(k, cur.K - 4) - k);
-          okb |= (k < cur.K ? 1u : 0u) << u;
-        } else {
-          const int gk = cur.k0 + (idx >> 5);
-          qb[u] = KG ? pb[u] : pb[u] + (ptrdiff_t)(min(gk, cur.K - 1) - gk) * cur.ldb;
-          okb |= (gk < cur.K ? 1u : 0u) << u;
-        }
+    for (int u = 0; u < 4; ++u) {
+      const int idx = tid + 256 * u;
+      if constexpr (A_KC) {
+        const int k = cur.k0 + 4 * (idx & 7);
+        qa[u] = pa[u] + (min(k, cur.K - 4) - k);
+        oka |= (k < cur.K ? 1u : 0u) << u;
+      } else {
+        const int gk = cur.k0 + (idx >> 5);
+        qa[u] = KG ? pa[u] : pa[u] + (ptrdiff_t)(min(gk, cur.K - 1) - gk) * cur.lda;
+        oka |= (gk < cur.K ? 1u : 0u) << u;
       }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(ra[u]) : "v"(qa[u]) : "memory");
-#pragma unroll
-      for (int u = 0; u < 4; ++u) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(rb[u]) : "v"(qb[u]) : "memory");
+      if constexpr (B_KC) {
+        const int k = cur.k0 + 4 * (idx & 7);
+        qb[u] = pb[u] + (min(k, cur.K - 4) - k);
+        okb |= (k < cur.K ? 1u : 0u) << u;
+      } else {
+        const int gk = cur.k0 + (idx >> 5);
+        qb[u] = KG ? pb[u] : pb[u] + (ptrdiff_t)(min(gk, cur.K - 1) - gk) * cur.ldb;
+        okb |= (gk < cur.K ? 1u : 0u) << u;
+      }
     }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(ra[u]) : "v"(qa[u]) : "memory");
+#pragma unroll
+    for (int u = 0; u < 4; ++u) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(rb[u]) : "v"(qb[u]) : "memory");
   };
   // all staged loads have landed; "+v" pins every use of the staged registers behind the wait
   auto wait_loads = [&]() {
@@ -1006,16 +993,13 @@ __global__ __launch_bounds__(256, 2) void gemm_x3b_kernel(const KArgs a) {
     }
   };
 
-  if ((a.dbg & 32) && ((blockIdx.y * gridDim.x + blockIdx.x) >> 8 & 1)) __builtin_amdgcn_s_setprio(2);
   for (int s = s_lo; s < s_hi; ++s) {
-    if (a.dbg & 16) __builtin_amdgcn_s_setprio(2);
-    if (!(a.dbg & 8)) compute();
-    if (a.dbg & 16) __builtin_amdgcn_s_setprio(0);
+    compute();
     wait_loads();
     __syncthreads();  // every wave is done reading the stage
-    if (s + 1 < s_hi && !(a.dbg & 2)) put_planes();
+    if (s + 1 < s_hi) put_planes();   // VALU + LDS only
     advance();
-    if (!(a.dbg & 1)) issue_loads();
+    issue_loads();
     __syncthreads();
   }
   wait_loads();  // drain the clamped tail loads with the staged registers pinned (see gemm_kernel)
@@ -1086,7 +1070,6 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
   constexpr int NA = TM / 32, NB = TN / 32;      // float4 chunks per producer thread and k-step
   constexpr int QA = TM / 4, QB = TN / 4;        // float4 per k-row of an m/n-contiguous tile
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  const long long r_entry = __builtin_amdgcn_s_memrealtime();
   const int wave = threadIdx.x >> 6;
   const bool producer = wave >= 4;
   const int tid = threadIdx.x & 255;  // index within the role's 256 threads
@@ -1114,7 +1097,6 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
   int s_hi = s_lo + steps_per_split;
   if (s_hi > steps_total) s_hi = steps_total;
   const int s_last = s_hi - 1;
-  const bool probe = (a.dbg & 64) && blk_x == 1 && blk_y == 0 && threadIdx.x == 0;
   constexpr int CT_LD = TN + 4;   // epilogue C tile in LDS
 
   if (producer) {
@@ -1188,68 +1170,44 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
         prefetch_rows();
       }
     };
+    // Branch-free (no branch may surround a staged load: see Stage::load_ptrs): every k-step takes the clamped form - a step
+    // inside its segment clamps nothing - and remembers which chunks lie past the end of K.
     auto issue_loads = [&](f32x4 (&xa)[NA], f32x4 (&xb)[NB], unsigned& ma, unsigned& mb) {
-      const bool full = cur.k0 + BK <= cur.K;
-      if (full) {
-        ma = mb = 0xffu;
-        if (a.dbg & 128) {  // diagnostic: the stepped pointers must lie inside their operands (ssc_debug_gemm_oob)
-          const size_t ea = (size_t)(A_KC ? a.M : a.seg[cur.seg].K) * cur.lda, eb = (size_t)(B_KC ? a.N : a.seg[cur.seg].K) * cur.ldb;
+      ma = mb = 0;
+      const float* qa[NA];
+      const float* qb[NB];
+      // k-contiguous operands: chunk u of this thread starts at k0 + 4*(tid & 7) for every u (idx = tid + 256 u)
+      const int kc = cur.k0 + 4 * (tid & 7);
+      const int kc_adj = min(kc, cur.K - 4) - kc;
+      const unsigned kc_ok = kc < cur.K ? 1u : 0u;
 #pragma unroll
-          for (int u = 0; u < NA; ++u) {
-            const ptrdiff_t off = pa[u] - cur.A;
-            if (!a.arows && (off < 0 || (size_t)off + 4 > ea)) {
-              if (atomicAdd(&g_oob[0], 1) == 0) { g_oob[1] = blk_x; g_oob[2] = blk_y; g_oob[3] = s_ld; g_oob[4] = u; g_oob[5] = tid; g_oob[6] = (int)(off >> 2); g_oob[7] = cur.k0; }
-              pa[u] = cur.A;
-            }
-          }
-#pragma unroll
-          for (int u = 0; u < NB; ++u) {
-            const ptrdiff_t off = pb[u] - cur.B;
-            if (off < 0 || (size_t)off + 4 > eb) {
-              if (atomicAdd(&g_oob[0], 1) == 0) { g_oob[1] = blk_x; g_oob[2] = blk_y; g_oob[3] = s_ld; g_oob[4] = 100 + u; g_oob[5] = tid; g_oob[6] = (int)(off >> 2); g_oob[7] = cur.k0; }
-              pb[u] = cur.B;
-            }
-          }
+      for (int u = 0; u < NA; ++u) {
+        const int idx = tid + 256 * u;
+        if constexpr (A_KC) {
+          qa[u] = pa[u] + kc_adj;
+          ma |= kc_ok << u;
+        } else {
+          const int gk = cur.k0 + idx / QA;
+          qa[u] = KG ? pa[u] : pa[u] + (ptrdiff_t)(min(gk, cur.K - 1) - gk) * cur.lda;
+          ma |= (gk < cur.K ? 1u : 0u) << u;
         }
-#pragma unroll
-        for (int u = 0; u < NA; ++u) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(xa[u]) : "v"(pa[u]) : "memory");
-#pragma unroll
-        for (int u = 0; u < NB; ++u) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(xb[u]) : "v"(pb[u]) : "memory");
-      } else {  // last k-step of a segment: clamp into range, remember which chunks are past the end
-        ma = mb = 0;
-        const float* qa[NA];
-        const float* qb[NB];
-#pragma unroll
-        for (int u = 0; u < NA; ++u) {
-          const int idx = tid + 256 * u;
-          if constexpr (A_KC) {
-            const int k = cur.k0 + 4 * (idx & 7);
-            qa[u] = pa[u] + (min(k, cur.K - 4) - k);
-            ma |= (k < cur.K ? 1u : 0u) << u;
-          } else {
-            const int gk = cur.k0 + idx / QA;
-            qa[u] = KG ? pa[u] : pa[u] + (ptrdiff_t)(min(gk, cur.K - 1) - gk) * cur.lda;
-            ma |= (gk < cur.K ? 1u : 0u) << u;
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < NB; ++u) {
-          const int idx = tid + 256 * u;
-          if constexpr (B_KC) {
-            const int k = cur.k0 + 4 * (idx & 7);
-            qb[u] = pb[u] + (min(k, cur.K - 4) - k);
-            mb |= (k < cur.K ? 1u : 0u) << u;
-          } else {
-            const int gk = cur.k0 + idx / QB;
-            qb[u] = KG ? pb[u] : pb[u] + (ptrdiff_t)(min(gk, cur.K - 1) - gk) * cur.ldb;
-            mb |= (gk < cur.K ? 1u : 0u) << u;
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < NA; ++u) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(xa[u]) : "v"(qa[u]) : "memory");
-#pragma unroll
-        for (int u = 0; u < NB; ++u) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(xb[u]) : "v"(qb[u]) : "memory");
       }
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        const int idx = tid + 256 * u;
+        if constexpr (B_KC) {
+          qb[u] = pb[u] + kc_adj;
+          mb |= kc_ok << u;
+        } else {
+          const int gk = cur.k0 + idx / QB;
+          qb[u] = KG ? pb[u] : pb[u] + (ptrdiff_t)(min(gk, cur.K - 1) - gk) * cur.ldb;
+          mb |= (gk < cur.K ? 1u : 0u) << u;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < NA; ++u) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(xa[u]) : "v"(qa[u]) : "memory");
+#pragma unroll
+      for (int u = 0; u < NB; ++u) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(xb[u]) : "v"(qb[u]) : "memory");
     };
     // wait until at most YOUNGER of the hand-issued loads are outstanding; "+v" pins every use of this stage's registers
     // behind the wait (cdna_hip_programming.md 5.7)
@@ -1273,7 +1231,7 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
       *reinterpret_cast<u32x2*>(p + 2 * plane) = lo;
     };
     auto put_planes = [&](unsigned char* st, const f32x4 (&xa)[NA], const f32x4 (&xb)[NB], unsigned ma, unsigned mb) {
-      const bool all = (ma == 0xffu && mb == 0xffu);  // whole k-step in range (uniform): no per-chunk select
+      const bool all = (ma == (1u << NA) - 1u) && (mb == (1u << NB) - 1u);  // every chunk of this thread in range: no select
 #pragma unroll
       for (int u = 0; u < NA; ++u) {
         const int idx = tid + 256 * u;
@@ -1307,19 +1265,19 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
       issue_loads(ra[0], rb[0], oka[0], okb[0]);
     }
     __syncthreads();
+    // Both halves always run (the trip count is rounded up to an even number of k-steps; the consumers take the same
+    // number of barriers): every path issues the same loads and waits; loads past the end re-read the last tile (clamped
+    // cursor) and are never stored.
     for (int s = s_lo; s < s_hi; s += 2) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        if (s + h < s_hi) {
-          constexpr int dummy = 0; (void)dummy;
-          const int j = (h + 1) % PF;   // (s + h - s_lo + 1) % PF: s - s_lo is even here
-          asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PF - 1) * NL) : "memory");
-          pin(ra[j], rb[j]);
-          if (s + h + 1 < s_hi && !(a.dbg & 2)) put_planes(lds + ((h + 1) & 1) * STAGE, ra[j], rb[j], oka[j], okb[j]);
-          advance();
-          if (!(a.dbg & 1)) issue_loads(ra[j], rb[j], oka[j], okb[j]);
-          __syncthreads();
-        }
+        const int j = (h + 1) % PF;   // (s + h - s_lo + 1) % PF: s - s_lo is even here
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PF - 1) * NL) : "memory");
+        pin(ra[j], rb[j]);
+        if (s + h + 1 < s_hi) put_planes(lds + ((h + 1) & 1) * STAGE, ra[j], rb[j], oka[j], okb[j]);   // VALU + LDS only
+        advance();
+        issue_loads(ra[j], rb[j], oka[j], okb[j]);
+        __syncthreads();
       }
     }
     // drain the clamped tail loads with the staged registers pinned (see gemm_kernel)
@@ -1394,17 +1352,11 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
   };
 
   __syncthreads();
-  long long t0 = 0, r0 = 0;
-  if (probe) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
-  for (int s = s_lo; s < s_hi; ++s) {
-    if (!(a.dbg & 8)) compute(lds + ((s - s_lo) & 1) * STAGE);
+  for (int s = s_lo; s < s_hi; s += 2) {   // two barriers per trip, like the producers
+    compute(lds);
     __syncthreads();
-  }
-  if (probe) {
-    g_clk[0] = __builtin_amdgcn_s_memtime() - t0;
-    g_clk[1] = __builtin_amdgcn_s_memrealtime() - r0;
-    g_clk[2] = s_hi - s_lo;
-    g_clk[3] = r0 - r_entry;   // 100 MHz ticks from kernel entry to the end of the prologue
+    if (s + 1 < s_hi) compute(lds + STAGE);
+    __syncthreads();
   }
 #undef SSC_X3W_MFMA
 
@@ -1449,10 +1401,6 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
         }
       }
     }
-  }
-  if (probe) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    g_clk[4] = __builtin_amdgcn_s_memrealtime() - r_entry;  // ... and to the end of the epilogue
   }
 }
 
@@ -1625,10 +1573,6 @@ inline bool x3w_skinny(const ssc_gemm_desc* d, bool vec) {   // 2 = only where t
 
 int launch(const ssc_gemm_desc* d, KArgs& k, int splits, hipStream_t st) {
   k.steps_per_split = ssc_cdiv(k.steps_total, splits);
-  {
-    static const int dbg = getenv("SSC_GEMM_DBG") ? atoi(getenv("SSC_GEMM_DBG")) : 0;
-    k.dbg = dbg;
-  }
   bool vec = true;  // every segment of both operands must allow 16 B/lane loads, else the 4 B/lane kernel runs
   for (int i = 0; i < k.nseg; ++i) vec = vec && k.seg[i].avec && k.seg[i].bvec;
   const bool compact = k.mcount || k.arows || k.crows || k.kcount || k.karows || k.kbrows;
@@ -1887,10 +1831,6 @@ int ssc_gemm_slabs_group(const ssc_gemm_desc* const* d, int n, float* const* reg
     k.bias = nullptr;
     k.accumulate = 0;
     k.crows = nullptr;
-    {
-      static const int dbg = getenv("SSC_GEMM_DBG") ? atoi(getenv("SSC_GEMM_DBG")) : 0;
-      k.dbg = dbg;
-    }
     g.gx[i] = ssc_cdiv(d[i]->N, 256);
     g.gy[i] = 1;
     g.gz[i] = splits;
@@ -1941,10 +1881,6 @@ int ssc_gemm_dw_group(const ssc_gemm_desc* const* d, int n, hipStream_t st) {
       kg0 = kg;
       k.steps_per_split = k.steps_total;
       k.out = dj->C; k.ldo = dj->ldc; k.slab_stride = 0; k.bias = dj->bias; k.accumulate = dj->accumulate;
-      {
-        static const int dbg = getenv("SSC_GEMM_DBG") ? atoi(getenv("SSC_GEMM_DBG")) : 0;
-        k.dbg = dbg;
-      }
       g.gx[m] = ssc_cdiv(dj->N, 128); g.gy[m] = ssc_cdiv(dj->M, 128); g.gz[m] = 1;
       if (m == 0) g.first[0] = 0;
       g.first[m + 1] = g.first[m] + g.gx[m] * g.gy[m];
@@ -2080,20 +2016,6 @@ extern "C" int ssc_set_gemm_wide_min_n(int n) {
 // diagnostic: SSC_SHADOW record {elements compared, mismatches, non-finite, first bad index}
 extern "C" int ssc_debug_gemm_shadow(unsigned long long* out4) {
   if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_shadow), 4 * sizeof(unsigned long long)) != hipSuccess) return SSC_EHIP;
-  return SSC_OK;
-}
-
-// diagnostic: read and clear the SSC_GEMM_DBG=128 pointer-audit record
-extern "C" int ssc_debug_gemm_oob(int* out8) {
-  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_oob), 8 * sizeof(int)) != hipSuccess) return SSC_EHIP;
-  int z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (hipMemcpyToSymbol(HIP_SYMBOL(g_oob), z, sizeof(z)) != hipSuccess) return SSC_EHIP;
-  return SSC_OK;
-}
-
-// diagnostic: in-kernel clock probe of gemm_x3w_kernel (SSC_GEMM_DBG=64): {shader cycles, 100 MHz ticks, k-steps}
-extern "C" int ssc_debug_gemm_clock(long long* out3) {
-  if (hipMemcpyFromSymbol(out3, HIP_SYMBOL(g_clk), 5 * sizeof(long long)) != hipSuccess) return SSC_EHIP;
   return SSC_OK;
 }
 

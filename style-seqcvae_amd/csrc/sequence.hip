@@ -26,7 +26,8 @@ struct Layout {
   int V, E, H, A, F, Z, S, tied;
   int Ep, Hp, Ap, Fp, Zp, Vp, H4, XW;  // padded leading dims ; XW = F + 2H
   size_t total = 0;                    // floats
-  size_t act;  // int32: [0] = number of active (t, b) rows, [4 ...] = their row numbers t*B+b in ascending order
+  size_t act;   // int32: [0] = number of (t, b) rows with a real target (w = 1), [4 ...] = their row numbers t*B+b, ascending
+  size_t live;  // int32: same layout; rows (t, b) with w = 1 at step t OR ANY LATER step of caption b (see build_active_rows_kernel)
   size_t tok, w, nvalid, sent_all, wcol_e, wcol_d, mask, avg, pv, emb, ga_static, ga_avg;
   size_t h1, c1, he, ce, hd, cd, gates_a, gates_e, gates_d, q, attn_logits, alpha, att, mu, lv, z, mulv;
   size_t slabs, slab_floats, logits, lse, proj;
@@ -52,6 +53,7 @@ Layout make_layout(const ssc_model_cfg* c, int B, int R, int L) {
   l.w = l.take(TB);
   l.nvalid = l.take(B);
   l.act = l.take(TB + 4);
+  l.live = l.take(TB + 4);
   l.sent_all = l.take(TB);
   l.wcol_e = l.take(l.H4); l.wcol_d = l.take(l.H4);
   l.mask = l.take((size_t)B * R);
@@ -121,6 +123,8 @@ struct Ctx {
   size_t slab_floats;
   const int* act_count = nullptr;  // device: number of (t, b) rows with a non-pad target ...
   const int* act_rows = nullptr;   // ... and their row numbers (build_active_rows_kernel); nullptr = no compaction
+  const int* live_count = nullptr; // device: number of (t, b) rows that can carry a non-zero gate gradient ...
+  const int* live_rows = nullptr;  // ... and their row numbers
 };
 
 void fill_desc(ssc_gemm_desc& d, bool a_kc, bool b_kc, std::initializer_list<Seg> segs, int M, int N) {
@@ -147,19 +151,28 @@ int gemm(const Ctx& c, bool a_kc, bool b_kc, std::initializer_list<Seg> segs, in
   return ssc_gemm(&d, c.st);
 }
 
-// Products over the (t, b) rows of the caption batch skip the padded rows on the device (ssc_gemm_desc row compaction):
-// those rows carry zero loss weight, so they contribute exact zeros to every weight gradient and their outputs are
-// never used.  When the operands do not qualify (alignment, fp32-MFMA mode) the product runs over all rows as before.
-//   gemm_rows: C[r] = A[r] . B for the active rows r only (other rows of C are left as they are)
-//   gemm_dw:   C = A^T B summed over the active rows only
-int gemm_rows(const Ctx& c, bool b_kc, std::initializer_list<Seg> segs, int M, int N, float* C, int ldc, const float* bias = nullptr) {
+// Products over the (t, b) rows of the caption batch skip rows on the device (ssc_gemm_desc row compaction).  Two lists:
+//   act  - rows whose target is a real token (loss weight w = 1): the only rows whose logits are ever used, and the only
+//          rows with a non-zero dlogits -> vocabulary head forward, its backward dHDv;
+//   live - rows (t, b) with w = 1 at step t or at ANY LATER step of caption b: every other row lies in the padding
+//          suffix, receives no gradient from the loss, the KL term or a later step, and so has dG = 0 exactly -> all
+//          weight-gradient products and the embedding-gradient product.  A row with w = 0 INSIDE a caption (an in-caption
+//          @@UNKNOWN@@, id 0 = the padding id: updown_captioner.py:265-278) is live: BPTT carries the
+//          gradient of the later steps through it (the LSTM backward is not masked by w).
+// When the operands do not qualify (alignment, fp32-MFMA mode) the product runs over all rows as before.
+//   gemm_rows: C[r] = A[r] . B for the listed rows r only (other rows of C are left as they are)
+//   gemm_dw:   C = A^T B summed over the live rows only
+int gemm_rows(const Ctx& c, bool b_kc, std::initializer_list<Seg> segs, int M, int N, float* C, int ldc, const float* bias = nullptr,
+              bool live = false) {
   ssc_gemm_desc d;
   fill_desc(d, true, b_kc, segs, M, N);
   d.C = C; d.ldc = ldc; d.bias = bias; d.accumulate = 0;
   d.splits = 0;
   d.workspace = c.slabs; d.workspace_floats = c.slab_floats;
   if (c.act_rows) {
-    d.m_count = c.act_count; d.a_rows = c.act_rows; d.c_rows = c.act_rows;
+    const int* cnt = live ? c.live_count : c.act_count;
+    const int* rows = live ? c.live_rows : c.act_rows;
+    d.m_count = cnt; d.a_rows = rows; d.c_rows = rows;
     const int rc = ssc_gemm(&d, c.st);
     if (rc != SSC_EALIGN && rc != SSC_EINVAL) return rc;
     d.m_count = d.a_rows = d.c_rows = nullptr;
@@ -180,7 +193,7 @@ int queue_dw(const Ctx& c, DwBatch& q, const float* A, int lda, const float* Bm,
   d.C = C; d.ldc = ldc;
   d.splits = 0;
   d.workspace = c.slabs; d.workspace_floats = c.slab_floats;
-  if (c.act_rows) { d.k_count = c.act_count; d.ka_rows = c.act_rows; d.kb_rows = c.act_rows; }
+  if (c.live_rows) { d.k_count = c.live_count; d.ka_rows = c.live_rows; d.kb_rows = c.live_rows; }
   return SSC_OK;
 }
 int flush_dw(const Ctx& c, DwBatch& q) {
@@ -220,14 +233,25 @@ int gemm_dw(const Ctx& c, const float* A, int lda, const float* Bm, int ldb, int
   return flush_dw(c, q);
 }
 
-// ascending list of the rows t*B+b whose target token is not padding (w = 1); one workgroup, ordered block scan
-__global__ __launch_bounds__(1024) void build_active_rows_kernel(const float* __restrict__ w, int n, int* __restrict__ act) {
+// Workgroup 0: ascending list of the rows t*B+b whose target token is not padding (w = 1).  Workgroup 1: ascending list of
+// the rows that are not in the padding SUFFIX of their caption (w = 1 at step t or at a later step of caption b).
+// One workgroup per list, ordered block scan.
+__global__ __launch_bounds__(1024) void build_active_rows_kernel(const float* __restrict__ w, int n, int B, int* __restrict__ act,
+                                                                 int* __restrict__ live) {
   __shared__ int part[1024];
   const int tid = threadIdx.x;
+  const bool suffix = blockIdx.x == 1;
+  int* out = suffix ? live : act;
+  auto flag = [&](int i) -> bool {
+    if (!suffix) return w[i] != 0.f;
+    for (int r = i; r < n; r += B)   // same caption, this step and every later one
+      if (w[r] != 0.f) return true;
+    return false;
+  };
   const int per = (n + 1023) / 1024;
   const int lo = min(tid * per, n), hi = min(lo + per, n);
   int cnt = 0;
-  for (int i = lo; i < hi; ++i) cnt += w[i] != 0.f;
+  for (int i = lo; i < hi; ++i) cnt += flag(i);
   part[tid] = cnt;
   __syncthreads();
   for (int off = 1; off < 1024; off <<= 1) {  // inclusive scan
@@ -238,10 +262,10 @@ __global__ __launch_bounds__(1024) void build_active_rows_kernel(const float* __
   }
   int pos = part[tid] - cnt;
   for (int i = lo; i < hi; ++i)
-    if (w[i] != 0.f) act[4 + pos++] = i;
-  if (tid == 1023) act[0] = part[1023];
+    if (flag(i)) out[4 + pos++] = i;
+  if (tid == 1023) out[0] = part[1023];
   // entries past the count are never read by a product; keep them in range anyway
-  for (int i = part[1023] + tid; i < n; i += 1024) act[4 + i] = 0;
+  for (int i = part[1023] + tid; i < n; i += 1024) out[4 + i] = 0;
 }
 
 // GEMM that leaves its split-K slabs (M x N, ld N) in `region` for a fused epilogue / consumer
@@ -341,9 +365,11 @@ extern "C" int ssc_train_fwd(const ssc_model_cfg* cfg, const ssc_params* p, cons
   // ---- per-sequence precompute --------------------------------------------------------------
   SSC_TRY(ssc_prep_tokens(bt->caps, B, l.L, cfg->pad, cfg->boundary, tok, W + l.w, W + l.nvalid, st));
   int* act = (int*)(W + l.act);
-  SSC_LAUNCH(build_active_rows_kernel, dim3(1), dim3(1024), 0, st, W + l.w, TB, act);
+  int* live = (int*)(W + l.live);
+  SSC_LAUNCH(build_active_rows_kernel, dim3(2), dim3(1024), 0, st, W + l.w, TB, B, act, live);
   SSC_CHECK_LAUNCH();
   c.act_count = act; c.act_rows = act + 4;
+  c.live_count = live; c.live_rows = live + 4;
   SSC_TRY(ssc_feat_prep(bt->feats, B, R, F, W + l.mask, W + l.avg, st));
   SSC_TRY(gemm(c, true, true, {{bt->feats, F, p->wv, p->ld_wv, F}}, B * R, A, W + l.pv, A));
   SSC_TRY(ssc_embed_gather(p->emb, p->ld_emb, tok, TB, E, W + l.emb, l.Ep, st));
@@ -496,6 +522,7 @@ static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const s
   const size_t sH = (size_t)B * l.Hp;
   const float* hd_all = W + l.hd + sH;
   c.act_count = (const int*)(W + l.act); c.act_rows = c.act_count + 4;  // built by ssc_train_fwd of this minibatch
+  c.live_count = (const int*)(W + l.live); c.live_rows = c.live_count + 4;
 
   if (phases & 1u) {
   // ---- vocabulary head ------------------------------------------------------------------------------
@@ -667,8 +694,8 @@ static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const s
     if (g->att_b_hh) SSC_TRY(ssc_colsum2(dga, H4, TB, H4, nullptr, g->att_b_hh, 1, nullptr, 0, c.slabs, st));
   }
   if (g->emb && !cfg->tied) {
-    SSC_TRY(ssc_fill(W + l.demb, (size_t)TB * l.Ep, 0.f, st));  // padded rows add nothing to the embedding gradient
-    SSC_TRY(gemm_rows(c, false, {{dga, H4, p->att_w_ih, p->ld_att_w_ih, H4}}, TB, E, W + l.demb, l.Ep));
+    SSC_TRY(ssc_fill(W + l.demb, (size_t)TB * l.Ep, 0.f, st));  // rows of the padding suffix add nothing to the embedding gradient
+    SSC_TRY(gemm_rows(c, false, {{dga, H4, p->att_w_ih, p->ld_att_w_ih, H4}}, TB, E, W + l.demb, l.Ep, nullptr, /*live=*/true));
     // zero the table gradient, then scatter-add rows by token id (padding_idx row gets none)
     if (hipMemset2DAsync(g->emb, (size_t)g->ld_emb * sizeof(float), 0, (size_t)E * sizeof(float), V, st) != hipSuccess)
       return SSC_EHIP;

@@ -115,7 +115,7 @@ class EpsInjector:
         torch.randn = self._orig
 
 
-def make_inputs(seed, B, R, F, L, V, Z, T, pad_region_row=True, sv=1):
+def make_inputs(seed, B, R, F, L, V, Z, T, pad_region_row=True, sv=1, unk=False):
     g = torch.Generator().manual_seed(seed)
     feats = torch.randn(B, R, F, generator=g)
     if pad_region_row:  # one image with two zero-padded regions (adaptive features)
@@ -125,6 +125,17 @@ def make_inputs(seed, B, R, F, L, V, Z, T, pad_region_row=True, sv=1):
     lens[0] = L  # one full-length caption
     for b in range(B):
         caps[b, : lens[b]] = torch.randint(2, V, (int(lens[b]),), generator=g)
+    if unk:
+        # in-caption @@UNKNOWN@@ (id 0 = the padding id; every out-of-vocabulary word in real data): the boundary END then
+        # lands on column count_nonzero + 1 (over a real token) and the UNK step has loss weight 0 while LATER steps of the
+        # same caption have weight 1 (updown_captioner.py:265-278)
+        caps[0, 2] = 0                      # the full-length caption
+        caps[1, 0] = 0                      # first word unknown
+        if B > 2 and int(lens[2]) > 3:
+            caps[2, 1] = 0
+            caps[2, 3] = 0                  # two unknown words in one caption
+        if B > 3:
+            caps[3, int(lens[3]) - 1] = 0   # last word unknown (indistinguishable from a shorter caption)
     senti = torch.randint(-1, 2, (B, 1), generator=g).float()
     eps = torch.randn(T, B, Z, generator=g)
     return feats, caps, senti, eps
@@ -166,12 +177,12 @@ def state_dict_np(model):
     return out
 
 
-def train_fixture(UpDownCaptioner, name, dims, sv, B=3, R=5, **kw):
+def train_fixture(UpDownCaptioner, name, dims, sv, B=3, R=5, unk=False, **kw):
     V, E, H, A, F, Z, L = dims
     T = L + 1
     model = build_reference_model(UpDownCaptioner, dims, sv, **kw)
     model.train()
-    feats, caps, senti, eps = make_inputs(1234, B, R, F, L, V, Z, T)
+    feats, caps, senti, eps = make_inputs(1234, B, R, F, L, V, Z, T, unk=unk)
     # hook per-step states through _decode_step
     steps = []
     orig = model._decode_step
@@ -286,6 +297,9 @@ def main():
     sgd_fixture(UpDownCaptioner, "g6_sgd", toy, sv=1)
     # odd sizes: nothing a multiple of 4/16/64 (kernel tail paths)
     train_fixture(UpDownCaptioner, "g7_train_odd", (131, 37, 50, 27, 70, 13, 5), sv=1, B=5, R=7)
+    # captions with @@UNKNOWN@@ (id 0) before their end
+    train_fixture(UpDownCaptioner, "g8_train_unk", (300, 40, 48, 32, 64, 16, 8), sv=1, B=5, R=5, unk=True)
+    train_fixture(UpDownCaptioner, "g8b_train_unk_sv0", (131, 37, 50, 27, 70, 13, 7), sv=0, B=4, R=6, unk=True)
 
 
 if __name__ == "__main__":
