@@ -53,9 +53,11 @@ def fused_step_bytes(c):
     return 4 * (weights + acts)
 
 
-def cpu_baseline(c, seconds_budget=25.0):
-    """The CPU oracle (oracle/: pure-torch restatement pinned to the reference) timed on this box's host cores on
-    the same workload: full train step (fwd + autograd bwd + clip + SGD), bounded sample."""
+def cpu_baseline(c, seconds_budget=40.0):
+    """The CPU oracle (oracle/: pure-torch restatement pinned to the reference) timed on this box's host cores on the same
+    workload: full train step (fwd + autograd bwd + clip + SGD) of the C2 minibatch.  Bounded sample: a short thread sweep
+    (one timed step per count after one warm-up) picks the best torch thread count - the default, every core of the box, is
+    oversubscribed for this step - then >= 3 timed steps at that count, true median."""
     import oracle
 
     cfg = oracle.OracleConfig(vocab_size=c["V"], image_feature_size=c["F"], embedding_size=c["E"], hidden_size=c["H"],
@@ -64,26 +66,39 @@ def cpu_baseline(c, seconds_budget=25.0):
     params = {k: v.requires_grad_(True) for k, v in oracle.init_params(cfg, seed=2).items()}
     feats, caps, senti, eps = synth_batch(1234, c["B"], c["R"], c["F"], c["L"], c["V"], c["Z"], "cpu")
     opt = torch.optim.SGD(list(params.values()), lr=0.015, momentum=0.9, weight_decay=0.001)
-    cores = torch.get_num_threads()
 
     def step():
+        t0 = time.time()
         opt.zero_grad()
         out = oracle.train_forward(params, cfg, feats, caps, senti, eps)
         oracle.train_objective(out, cfg).backward()
         torch.nn.utils.clip_grad_norm_(list(params.values()), 12.5)
         opt.step()
+        return time.time() - t0
 
-    step()  # warm-up
-    times = []
+    ncpu = os.cpu_count() or 1
+    default_threads = torch.get_num_threads()
     t_start = time.time()
-    while len(times) < 5 and (time.time() - t_start) < seconds_budget:
-        t0 = time.time()
-        step()
-        times.append(time.time() - t0)
-    med = sorted(times)[len(times) // 2]
-    return {"value": c["B"] / med, "unit": "captions/s", "cores": cores, "kind": "port",
-            "sample": f"{len(times)} train steps (fwd+bwd+clip+SGD) of the C2 minibatch (B={c['B']}) after 1 warm-up, "
-                      f"median {med:.2f} s/step, torch {torch.__version__} CPU, os.cpu_count()={os.cpu_count()}"}
+    sweep = {}
+    for n in sorted({min(x, ncpu) for x in (8, 16, 32, 64)} | {default_threads}):
+        if time.time() - t_start > seconds_budget * 0.6 and sweep:
+            break
+        torch.set_num_threads(n)
+        if not sweep:
+            step()   # warm-up (allocator, first-touch)
+        sweep[n] = step()
+    best = min(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    times = [sweep[best]]
+    while len(times) < 3 or (len(times) < 10 and time.time() - t_start < seconds_budget):
+        times.append(step())
+    torch.set_num_threads(default_threads)
+    times.sort()
+    med = times[len(times) // 2] if len(times) % 2 else 0.5 * (times[len(times) // 2 - 1] + times[len(times) // 2])
+    return {"value": c["B"] / med, "unit": "captions/s", "cores": best, "kind": "port",
+            "sample": f"{len(times)} timed train steps (fwd+bwd+clip+SGD) of the C2 minibatch (B={c['B']}) at {best} torch threads "
+                      f"(best of the sweep {{threads: s/step}} = { {k: round(v, 2) for k, v in sweep.items()} }), median {med:.2f} s/step, "
+                      f"torch {torch.__version__} CPU, os.cpu_count()={ncpu}"}
 
 
 def attention_roofline(device):
@@ -134,23 +149,25 @@ def attention_roofline(device):
     return out
 
 
-def bench_decode(args, model, eng, c, rank, world, device):
+def measure_decode(model, c, rank, world, device, images, warmup):
     """BASELINE.json configs[3] (C4): beam 5 (per-node 2) x 20 latent samples per image, 36x2048 features, max 20
-    steps, trivial one-state FSM, images sharded over ranks (no collective).  A "step" = one chunk of images."""
+    steps, trivial one-state FSM, images sharded over ranks (no collective).  A "step" = one chunk of 50 images
+    (5000 rows per beam-search call).  Returns the result dict on rank 0 (None elsewhere)."""
     import torch.distributed as dist
     from ssc_runtime.inference import count_tokens, diverse_decode
 
+    was_training = model.training
     model.eval()
     dec = model._dec
     chunk = 50                       # images per beam-search call: 50 x 20 samples x 5 beams = 5000 rows
-    per_rank = args.images // world
+    per_rank = images // world
     n_chunks = max(1, per_rank // chunk)
     g = torch.Generator().manual_seed(4321 + rank)
     feats = [torch.randn(chunk, c["R"], c["F"], generator=g).to(device) for _ in range(min(n_chunks, 4))]
     senti = torch.ones(chunk, device=device)
     results = {}
     for early in (True, False):
-        for i in range(args.warmup if early else 1):
+        for i in range(warmup if early else 1):
             diverse_decode(dec, feats[i % len(feats)], senti, 20, 5, c["L"], 1, early_stop=early)
         if world > 1:
             dist.barrier()
@@ -172,25 +189,28 @@ def bench_decode(args, model, eng, c, rank, world, device):
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             el, tokens, rows_steps = float(tmax[0]), float(t[1]), float(t[2])
         results[early] = (el, tokens, rows_steps)
-    if rank == 0 and os.environ.get("SSC_SHADOW"):   # wave-specialised vs 4-wave kernel on every large product (diagnostic)
-        import ctypes as _C
-        from ssc_runtime import lib as _L
-        rec = (_C.c_ulonglong * 4)()
-        _C.CDLL(_L.LIB_PATH).ssc_debug_gemm_shadow(rec)
-        print("gemm shadow compare {compared, mismatches, non-finite, first bad index}:", list(rec), file=sys.stderr, flush=True)
-    if rank == 0:
-        el, tokens, rows_steps = results[True]
-        el2, tokens2, rows_steps2 = results[False]
-        print(json.dumps({
-            "metric": "decode tokens/sec (beam 5 x 20 latent samples per image)", "value": tokens / el, "unit": "tokens/s",
-            "n_gpus": world, "steps": n_chunks, "warmup": args.warmup, "ms_per_step": el / n_chunks * 1e3,
+    if was_training:
+        model.train()
+    if rank != 0:
+        return None
+    el, tokens, rows_steps = results[True]
+    el2, tokens2, rows_steps2 = results[False]
+    return {"metric": "decode tokens/sec (beam 5 x 20 latent samples per image)", "value": tokens / el, "unit": "tokens/s",
+            "n_gpus": world, "steps": n_chunks, "warmup": warmup, "ms_per_step": el / n_chunks * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "C4 diverse decode: %d images, 36x2048 feats, beam 5 (per-node 2), N_Z=20, max 20 steps, "
                                    "trivial FSM, random-init weights" % (n_chunks * chunk * world),
                        "images_per_call": chunk, "rows_per_call": chunk * 100},
             "captions_per_s": n_chunks * chunk * world * 20 / el, "row_steps_per_s": rows_steps / el,
             "early_stop_disabled": {"tokens_per_s": tokens2 / el2, "row_steps_per_s": rows_steps2 / el2,
-                                    "captions_per_s": n_chunks * chunk * world * 20 / el2}}), flush=True)
+                                    "captions_per_s": n_chunks * chunk * world * 20 / el2}}
+
+
+def bench_decode(args, model, eng, c, rank, world, device):
+    import torch.distributed as dist
+    res = measure_decode(model, c, rank, world, device, args.images, args.warmup)
+    if rank == 0:
+        print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -207,6 +227,10 @@ def main():
                     help="train: headline captions/sec (default); decode: C4 diverse-decode tokens/sec")
     ap.add_argument("--images", type=int, default=1000, help="decode mode: synthetic images in total")
     ap.add_argument("--dump-gemm", default="", help="write the per-shape GEMM timing table (roofline leg) to this file")
+    ap.add_argument("--no-decode", action="store_true", help="skip the short decode leg of the default run")
+    ap.add_argument("--timed-only", action="store_true",
+                    help="only the timed train steps (no roofline / attention / decode / CPU legs): what the rocprofv3 passes run, "
+                         "so that every profiled launch belongs to the C2 train step")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -245,6 +269,13 @@ def main():
     eng = model._engine()  # flat parameter / gradient store + fused kernels; the module's parameters are views of it
     if args.mode == "decode":
         return bench_decode(args, model, eng, c, rank, world, device)
+    # decode leg of the headline metric (BASELINE.json: "captions/sec (train step) + decode tokens/sec"): a short C4 run
+    # (200 images per rank = 4 beam-search calls of 5000 rows), reported in the same JSON line.  It runs FIRST, on the
+    # random-init weights C4 is defined on (BOUNDARY is then rarely emitted, so the searches run their full
+    # length; after a few SGD steps on synthetic captions the model emits BOUNDARY at once).
+    dres = None
+    if not args.timed_only and not args.no_decode:
+        dres = measure_decode(model, c, rank, world, device, 200 * world, 2)
     batches = [synth_batch(1234 + rank + 100 * i, c["B"], c["R"], c["F"], c["L"], c["V"], c["Z"], device) for i in range(4)]
     total_iters = 70000
 
@@ -271,26 +302,40 @@ def main():
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    loss_probe = eng.forward(*batches[0])[0].mean().item()
+    loss_probe = None if args.timed_only else eng.forward(*batches[0])[0].mean().item()
 
     result = None
-    if rank == 0:
+    if rank == 0 and args.timed_only:
+        print(json.dumps({"metric": "captions/sec (train step)", "value": world * c["B"] * args.steps / elapsed, "unit": "captions/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+                          "timed_only": True}), flush=True)
+    elif rank == 0:
         ms = elapsed / args.steps * 1e3
         value = world * c["B"] * args.steps / elapsed
         # ---- roofline leg: in-situ hipEvent timing of every GEMM launch over 2 further steps -----------------------
         lib = L.load()
-        lib.ssc_prof_enable(1)
         nprof = 2
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        fwd_ms = []
+        B = c["B"]
+        # (a) the T-step time loops alone (hipEvent pair around the loop inside ssc_train_fwd / ssc_train_bwd; no other
+        #     instrumentation active): the fused attention+LSTM step of SURVEY 8(d) is loop time / T
+        import ctypes as _C
+        lib.ssc_prof_loop_enable(1)
+        fwd_loop_ms, bwd_loop_ms = [], []
+        for i in range(3):
+            feats, caps, senti, eps = batches[i % len(batches)]
+            eng.forward(feats, caps, senti, eps)
+            eng.backward(torch.full((B,), 1.0 / B, device=device), torch.full((B,), 1.0 / (B * 750.0), device=device))
+            f_ms, b_ms = _C.c_float(), _C.c_float()
+            lib.ssc_prof_loop_ms(_C.byref(f_ms), _C.byref(b_ms))
+            fwd_loop_ms.append(f_ms.value)
+            bwd_loop_ms.append(b_ms.value)
+        lib.ssc_prof_loop_enable(0)
+        # (b) a hipEvent pair around every GEMM launch of two further steps
+        lib.ssc_prof_enable(1)
         for i in range(nprof):
             feats, caps, senti, eps = batches[i % len(batches)]
-            ev0.record()
             eng.forward(feats, caps, senti, eps)
-            ev1.record()
             torch.cuda.synchronize()
-            fwd_ms.append(ev0.elapsed_time(ev1))
-            B = c["B"]
             eng.backward(torch.full((B,), 1.0 / B, device=device), torch.full((B,), 1.0 / (B * 750.0), device=device))
         buf = torch.zeros(4096 * 6, dtype=torch.float32)
         n = lib.ssc_prof_collect(buf.data_ptr(), 4096)
@@ -359,12 +404,15 @@ def main():
         step_recs = [r for r in rec.tolist() if int(r[0]) == 0 and int(r[1]) == c["B"] and int(r[2]) == 4 * c["H"]]
         T = c["L"] + 1
         fused = fused_step_bytes(c)
-        fwd_step_us = (sum(fwd_ms) / len(fwd_ms)) / T * 1e3   # whole forward / T: upper bound on one fused step
-        roofline_step = {"bound": "hbm", "scope": "fused attention+LSTM step (SURVEY §8(d)), forward, incl. its share of "
-                         "the hoisted/vocab work", "achieved": fused / (fwd_step_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": fused / (fwd_step_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+        fwd_step_us = sorted(fwd_loop_ms)[len(fwd_loop_ms) // 2] / T * 1e3   # the time loop alone, median of 3 calls
+        bwd_step_us = sorted(bwd_loop_ms)[len(bwd_loop_ms) // 2] / T * 1e3
+        roofline_step = {"bound": "hbm", "scope": "fused attention+LSTM step (SURVEY 8(d): rows #7-#11, excl. the vocabulary head "
+                         "and the hoisted per-sequence terms), forward: time of the T-step loop of ssc_train_fwd / T (hipEvent pair "
+                         "around the loop, no other instrumentation)", "achieved": fused / (fwd_step_us * 1e-6) / 1e9,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fused / (fwd_step_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_step": fused, "us_per_step": fwd_step_us,
-                         "gate_gemm_us_per_step": sum(r[5] for r in step_recs) / nprof / T * 1e3}
+                         "gate_gemm_us_per_step_with_event_overhead": sum(r[5] for r in step_recs) / nprof / T * 1e3,
+                         "bptt_us_per_step": bwd_step_us}
         result = {"metric": "captions/sec (train step)", "value": value, "unit": "captions/s", "n_gpus": world,
                   "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
                   "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -375,6 +423,11 @@ def main():
                   "roofline_step": roofline_step,
                   "gemm_time_ms_per_step": {names[k]: agg[k]["ms"] / nprof for k in agg}}
         result["attention_roofline"] = attention_roofline(device)
+    if rank == 0 and dres is not None:
+        result["decode_tokens_per_s"] = dres["value"]
+        result["decode"] = {k: dres[k] for k in ("metric", "value", "unit", "steps", "ms_per_step", "config", "captions_per_s",
+                                                 "row_steps_per_s", "early_stop_disabled")}
+    if rank == 0 and not args.timed_only:
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(c)
         print(json.dumps(result), flush=True)

@@ -11,8 +11,10 @@
  *  - plain C: raw device pointers, ints, floats; no torch / C++ types.
  *  - all tensors fp32 row-major unless noted; token ids int64; `ld*` = leading dimension in floats.
  *  - every buffer is caller-allocated device memory (e.g. torch tensor .data_ptr()), kept alive by
- *    the caller until `stream` is synchronised.  The library allocates nothing, keeps no global
- *    mutable state, is re-entrant per stream and safe under hipGraph capture.
+ *    the caller until `stream` is synchronised.  The library allocates nothing and is re-entrant per
+ *    stream and safe under hipGraph capture.  Process-wide state: the numerics mode of NT products
+ *    (ssc_set_gemm_mode, below) and the opt-in diagnostics / tuning switches of ssc_debug.h, which are
+ *    not part of this ABI.
  *  - `stream` is a hipStream_t passed as void* (0 = default stream).
  *  - return value: 0 on success, negative SSC_E* otherwise; never throws.
  */
@@ -83,14 +85,6 @@ int ssc_gemm(const ssc_gemm_desc* d, void* stream);
  * accumulation (error ~ one fp32 rounding per product); mode 0 uses the exact-fp32 MFMA v_mfma_f32_32x32x2_f32.
  * Process-wide; returns the previous mode.  Environment default: SSC_GEMM_MODE=x3|f32. */
 int ssc_set_gemm_mode(int mode);
-/* tuning hook: minimum N at which M<=64 products use the 64x128 block tile; returns the previous value */
-int ssc_set_gemm_wide_min_n(int n);
-
-/* In-situ GEMM profiling for bench.py's roofline leg (process-global switch, not thread-safe, off by default):
- * while enabled every GEMM launch is bracketed by a hipEvent pair on its stream.  ssc_prof_collect synchronises the
- * device and writes up to max_records x 6 floats {kind (0 NT,1 NN,3 TN), M, N, sum K, splits, milliseconds}. */
-int ssc_prof_enable(int on);
-int ssc_prof_collect(float* out, int max_records);
 int ssc_gemm_auto_splits(int M, int N, int ksteps); /* the split count ssc_gemm picks for splits=0 */
 
 /* ------------------------------------------------------------------------------------------------

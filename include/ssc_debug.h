@@ -1,0 +1,47 @@
+/*
+ * ssc_debug.h - diagnostics, profiling and tuning switches of libssc_hip.so.  NOT part of the product ABI (ssc.h):
+ * nothing here is needed to run the hot path, and everything here is process-global and not thread-safe.
+ * Used by bench.py (roofline leg), tools/ and the kernel-form tests.
+ */
+#ifndef SSC_DEBUG_H
+#define SSC_DEBUG_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* In-situ GEMM profiling: while enabled every GEMM launch is bracketed by a hipEvent pair on its stream.
+ * ssc_prof_collect synchronises the device and writes up to max_records x 6 floats
+ * {kind (0 NT, 1 NN, 3 TN), M, N, sum K, splits, milliseconds}; returns the record count. */
+int ssc_prof_enable(int on);
+int ssc_prof_collect(float* out, int max_records);
+
+/* Time-loop timing of ssc_train_fwd / ssc_train_bwd: while enabled a hipEvent pair brackets the T-step loop itself
+ * (precompute, hoisted products, vocabulary head and the weight-gradient products are outside).  ssc_prof_loop_ms
+ * synchronises the events of the LAST forward / backward call and returns the loop times in milliseconds
+ * (negative when that call has not run since the switch was turned on). */
+int ssc_prof_loop_enable(int on);
+int ssc_prof_loop_ms(float* fwd_loop_ms, float* bwd_loop_ms);
+
+/* Named switches between kernel forms that compute the same product (A/B measurements, kernel-form tests).
+ * Keys (default; environment variable read once at load):
+ *   "large_form"  large products: 0 64-wide kernels | 3 4-wave 128x128 3xBF16 kernel (default) | 2 wave-specialised
+ *                 128x128 | 1 by grid size                                                        (SSC_X3B)
+ *   "x3w_skinny"  minibatch products on the wave-specialised 64x256 kernel: 0 | 1 NT+NN (default) | 2 NN only (SSC_X3W_SKINNY)
+ *   "x3w_min_n"   ... from this output width on (1024)                                             (SSC_X3W_MIN_N)
+ *   "x3_wide" (0), "x3_nbuf" (1), "x3_pf" (2)   forms of the 64-wide 3xBF16 kernel
+ *   "wide_min_n"  exact-fp32 kernels: 64x128 tile for M <= 64 from this width on (1024)
+ *   "gemm_group"  grouped launches of independent minibatch products (1)                          (SSC_GEMM_GROUP)
+ *   "dw_group"    grouped launches of the weight-gradient products (1)                            (SSC_DW_GROUP)
+ * Returns SSC_EINVAL for an unknown key. */
+int ssc_debug_set(const char* key, int value);
+int ssc_debug_get(const char* key, int* value);
+
+/* resident workgroups per CU the runtime reports for the GEMM kernels (tools/occ.py) */
+int ssc_debug_gemm_occupancy(int* out4);
+int ssc_debug_gemm_occupancy_x3b(int* out4);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

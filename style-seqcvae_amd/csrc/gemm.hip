@@ -20,8 +20,10 @@
 // Split-K: grid.z workgroups per tile write partial slabs that a second kernel (or the fused LSTM /
 // latent epilogue kernels) sums in a fixed order -> deterministic, no float atomics.
 #include <stdlib.h>
+#include <string.h>
 
 #include "ssc_common.h"
+#include "ssc_debug.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -1429,21 +1431,6 @@ __global__ __launch_bounds__(512) void gemm_x3w_kernel(const KGroup g) {
   x3w_body<A_KC, B_KC, KG, TM, TN, PF>(g.a[p], x, yz % gy, yz / gy, gx, gy, gz);
 }
 
-__device__ unsigned long long g_shadow[4];   // SSC_SHADOW diagnostic: {elements compared, mismatches, NaN/Inf in x3w, first bad index}
-__global__ void shadow_compare_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb, int M, int N) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (size_t)M * N) return;
-  const int r = (int)(i / N), c = (int)(i % N);
-  const float x = a[(size_t)r * lda + c], y = b[(size_t)r * ldb + c];
-  const bool bad_num = !(fabsf(x) < 3e38f);
-  const bool diff = !(fabsf(x - y) <= 1e-3f * (fabsf(x) + fabsf(y)) + 1e-3f);
-  if (threadIdx.x == 0) atomicAdd(&g_shadow[0], (unsigned long long)min((size_t)256, (size_t)M * N - i));
-  if (bad_num) atomicAdd(&g_shadow[2], 1ull);
-  if (diff) {
-    if (atomicAdd(&g_shadow[1], 1ull) == 0) g_shadow[3] = i;
-  }
-}
-
 __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int nslab, size_t slab_stride, int M, int N,
                                     float* __restrict__ C, int ldc, const float* __restrict__ bias, int accumulate,
                                     const int* __restrict__ mcount, const int* __restrict__ crows) {
@@ -1525,6 +1512,8 @@ inline int gemm_mode() {
   return g_gemm_mode;
 }
 inline bool use_x3(const ssc_gemm_desc* d, bool vec) { return gemm_mode() == 1 && d->a_kc && d->b_kc && vec; }
+// Tuning / diagnostic switches (include/ssc_debug.h: ssc_debug_set / ssc_debug_get; environment defaults in parentheses).
+// They select between kernel forms that compute the same product; none is part of the product ABI.
 int g_x3b = getenv("SSC_X3B") ? atoi(getenv("SSC_X3B")) : 3;  // large products (M, N >= 512): 0 = 64x64 kernels, 3 (default) = the 4-wave 128x128 3xBF16 kernel, 2 = its wave-specialised form, 1 = chosen by grid size (hooks -8, -9, -10, -14).  The wave-specialised 128x128 form is opt-in: it is ~5-10 % faster on grids several rounds deep (decode), but one long decode run ended in an unexplained GPU memory fault with it
 int g_x3_nbuf = 1;  // single LDS stage: 31 KB per workgroup -> four resident workgroups per CU (rocprof r01: 37 vs 43 us)
 int g_x3_wide = 0;
@@ -1566,6 +1555,8 @@ int x3w_prepare() {
 }
 int g_x3w_skinny = getenv("SSC_X3W_SKINNY") ? atoi(getenv("SSC_X3W_SKINNY")) : 1;  // 0 off, 1 NT and NN, 2 NN only (hook -11 / -12 / -13)
 int g_x3w_min_n = getenv("SSC_X3W_MIN_N") ? atoi(getenv("SSC_X3W_MIN_N")) : 1024;   // narrower products do not fill the chip with 256-column tiles (rocprof: slower than the 64-wide kernels)
+int g_gemm_group = getenv("SSC_GEMM_GROUP") ? atoi(getenv("SSC_GEMM_GROUP")) : 1;   // grouped launches of independent minibatch products
+int g_dw_group = getenv("SSC_DW_GROUP") ? atoi(getenv("SSC_DW_GROUP")) : 1;       // grouped launches of the weight-gradient products (wave-specialised 128x128 form); 0 = one 4-wave launch per product
 inline bool x3w_skinny_shape(int M, int N) { return g_x3w_skinny && gemm_mode() == 1 && M <= 64 && N >= g_x3w_min_n; }
 inline bool x3w_skinny(const ssc_gemm_desc* d, bool vec) {   // 2 = only where the weight matrix is [K][N] (backward dG W)
   return vec && d->a_kc && x3w_skinny_shape(d->M, d->N) && (g_x3w_skinny == 1 || !d->b_kc);
@@ -1625,23 +1616,6 @@ int launch(const ssc_gemm_desc* d, KArgs& k, int splits, hipStream_t st) {
       KGroup g1;
       group_of_one(g1, k, grid);
       SSC_LAUNCH(fn, dim3(g1.first[1]), dim3(512), (x3w_lds_bytes<128, 128>()), st, g1);
-      static const bool shadow = getenv("SSC_SHADOW") != nullptr;   // diagnostic: recompute with the 4-wave kernel and compare
-      if (shadow && !compact && splits == 1 && !k.accumulate) {
-        static float* scratch = nullptr;
-        static size_t cap = 0;
-        const size_t need = (size_t)d->M * d->N;
-        if (need > cap) {
-          if (scratch) (void)hipFree(scratch);
-          if (hipMalloc(&scratch, need * sizeof(float)) != hipSuccess) return SSC_EHIP;
-          cap = need;
-        }
-        KArgs k2 = k;
-        k2.out = scratch; k2.ldo = d->N; k2.slab_stride = 0;
-        if (d->a_kc && d->b_kc) SSC_LAUNCH((gemm_x3b_kernel<true, true, false>), grid, dim3(256), 0, st, k2);
-        else if (d->a_kc) SSC_LAUNCH((gemm_x3b_kernel<true, false, false>), grid, dim3(256), 0, st, k2);
-        else SSC_LAUNCH((gemm_x3b_kernel<false, false, false>), grid, dim3(256), 0, st, k2);
-        SSC_LAUNCH(shadow_compare_kernel, dim3((unsigned)((need + 255) / 256)), dim3(256), 0, st, k.out, k.ldo, scratch, d->N, d->M, d->N);
-      }
     } else
     if (d->a_kc && d->b_kc) SSC_LAUNCH((gemm_x3b_kernel<true, true, false>), grid, dim3(256), 0, st, k);
     else if (d->a_kc) SSC_LAUNCH((gemm_x3b_kernel<true, false, false>), grid, dim3(256), 0, st, k);
@@ -1787,7 +1761,7 @@ int ssc_gemm_slabs_auto(const ssc_gemm_desc* d, float* slabs, size_t cap_floats,
 int ssc_gemm_slabs_group(const ssc_gemm_desc* const* d, int n, float* const* regions, const size_t* caps, int* nslab,
                          hipStream_t st) {
   if (!d || n < 1 || n > SSC_GROUP_MAX || !regions || !caps || !nslab) return SSC_EINVAL;
-  static const bool group_on = !(getenv("SSC_GEMM_GROUP") && atoi(getenv("SSC_GEMM_GROUP")) == 0);   // A/B switch (tools)
+  const bool group_on = g_gemm_group != 0;
   KGroup g;
   bool ok = n >= 2 && group_on;
   long work = 0;
@@ -1861,7 +1835,7 @@ int ssc_gemm_slabs_group(const ssc_gemm_desc* const* d, int n, float* const* reg
 // workgroup per CU no longer loses to tile quantisation (380 tiles on 256 CUs) - the others one by one.
 int ssc_gemm_dw_group(const ssc_gemm_desc* const* d, int n, hipStream_t st) {
   if (!d || n < 1) return SSC_EINVAL;
-  static const bool group_on = !(getenv("SSC_GEMM_GROUP") && atoi(getenv("SSC_GEMM_GROUP")) == 0);   // A/B switch (tools)
+  const bool group_on = g_gemm_group != 0 && g_dw_group != 0;
   int i = 0;
   while (i < n) {
     KGroup g;
@@ -1991,32 +1965,33 @@ extern "C" int ssc_set_gemm_mode(int mode) {
   return prev;
 }
 
-// tuning hook (tools/gemm_probe.py): minimum N for the 64x128 skinny tile; returns the previous value
-extern "C" int ssc_set_gemm_wide_min_n(int n) {
-  int prev = g_wide_min_n;
-  if (n > 0) g_wide_min_n = n;
-  if (n == -1) g_x3_wide = 1;   // probe hooks: -1 / -2 switch the 3xBF16 wide tile on / off
-  if (n == -2) g_x3_wide = 0;
-  if (n == -3) g_x3_nbuf = 1;
-  if (n == -4) g_x3_nbuf = 2;
-  if (n == -5) g_x3_pf = 1;
-  if (n == -6) g_x3_pf = 2;
-  if (n == -7) g_x3_pf = 4;
-  if (n == -8) g_x3b = 0;       // large products back on the 64x64 3xBF16 (NT) / fp32 MFMA (NN, TN) kernels
-  if (n == -9) g_x3b = 3;   // (tests: the 4-wave form regardless of the grid)
-  if (n == -10) g_x3b = 2;
-  if (n == -14) g_x3b = 3;   // (tests: back to the default)
-  if (n == -17) g_x3b = 1;
-  if (n == -11) g_x3w_skinny = 0;
-  if (n == -12) g_x3w_skinny = 1;
-  if (n == -13) g_x3w_skinny = 2;      // ... on the wave-specialised (producer / consumer) form of that kernel
-  return prev;
-}
+// ---- include/ssc_debug.h -----------------------------------------------------------------------------------------
+namespace {
+struct DebugKey { const char* name; int* var; };
+const DebugKey g_debug_keys[] = {
+    {"large_form", &g_x3b},          // large products (M, N >= 512): 0 = 64-wide kernels, 3 = 4-wave 128x128 3xBF16 kernel (default), 2 = its wave-specialised form, 1 = chosen by grid size   (SSC_X3B)
+    {"x3_wide", &g_x3_wide},         // 64x128 block tile for 3xBF16 products with M <= 64, N >= 1024 on the 4-wave kernel
+    {"x3_nbuf", &g_x3_nbuf},         // LDS stages of the 64-wide 3xBF16 kernel (1 | 2)
+    {"x3_pf", &g_x3_pf},             // register prefetch depth of the 64-wide 3xBF16 kernel (1 | 2 | 4)
+    {"x3w_skinny", &g_x3w_skinny},   // minibatch products on the wave-specialised 64x256 kernel: 0 off, 1 NT and NN (default), 2 NN only   (SSC_X3W_SKINNY)
+    {"x3w_min_n", &g_x3w_min_n},     // ... from this output width on   (SSC_X3W_MIN_N)
+    {"wide_min_n", &g_wide_min_n},   // exact-fp32 kernels: 64x128 tile for M <= 64 from this width on
+    {"gemm_group", &g_gemm_group},   // grouped launches of independent minibatch products (0 | 1)   (SSC_GEMM_GROUP)
+    {"dw_group", &g_dw_group},       // grouped launches of the weight-gradient products (0 | 1)   (SSC_DW_GROUP)
+};
+}  // namespace
 
-// diagnostic: SSC_SHADOW record {elements compared, mismatches, non-finite, first bad index}
-extern "C" int ssc_debug_gemm_shadow(unsigned long long* out4) {
-  if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_shadow), 4 * sizeof(unsigned long long)) != hipSuccess) return SSC_EHIP;
-  return SSC_OK;
+extern "C" int ssc_debug_set(const char* key, int value) {
+  if (!key) return SSC_EINVAL;
+  for (const DebugKey& k : g_debug_keys)
+    if (!strcmp(k.name, key)) { *k.var = value; return SSC_OK; }
+  return SSC_EINVAL;
+}
+extern "C" int ssc_debug_get(const char* key, int* value) {
+  if (!key || !value) return SSC_EINVAL;
+  for (const DebugKey& k : g_debug_keys)
+    if (!strcmp(k.name, key)) { *value = *k.var; return SSC_OK; }
+  return SSC_EINVAL;
 }
 
 // diagnostic: resident workgroups per CU the runtime reports for the GEMM kernels (tools/, not used by the product path)

@@ -16,6 +16,7 @@
 #include <initializer_list>
 
 #include "ssc_common.h"
+#include "ssc_debug.h"
 
 namespace {
 
@@ -206,7 +207,8 @@ int flush_dw(const Ctx& c, DwBatch& q) {
     const bool al = ssc_aligned16(d.seg[0].A) && ssc_aligned16(d.seg[0].B) && !(d.seg[0].lda & 3) && !(d.seg[0].ldb & 3) && !(d.M & 3) && !(d.N & 3);
     if (!al) d.k_count = d.ka_rows = d.kb_rows = nullptr;
   }
-  static const bool grouped = !(getenv("SSC_DW_GROUP") && atoi(getenv("SSC_DW_GROUP")) == 0);   // A/B switch (tools)
+  int grouped = 1;
+  (void)ssc_debug_get("dw_group", &grouped);   // include/ssc_debug.h: 0 = one 4-wave launch per product (A/B switch)
   if (!grouped) {
     int rc1 = SSC_OK;
     for (int i = 0; i < q.n && rc1 == SSC_OK; ++i) {
@@ -316,7 +318,35 @@ int check_cfg(const ssc_model_cfg* c, const ssc_params* p, const ssc_batch* b) {
   return SSC_OK;
 }
 
+// include/ssc_debug.h: hipEvent pair around the time loop of the last forward / backward call
+struct LoopProf {
+  hipEvent_t e[4];
+  bool created = false, on = false, fwd = false, bwd = false;
+} g_loop;
+
 }  // namespace
+
+extern "C" int ssc_prof_loop_enable(int on) {
+  if (on && !g_loop.created) {
+    for (hipEvent_t& e : g_loop.e)
+      if (hipEventCreate(&e) != hipSuccess) return SSC_EHIP;
+    g_loop.created = true;
+  }
+  g_loop.on = on != 0;
+  g_loop.fwd = g_loop.bwd = false;
+  return SSC_OK;
+}
+extern "C" int ssc_prof_loop_ms(float* fwd_loop_ms, float* bwd_loop_ms) {
+  if (!fwd_loop_ms || !bwd_loop_ms) return SSC_EINVAL;
+  *fwd_loop_ms = *bwd_loop_ms = -1.f;
+  if (g_loop.fwd) {
+    if (hipEventSynchronize(g_loop.e[1]) != hipSuccess || hipEventElapsedTime(fwd_loop_ms, g_loop.e[0], g_loop.e[1]) != hipSuccess) return SSC_EHIP;
+  }
+  if (g_loop.bwd) {
+    if (hipEventSynchronize(g_loop.e[3]) != hipSuccess || hipEventElapsedTime(bwd_loop_ms, g_loop.e[2], g_loop.e[3]) != hipSuccess) return SSC_EHIP;
+  }
+  return SSC_OK;
+}
 
 extern "C" size_t ssc_train_workspace_bytes(const ssc_model_cfg* cfg, int B, int R, int L) {
   if (!cfg || B <= 0 || R <= 0 || L <= 0) return 0;
@@ -391,6 +421,7 @@ extern "C" int ssc_train_fwd(const ssc_model_cfg* cfg, const ssc_params* p, cons
   const bool fc_adjacent = (p->fc_lv_w == p->fc_mean_w + (size_t)Z * p->ld_fc_mean_w) && p->ld_fc_lv_w == p->ld_fc_mean_w;
 
   // ---- time loop ----------------------------------------------------------------------------------
+  if (g_loop.on) { (void)hipEventRecord(g_loop.e[0], st); }
   for (int t = 0; t < T; ++t) {
     float* h1p = W + l.h1 + t * sH; float* h1n = h1p + sH;
     float* c1p = W + l.c1 + t * sH; float* c1n = c1p + sH;
@@ -480,6 +511,8 @@ extern "C" int ssc_train_fwd(const ssc_model_cfg* cfg, const ssc_params* p, cons
     }
   }
 
+  if (g_loop.on) { (void)hipEventRecord(g_loop.e[1], st); g_loop.fwd = true; }
+
   // ---- vocabulary projection + CE over all steps (updown_captioner.py:444-445, 457-466) -----------
   const float* hd_all = W + l.hd + sH;  // rows t*B+b = h_dec after step t
   // only the rows with a real target are projected (ssc_ce_fwd skips the others)
@@ -557,6 +590,7 @@ static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const s
   int n_gh1 = 0, n_ghd = 0, n_ghe = 0;  // slab counts carried from step t+1 (none at t = T-1)
   const size_t sBH = (size_t)B * H;
 
+  if (g_loop.on) { (void)hipEventRecord(g_loop.e[2], st); }
   for (int t = T - 1; t >= 0; --t) {
     float* dgd = W + l.dgd + (size_t)t * B * H4;
     float* dge = W + l.dge + (size_t)t * B * H4;
@@ -646,6 +680,8 @@ static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const s
       n_gh1 = ns3[0]; n_ghd = ns3[1]; n_ghe = ns3[2];
     }
   }
+
+  if (g_loop.on) { (void)hipEventRecord(g_loop.e[3], st); g_loop.bwd = true; }
 
   if (S) {  // sentiment replicated over time (row = t*B+b) for the rank-1 column gradients
     SSC_LAUNCH(repeat_kernel, dim3(ssc_cdiv(TB, 256)), dim3(256), 0, st, bt->sentiment, B, T, W + l.sent_all);

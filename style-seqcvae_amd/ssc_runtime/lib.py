@@ -108,9 +108,6 @@ SYMBOLS = {
     "ssc_gemm": (_i, [C.POINTER(GemmDesc), vp]),
     "ssc_gemm_auto_splits": (_i, [_i, _i, _i]),
     "ssc_set_gemm_mode": (_i, [_i]),
-    "ssc_set_gemm_wide_min_n": (_i, [_i]),
-    "ssc_prof_enable": (_i, [_i]),
-    "ssc_prof_collect": (_i, [vp, _i]),
     "ssc_feat_prep": (_i, [vp, _i, _i, _i, vp, vp, vp]),
     "ssc_prep_tokens": (_i, [vp, _i, _i, _i, _i, vp, vp, vp, vp]),
     "ssc_embed_gather": (_i, [vp, _i, vp, _i, _i, vp, _i, vp]),
@@ -152,13 +149,25 @@ SYMBOLS = {
     "ssc_beam_backtrace": (_i, [vp, vp, _i, _i, _i, vp, vp]),
 }
 
+# include/ssc_debug.h (diagnostics / profiling / tuning switches: not part of the product ABI)
+DEBUG_SYMBOLS = {
+    "ssc_prof_enable": (_i, [_i]),
+    "ssc_prof_collect": (_i, [vp, _i]),
+    "ssc_prof_loop_enable": (_i, [_i]),
+    "ssc_prof_loop_ms": (_i, [C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "ssc_debug_set": (_i, [C.c_char_p, _i]),
+    "ssc_debug_get": (_i, [C.c_char_p, C.POINTER(C.c_int)]),
+    "ssc_debug_gemm_occupancy": (_i, [vp]),
+    "ssc_debug_gemm_occupancy_x3b": (_i, [vp]),
+}
+
 _lib = None
 
 
 class _Lib:
     def __init__(self, cdll):
         self._cdll = cdll
-        for name, (res, args) in SYMBOLS.items():
+        for name, (res, args) in list(SYMBOLS.items()) + list(DEBUG_SYMBOLS.items()):
             fn = getattr(cdll, name)  # AttributeError if the .so lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
@@ -168,7 +177,7 @@ class _Lib:
         raw = self.__dict__.get("_raw_" + name)
         if raw is None:
             raise AttributeError(name)
-        if raw.restype is not C.c_int or name in ("ssc_version", "ssc_last_hip_error", "ssc_gemm_auto_splits", "ssc_prof_collect", "ssc_set_gemm_mode", "ssc_set_gemm_wide_min_n"):
+        if raw.restype is not C.c_int or name in ("ssc_version", "ssc_last_hip_error", "ssc_gemm_auto_splits", "ssc_prof_collect", "ssc_set_gemm_mode"):
             return raw
 
         def checked(*a):

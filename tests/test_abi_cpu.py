@@ -11,8 +11,8 @@ from ssc_runtime import lib as L
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_symbols():
-    text = open(os.path.join(ROOT, "include", "ssc.h")).read()
+def header_symbols(name="ssc.h"):
+    text = open(os.path.join(ROOT, "include", name)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(ssc_[a-z0-9_]+)\s*\(", text)))
 
@@ -27,6 +27,26 @@ def test_library_exports_every_declared_symbol():
         assert n in L.SYMBOLS, f"{n} missing from the ctypes table"
     assert sorted(L.SYMBOLS) == names
     assert lib.ssc_version() == 1 and lib.ssc_arch() == b"gfx950"
+    # diagnostics / profiling / tuning switches live in their own header, outside the product ABI
+    dbg = header_symbols("ssc_debug.h")
+    assert sorted(L.DEBUG_SYMBOLS) == dbg and not set(dbg) & set(names)
+    for n in dbg:
+        assert hasattr(cdll, n), f"{n} declared in include/ssc_debug.h but not exported"
+    assert not [n for n in names if n.startswith("ssc_debug") or n.startswith("ssc_prof")]
+
+
+def test_debug_switches_by_name():
+    lib = L.load()
+    v = C.c_int(-1)
+    lib.ssc_debug_get(b"large_form", C.byref(v))
+    assert v.value in (0, 1, 2, 3)
+    prev = v.value
+    lib.ssc_debug_set(b"large_form", 2)
+    lib.ssc_debug_get(b"large_form", C.byref(v))
+    assert v.value == 2
+    lib.ssc_debug_set(b"large_form", prev)
+    with pytest.raises(L.SscError, match="SSC_EINVAL"):
+        lib.ssc_debug_set(b"no_such_switch", 1)
 
 
 def test_struct_layouts_match_header_field_order():

@@ -222,12 +222,12 @@ def test_gemm_compaction_needs_split_mode():
     ("NN", 1344, 1200, [10000], 5), ("NN", 1344, 1000, [4800], 0), ("NN", 516, 644, [1204, 100], 1),
     ("TN", 4800, 1200, [1344], 1), ("TN", 10000, 1200, [1344], 0), ("TN", 768, 2048, [2304], 5), ("TN", 520, 600, [1350, 77], 3),
 ])
-@pytest.mark.parametrize("form", [-9, -10])
+@pytest.mark.parametrize("form", [3, 2])
 def test_large_products_split_bf16(kind, M, N, Ks, splits, form):
     """The 128x128 3xBF16 kernel (all three layouts; the m/n-contiguous operands go through the transposing LDS read)
     against float64: fp32-level accuracy, error <= 2e-6 * sum|a||b|."""
     a_kc, b_kc = {"NT": (1, 1), "NN": (1, 0), "TN": (0, 0)}[kind]
-    L.load().ssc_set_gemm_wide_min_n(form)   # -9: 4-wave 128x128 kernel, -10: its wave-specialised form
+    L.load().ssc_debug_set(b"large_form", form)   # 3: 4-wave 128x128 kernel (default), 2: its wave-specialised form
     g = torch.Generator().manual_seed(M + N + len(Ks))
     As = [(torch.randn((M, K) if a_kc else (K, M), generator=g) * torch.exp(torch.randn((M, K) if a_kc else (K, M), generator=g))).cuda() for K in Ks]
     Bs = [(torch.randn((N, K) if b_kc else (K, N), generator=g) * torch.exp(torch.randn((N, K) if b_kc else (K, N), generator=g))).cuda() for K in Ks]
@@ -254,19 +254,19 @@ def test_large_products_split_bf16(kind, M, N, Ks, splits, form):
         ad, bd = a.cpu().double(), b.cpu().double()
         refi += (ad if a_kc else ad.T) @ (bd.T if b_kc else bd)
     assert torch.equal(out.cpu().double(), refi)
-    L.load().ssc_set_gemm_wide_min_n(-14)
+    L.load().ssc_debug_set(b"large_form", 3)
 
 
-@pytest.mark.parametrize("form", [-12, -13, -11])
+@pytest.mark.parametrize("form", [1, 2, 0])
 @pytest.mark.parametrize("kind,N,Ks,splits", [("NT", 4800, [2048, 1200, 1200, 1200], 0), ("NN", 4448, [4800, 4800], 0),
                                               ("NN", 2052, [1000, 36], 3), ("NT", 2300, [1204], 1)])
 def test_minibatch_products_wave_specialised(kind, N, Ks, splits, form):
-    """M = 64 rows against a wide weight matrix on the 64x256 producer/consumer kernel (-12: NT and NN, -13: NN only,
-    -11: off = 64-wide kernels): same fp32-level accuracy in every form."""
+    """M = 64 rows against a wide weight matrix on the 64x256 producer/consumer kernel (x3w_skinny 1: NT and NN, 2: NN only,
+    0: off = 64-wide kernels): same fp32-level accuracy in every form."""
     M = 64
     a_kc, b_kc = {"NT": (1, 1), "NN": (1, 0)}[kind]
     lib = L.load()
-    lib.ssc_set_gemm_wide_min_n(form)
+    lib.ssc_debug_set(b"x3w_skinny", form)
     try:
         g = torch.Generator().manual_seed(N)
         As = [torch.randn(M, K, generator=g).cuda() for K in Ks]
@@ -282,6 +282,6 @@ def test_minibatch_products_wave_specialised(kind, N, Ks, splits, form):
             ref += ad @ bd
             mag += ad.abs() @ bd.abs()
         err = ((out.cpu().double() - ref).abs() / mag.clamp_min(1e-30)).max().item()
-        assert err <= (2e-6 if (form != -11 or kind == "NT") else 4e-6), err
+        assert err <= (2e-6 if (form != 0 or kind == "NT") else 4e-6), err
     finally:
-        lib.ssc_set_gemm_wide_min_n(-12)
+        lib.ssc_debug_set(b"x3w_skinny", 1)

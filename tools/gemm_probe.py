@@ -19,16 +19,9 @@ DEFAULT = ["NT:64:4800:2048+1200+1200+1200", "NN:64:4448:4800+4800", "NN:64:1200
 def main():
     import os as _os
     from ssc_runtime import lib as _L
-    if _os.environ.get("SSC_X3_WIDE"):
-        _L.load().ssc_set_gemm_wide_min_n(-1)
-    if _os.environ.get("SSC_X3_PF"):
-        _L.load().ssc_set_gemm_wide_min_n({"1": -5, "2": -6, "4": -7}[_os.environ["SSC_X3_PF"]])
-    if _os.environ.get("SSC_X3_NBUF") == "2":
-        _L.load().ssc_set_gemm_wide_min_n(-4)
-    if _os.environ.get("SSC_X3_NBUF") == "1":
-        _L.load().ssc_set_gemm_wide_min_n(-3)
-    if _os.environ.get("SSC_X3B"):
-        _L.load().ssc_set_gemm_wide_min_n({"0": -8, "1": -9, "2": -10}[_os.environ["SSC_X3B"]])
+    for env, key in (("SSC_X3_WIDE", b"x3_wide"), ("SSC_X3_PF", b"x3_pf"), ("SSC_X3_NBUF", b"x3_nbuf")):   # include/ssc_debug.h
+        if _os.environ.get(env):
+            _L.load().ssc_debug_set(key, int(_os.environ[env]))
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     shapes = sys.argv[2:] or DEFAULT
     for sh in shapes:
