@@ -215,11 +215,16 @@ class UpDownCaptioner(nn.Module):
         return {"predictions": best}
 
     def _image_context(self, image_features):
-        key = (image_features.data_ptr(), tuple(image_features.shape), image_features._version)
-        if self._ctx_cache is None or self._ctx_cache[0] != key or self._ctx_cache[2] != self._eng.param_version():
+        """Per-image terms (mask, averaged features, projected features, hoisted gate term) for the eval decode step, computed
+        once per image set and parameter version.  The cache entry keeps a REFERENCE to the caller's tensor and is hit only
+        for that very tensor object at the same in-place version: a freed tensor's address can be handed to the next batch
+        by the caching allocator (same pointer, same shape, version 0), so a key made of data_ptr/shape would alias."""
+        c = self._ctx_cache
+        if (c is None or c[0] is not image_features or c[1] != image_features._version or
+                c[3] != self._eng.param_version()):
             ctx = self._dec.prepare(image_features.float())
-            self._ctx_cache = (key, ctx, self._eng.param_version())
-        return self._ctx_cache[1]
+            self._ctx_cache = (image_features, image_features._version, ctx, self._eng.param_version())
+        return self._ctx_cache[2]
 
     def _rows(self, t, B, G):
         """(B, k) per-image tensor -> (G, k) per-row, batch-major."""

@@ -283,8 +283,85 @@ def decode_fixture(UpDownCaptioner, name, dims, sv, B=2, R=5, beam=5):
     print(name, "lp0[0,:3]", lp0[0, :3].numpy())
 
 
+FSM_WORDFORMS = "dog\tdog,dogs\ncat\tcat,cats,kitten\nfire\tfire\nhydrant\thydrant,hydrants\nsalt\tsalt\n" \
+                "and\tand\npepper\tpepper,peppers\nred\tred,reddish\nbird\tbird,birds,zzz_not_in_vocab\n"
+FSM_CASES = [[], ["dog"], ["dog", "cat"], ["fire hydrant"], ["dog", "fire hydrant", "salt and pepper"],
+             ["red", "dog", "red"], ["bird", "bird"], ["cat", "salt and pepper"]]
+
+
+def fsm_fixture(name="g9_fsm"):
+    """FiniteStateMachineBuilder.build (updown-baseline/updown/utils/constraints.py:328-361) on a toy vocabulary: the
+    adjacency tensors (trimmed to the states in use, as the reference's collate does), the next-sub-state index and
+    constraint2states for single-word, multi-word, repeated and out-of-vocabulary constraints."""
+    import json
+    import tempfile
+
+    def mod(n, **attrs):
+        m = types.ModuleType(n)
+        m.__dict__.update(attrs)
+        sys.modules[n] = m
+
+    mod("anytree")                                     # only the ConstraintFilter uses it; bare symbols suffice to import
+    mod("anytree.search", findall=lambda *a, **k: [])
+    from updown.utils.constraints import FiniteStateMachineBuilder
+    words = ["a", "the", "dog", "dogs", "cat", "cats", "kitten", "fire", "hydrant", "hydrants", "salt", "and", "pepper",
+             "peppers", "red", "reddish", "bird", "birds", "on", "street"]
+    vocab = ToyVocabulary(2)
+    vocab._tokens += words
+    vocab._index = {t: i for i, t in enumerate(vocab._tokens)}
+    data = {"wordforms_tsv": np.array(FSM_WORDFORMS), "vocab_tokens": np.array(json.dumps(vocab._tokens))}
+    with tempfile.TemporaryDirectory() as td:
+        tsv = os.path.join(td, "wordforms.tsv")
+        open(tsv, "w").write(FSM_WORDFORMS)
+        for kmax in (3, 2):
+            builder = FiniteStateMachineBuilder(vocab, tsv, None, max_given_constraints=kmax)
+            for ci, cons in enumerate(FSM_CASES):
+                if len(cons) > kmax:
+                    continue
+                fsm, nstates, c2s = builder.build(list(cons))
+                key = f"k{kmax}/case{ci}"
+                data[key + "/constraints"] = np.array(json.dumps(cons))
+                data[key + "/nstates"] = np.array(nstates)
+                data[key + "/fsm_bits"] = np.packbits(fsm[:nstates, :nstates, :].numpy().astype(np.uint8))
+                data[key + "/constraint2states"] = np.array(json.dumps(c2s))
+                print(name, key, cons, "states", nstates, c2s)
+        # select_best_beam_with_constraints (updown-baseline/updown/utils/decoding.py:30-138), both branches, on the machines
+        # of three-constraint inputs: objects with and without attribute constraints
+        from updown.utils.decoding import select_best_beam_with_constraints
+        builder = FiniteStateMachineBuilder(vocab, tsv, None, max_given_constraints=3)
+        g = torch.Generator().manual_seed(5)
+        sel_cases = [
+            (["red", "dog", "cat"], [["dog", ["red"]], ["cat", []]], 2),
+            (["red", "dog", "cat"], [["dog", ["red"]], ["cat", []]], 1),
+            (["dog", "cat", "bird"], [["dog", []], ["cat", []], ["bird", []]], 2),
+            (["red", "dog"], [["dog", ["red"]]], 2),
+            (["dog"], [["dog", []]], 2),
+        ]
+        for si, (cons, cands, min_sat) in enumerate(sel_cases):
+            fsm, nstates, c2s = builder.build(list(cons))
+            S, beam, steps = nstates, 3, 6
+            beams = torch.randint(0, len(vocab._tokens), (1, S, beam, steps), generator=g)
+            lps = -torch.rand(1, S, beam, generator=g) * 10
+            given = torch.tensor([len(cons)])
+            for simple in (True, False):
+                best, valid = select_best_beam_with_constraints(beams, lps, given, [cands], [c2s], min_sat, simple)
+                key = f"sel/case{si}/simple{int(simple)}"
+                data[key + "/best"] = best.numpy()
+                data[key + "/valid"] = valid.numpy()
+            key = f"sel/case{si}"
+            data[key + "/constraints"] = np.array(json.dumps(cons))
+            data[key + "/candidates"] = np.array(json.dumps(cands))
+            data[key + "/constraint2states"] = np.array(json.dumps(c2s))
+            data[key + "/min"] = np.array(min_sat)
+            data[key + "/beams"] = beams.numpy()
+            data[key + "/lps"] = lps.numpy()
+            print(name, key, cons, cands, "best", best.tolist()[0][:3], "valid rows", valid.shape[1])
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **data)
+
+
 def main():
     UpDownCaptioner = import_reference()
+    fsm_fixture()
     #        V    E   H   A   F   Z   L
     toy = (300, 40, 48, 32, 64, 16, 6)
     train_fixture(UpDownCaptioner, "g1_train_sv1", toy, sv=1)

@@ -210,3 +210,91 @@ def test_trivial_fsm_none_equals_all_ones_mask():
     a, alp = cbs_search(start, None, step, ones, 1, steps, beam, 2)
     b, blp = cbs_search(start, None, step, None, 1, steps, beam, 2)
     assert torch.equal(a, b) and torch.equal(alp, blp)
+
+
+# ---- constrained beam search with REAL finite state machines -------------------------------------------------
+def _cbs_setup(tmp_path, kmax):
+    """Toy captioner whose vocabulary holds the constraint word forms, and the FSM builder over it."""
+    from ssc_runtime.constraints import FiniteStateMachineBuilder
+    from ssc_runtime.vocab import Vocabulary
+    words = ["a", "the", "dog", "dogs", "cat", "cats", "fire", "hydrant", "hydrants", "red", "reddish", "on", "street", "sits"]
+    tsv = tmp_path / "wordforms.tsv"
+    tsv.write_text("dog\tdog,dogs\ncat\tcat,cats\nfire\tfire\nhydrant\thydrant,hydrants\nred\tred,reddish\n")
+    vocab = Vocabulary(["@@UNKNOWN@@", "@@BOUNDARY@@"] + words + [f"w{i}" for i in range(40)])
+    return vocab, FiniteStateMachineBuilder(vocab, str(tsv), None, max_given_constraints=kmax)
+
+
+@pytest.mark.parametrize("constraints,min_sat", [(["dog"], 1), (["dog", "cat"], 2), (["fire hydrant", "dog"], 2),
+                                                 (["dog", "cat", "red"], 2), (["dog", "cat", "fire hydrant"], 3)])
+def test_eval_forward_with_built_fsm_matches_oracle(tmp_path, constraints, min_sat):
+    """k = 1..3 constraints (single- and multi-word): the machine comes from ssc_runtime.constraints (bit-identical to the
+    reference builder, tests/test_constraints_cpu.py), the search runs on the device (ssc_beam_*), the best
+    constraint-satisfying beam is selected on the host; predictions equal the oracle's, and the constraint words appear."""
+    vocab, builder = _cbs_setup(tmp_path, 3)
+    V = vocab.get_vocab_size()
+    cfg = oracle.OracleConfig(vocab_size=V, image_feature_size=48, embedding_size=300, hidden_size=32,
+                              attention_projection_size=16, z_space=8, max_caption_length=9, sentiment_vae=1,
+                              senti_prior_multip=0.5, tied=True, beam_size=3)
+    params = oracle.init_params(cfg, seed=31)
+    g = torch.Generator().manual_seed(12)
+    B, R, beam = 1, 5, 3
+    feats = torch.randn(B, R, 48, generator=g)
+    senti = torch.tensor([[1.0]])
+    fsm, nstates, c2s = builder.build_trimmed(constraints)
+    S = nstates
+    eps = [torch.randn(B, 8, generator=g)] + [torch.randn(B * S * beam, 8, generator=g) for _ in range(10)]
+    k = torch.tensor([len(constraints)])
+    want = oracle.eval_forward(params, cfg, feats, senti, fsm, k, eps, beam_size=beam, min_constraints_to_satisfy=min_sat)
+    from var_updown.models import UpDownCaptioner
+
+    class Tied(UpDownCaptioner):   # USE_CBS needs the frozen, output-tied 300-d embedding; the table comes from the state dict
+        def _initialize_glove(self):
+            return torch.zeros(self._vocabulary.get_vocab_size(), self.embedding_size)
+
+    m = Tied(vocab, 48, 300, 32, 16, max_caption_length=9, beam_size=beam, use_cbs=True,
+                        min_constraints_to_satisfy=min_sat, z_space=8, prior_std=1.0, latent_embedding="glove",
+                        sentiment_vae=1, senti_prior_multip=0.5, cbs_simple=True, device=torch.device("cuda"))
+    sd = dict(params)
+    sd["_output_layer.weight"] = sd["_embedding_layer.weight"]
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    m._eps_override = [e.clone() for e in eps]
+    out = m(dev(feats), None, None, sentiment=dev(senti), fsm=fsm, num_constraints=k, constraints=None, constraint2states=None)
+    assert torch.equal(out["predictions"].cpu(), want["predictions"])
+    # the selected beam satisfies at least min(k, min_sat) constraints: count constraints whose words appear in order
+    toks = [vocab.get_token_from_index(int(t)) for t in out["predictions"][0].cpu()]
+    forms = {"dog": {"dog", "dogs"}, "cat": {"cat", "cats"}, "red": {"red", "reddish"}}
+
+    def satisfied(c):
+        ws = c.split()
+        if len(ws) == 1:
+            return any(t in forms[c] for t in toks)
+        return any(toks[i] == "fire" and toks[i + 1] in ("hydrant", "hydrants") for i in range(len(toks) - 1))
+    assert sum(satisfied(c) for c in constraints) >= min(len(constraints), min_sat), toks
+
+
+def test_standalone_attention_module_forward_matches_float64():
+    """BottomUpTopDownAttention.forward (attention.py:36-97) as a callable module on the HIP path."""
+    from var_updown.modules.attention import BottomUpTopDownAttention
+    torch.manual_seed(4)
+    att = BottomUpTopDownAttention(40, 64, 24).cuda()
+    g = torch.Generator().manual_seed(6)
+    B, R = 5, 7
+    q = torch.randn(B, 40, generator=g)
+    feats = torch.randn(B, R, 64, generator=g)
+    mask = torch.ones(B, R)
+    mask[1, 5:] = 0
+    mask[3, 2:] = 0
+    wq, wv, wa = (p.detach().cpu().double() for p in (att._query_vector_projection_layer.weight,
+                                                       att._image_features_projection_layer.weight, att._attention_layer.weight))
+
+    def ref(m):
+        logits = (torch.tanh((q.double() @ wq.t())[:, None, :] + feats.double() @ wv.t()) @ wa.t()).squeeze(-1)
+        if m is None:
+            return torch.softmax(logits, -1)
+        p = torch.softmax(logits * m.double(), -1) * m.double()
+        return p / (p.sum(-1, keepdim=True) + 1e-13)
+    got = att(q.cuda(), feats.cuda(), mask.cuda())
+    assert got.shape == (B, R) and maxdiff(got, ref(mask)) < 1e-5
+    assert float(got[1, 5:].abs().max()) == 0.0
+    assert maxdiff(att(q.cuda(), feats.cuda()), ref(None)) < 1e-5
