@@ -42,6 +42,8 @@ parser.add_argument("--vocab-size", type=int, default=10000, help="vocabulary si
 parser.add_argument("--num-boxes", type=int, default=36)
 parser.add_argument("--eps-source", default="device", choices=["cpu", "device"],
                     help="cpu: the reference's CPU randn stream per step; device: GPU RNG, no host traffic")
+parser.add_argument("--zero-eps", action="store_true", help="testing: eps = 0 (deterministic z = mean)")
+parser.add_argument("--stop-after", type=int, default=0, help="testing: stop after this iteration (NUM_ITERATIONS keeps defining the schedule)")
 parser.add_argument("--fused-optimizer", action="store_true",
                     help="clip + SGD in one HIP pass on the flat buffers instead of torch.optim.SGD")
 
@@ -77,11 +79,11 @@ def main():
     else:
         vocabulary = Vocabulary.from_files(_C.DATA.VOCABULARY)
         if not _A.train_tensors:
-            raise SystemExit("the h5/nltk dataset readers are out of scope: pass --train-tensors file.pt or --synthetic N")
+            raise SystemExit("the h5 / nltk dataset readers are not built (h5py, nltk are not installable here): pass "
+                             "--train-tensors file.pt (ssc_runtime/data.py: dense or ragged region features) or --synthetic N")
         data = TensorFileData(_A.train_tensors)
     if _C.OPTIM.BATCH_SIZE % world:
         raise SystemExit("OPTIM.BATCH_SIZE (global) must be divisible by the number of ranks")
-    loader = cycle(data, _C.OPTIM.BATCH_SIZE // world, device, rank, world, seed=_C.RANDOM_SEED)
 
     model = UpDownCaptioner.from_config(_C, vocabulary=vocabulary, cbs_simple=_C.MODEL.CBS_SIMPLE, device=device).to(device)
     model.eps_source = _A.eps_source
@@ -89,14 +91,27 @@ def main():
     eng = model._engine()
     optimizer = torch.optim.SGD(model.parameters(), lr=_C.OPTIM.LR, momentum=_C.OPTIM.MOMENTUM,
                                 weight_decay=_C.OPTIM.WEIGHT_DECAY)
-    lr_scheduler = torch.optim.lr_scheduler.LambdaLR(optimizer, lr_lambda=lambda it: 1 - it / _C.OPTIM.NUM_ITERATIONS)
+    # Learning rate: the reference's LambdaLR(1 - it / NUM_ITERATIONS) stepped once per iteration (train.py:132-134,176) gives
+    # iteration i the rate LR * (1 - (i - 1) / N).  It is computed from the iteration number on BOTH paths, so a resumed run
+    # continues the decay where it stopped (a fresh LambdaLR would restart at LR).
+    eng.dp_autograd = world > 1 and not _A.fused_optimizer
+    named = list(model.named_parameters())
     start_iteration = 1
     if _A.start_from_checkpoint:
+        # Layout {"model": state_dict, "optimizer": SGD state_dict} as written by the reference's CheckpointManager
+        # (updown-baseline/updown/utils/checkpointing.py:81-112); the iteration rides inside the optimizer entry
+        # (the reference's train.py:143-149 loads every other top-level key into the model).
         ckpt = torch.load(_A.start_from_checkpoint, map_location=device, weights_only=True)
         model.load_state_dict(ckpt["model"])
-        if "optimizer" in ckpt and not _A.fused_optimizer:
-            optimizer.load_state_dict(ckpt["optimizer"])
-        start_iteration = int(ckpt.get("iteration", 0)) + 1  # correct resume (the reference restarts at 1: train.py:149)
+        osd = ckpt.get("optimizer")
+        if osd is not None:
+            if _A.fused_optimizer:
+                eng.load_optimizer_state_dict(named, osd)
+            else:
+                optimizer.load_state_dict({"state": osd["state"], "param_groups": osd["param_groups"]})
+            start_iteration = int(osd.get("iteration", 0)) + 1   # correct resume (the reference restarts at 1: train.py:149)
+    # batch i of a run is a function of (seed, i): a resumed run continues the data order where it stopped
+    loader = cycle(data, _C.OPTIM.BATCH_SIZE // world, device, rank, world, seed=_C.RANDOM_SEED, start_batch=start_iteration - 1)
     log = open(os.path.join(_A.serialization_dir, "scalars.jsonl"), "a") if rank == 0 else None
 
     t0 = time.time()
@@ -105,8 +120,13 @@ def main():
                          or iteration % _C.OPTIM.BEFORE_UPDATE_DECODER_EVERY == 0)   # train.py:156-161
         for p in model._updown_cell._language_lstm_cell_decoder.parameters():
             p.requires_grad = train_decoder
+        if _A.stop_after and iteration > _A.stop_after:
+            break
         batch = next(loader)
         lr = _C.OPTIM.LR * (1 - (iteration - 1) / _C.OPTIM.NUM_ITERATIONS)
+        if _A.zero_eps:
+            Bz, Lz = batch["caption_tokens"].shape
+            model._eps_override = torch.zeros(Lz + 1, Bz, _C.MODEL.Z_SPACE, device=device)
         if _A.fused_optimizer:
             B, L = batch["caption_tokens"].shape
             eps = model._draw_eps(L + 1, B, device)
@@ -121,18 +141,12 @@ def main():
             out = model(batch["image_features"], None, None, batch["caption_tokens"], batch["sentiment"])
             reconstr_loss, kld_loss = out["loss"].mean(), out["kld"].mean()
             loss = reconstr_loss + kld_loss / _C.MODEL.KLD_WEIGHT
-            loss.backward()
-            if world > 1:  # mean over ranks of the local-mean gradients
-                import torch.distributed as dist
-                for p in model.parameters():
-                    if p.grad is not None:
-                        dist.all_reduce(p.grad)
-                        p.grad.div_(world)
+            for group in optimizer.param_groups:
+                group["lr"] = lr
+            loss.backward()   # world > 1: the flat gradient buffer is all-reduced once inside backward (eng.dp_autograd)
             torch.nn.utils.clip_grad_norm_(model.parameters(), _C.OPTIM.CLIP_GRADIENTS)
             optimizer.step()
-            lr_scheduler.step()
-            lr = optimizer.param_groups[0]["lr"]
-        if rank == 0 and (iteration % 100 == 0 or iteration == start_iteration):
+        if rank == 0 and (iteration % 100 == 0 or iteration == start_iteration or _C.OPTIM.NUM_ITERATIONS <= 100):
             rec = {"iteration": iteration, "1reconstr_loss": float(reconstr_loss), "2kld_loss": float(kld_loss),
                    "3loss": float(loss), "4learning_rate": lr, "elapsed_s": time.time() - t0}
             log.write(json.dumps(rec) + "\n")
@@ -140,10 +154,13 @@ def main():
             if iteration % 2000 == 0 or iteration == start_iteration:
                 print("{:6f}    {:6f}    {:6f}".format(rec["3loss"], rec["1reconstr_loss"], rec["2kld_loss"]))
         if rank == 0 and iteration % _A.checkpoint_every == 0:
-            sd = {"model": model.state_dict(), "iteration": iteration}
-            if not _A.fused_optimizer:
-                sd["optimizer"] = optimizer.state_dict()
-            torch.save(sd, os.path.join(_A.serialization_dir, f"checkpoint_{iteration}.pth"))
+            if _A.fused_optimizer:
+                osd = eng.optimizer_state_dict(named, lr, _C.OPTIM.MOMENTUM, _C.OPTIM.WEIGHT_DECAY, iteration)
+            else:
+                osd = optimizer.state_dict()
+                osd["iteration"] = iteration
+            torch.save({"model": model.state_dict(), "optimizer": osd},
+                       os.path.join(_A.serialization_dir, f"checkpoint_{iteration}.pth"))
     if world > 1:
         import torch.distributed as dist
         dist.barrier()

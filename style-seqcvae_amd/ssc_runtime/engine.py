@@ -175,6 +175,10 @@ class TrainEngine:
         self.fwd_version = 0
         self.dp_buckets = 1
         self.dp_overlap = True
+        self.dp_autograd = False      # the autograd path (UpDownCaptioner.forward + loss.backward()) all-reduces the flat
+                                      # gradient buffer inside backward (scripts/train.py without --fused-optimizer)
+        self.dp_profile = False       # record the exposed all-reduce time of every overlapped backward (bench.py --gpus N)
+        self.dp_exposure_events = []  # [(bwd kernels done, gradients reduced)] torch.cuda.Event pairs
 
     def adopt(self, named: "Dict[str, torch.nn.Parameter]"):
         """Re-home nn.Parameters into the flat store (copy once, then `param.data` IS the view).  Cheap when they
@@ -269,9 +273,22 @@ class TrainEngine:
             self.lib.ssc_train_bwd_phases(C.byref(self._cfg), C.byref(p), C.byref(bt), _lib.ptr(ws), ws.numel() * 4,
                                           _lib.ptr(gl), _lib.ptr(gk), C.byref(g), mask, _lib.stream_ptr())
             works.append(dist.all_reduce(self.grads.flat[lo:hi], op=dist.ReduceOp.SUM, group=group, async_op=True))
+        if self.dp_profile:   # exposure = time the compute stream sits between its last backward kernel and the reduced gradients
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         for w in works:
             w.wait()
+        if self.dp_profile:
+            e1.record()
+            self.dp_exposure_events.append((e0, e1))
         return world
+
+    def dp_exposure_ms(self):
+        """Exposed all-reduce time per overlapped backward since the last call (synchronises)."""
+        torch.cuda.synchronize()
+        out = [a.elapsed_time(b) for a, b in self.dp_exposure_events]
+        self.dp_exposure_events = []
+        return out
 
     def backward(self, gl, gk, skip: Sequence[str] = ()):
         """Writes d(sum_b gl_b loss_b + gk_b kld_b)/dparam into self.grads for every parameter not in `skip`
@@ -334,6 +351,47 @@ class TrainEngine:
                               float(lr), float(momentum), float(weight_decay), 0, st)
         self.steps_done += 1
         return sq
+
+    def optimizer_state_dict(self, named_parameters, lr, momentum, weight_decay, iteration) -> dict:
+        """The fused optimiser's state in torch.optim.SGD's state_dict layout (one momentum_buffer per parameter, indexed
+        in `named_parameters` order = model.parameters() order), so that a checkpoint written on either path of
+        scripts/train.py resumes on the other and `optimizer.load_state_dict` of the reference's train.py:142-151 accepts
+        it.  `iteration` rides along inside this entry: the reference loads every OTHER top-level key into the model."""
+        names = [n for n, _ in named_parameters]
+        state = {}
+        if self.momentum is not None:
+            for i, n in enumerate(names):
+                o, cnt = self.params.offsets[n]
+                shp = self.params.shapes[n]
+                if len(shp) == 2 and shp[0] > 1:
+                    buf = self.momentum[o:o + cnt].view(shp[0], _r4(shp[1]))[:, :shp[1]]
+                else:
+                    buf = self.momentum[o:o + shp[-1]].view(*shp)
+                state[i] = {"momentum_buffer": buf.detach().clone().contiguous()}
+        group = {"lr": float(lr), "momentum": float(momentum), "dampening": 0, "weight_decay": float(weight_decay),
+                 "nesterov": False, "maximize": False, "foreach": None, "differentiable": False, "fused": None,
+                 "params": list(range(len(names)))}
+        return {"state": state, "param_groups": [group], "iteration": int(iteration)}
+
+    def load_optimizer_state_dict(self, named_parameters, sd: dict):
+        """Inverse of optimizer_state_dict; also accepts a torch.optim.SGD state_dict (parameters without a buffer - never
+        updated so far - start from zero, torch's lazily created buffer)."""
+        names = [n for n, _ in named_parameters]
+        if self.momentum is None:
+            self.momentum = torch.zeros_like(self.params.flat)
+        self.momentum.zero_()
+        for i, st in sd.get("state", {}).items():
+            buf = st.get("momentum_buffer")
+            if buf is None:
+                continue
+            n = names[int(i)]
+            o, cnt = self.params.offsets[n]
+            shp = self.params.shapes[n]
+            if len(shp) == 2 and shp[0] > 1:
+                dst = self.momentum[o:o + cnt].view(shp[0], _r4(shp[1]))[:, :shp[1]]
+            else:
+                dst = self.momentum[o:o + shp[-1]].view(*shp)
+            dst.copy_(buf.to(self.device, torch.float32).view_as(dst))
 
     # ---- data parallel -----------------------------------------------------------------------------------
     def allreduce_grads(self, group=None):

@@ -42,6 +42,10 @@ class _SeqCVAETrainFn(torch.autograd.Function):
         need = ctx.needs_input_grad[6:]
         skip = [n for n, k in zip(ctx.names, need) if not k]
         eng.backward(gl, gk, skip=skip)
+        if eng.dp_autograd:   # data parallel on the autograd path: ONE sum all-reduce of the flat gradient buffer, then the mean
+            world = eng.allreduce_grads()
+            if world > 1:
+                eng.grads.flat.mul_(1.0 / world)
         frozen = set(eng.frozen_names)
         grads = tuple(eng.grads.views[n].clone() if (k and n not in frozen) else None for n, k in zip(ctx.names, need))
         return (None,) * 6 + grads

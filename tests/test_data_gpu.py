@@ -1,0 +1,72 @@
+"""GPU: the prefetching batch producer (ssc_runtime/data.py PrefetchLoader): device batches equal a direct gather (dense and
+ragged / zero-padded features), the stream hand-off is ordered, resuming at batch k replays the stream, and the sustained
+upload rate covers what a 6-7 k captions/s consumer needs (18.9 MB per 64 captions -> ~2 GB/s; SURVEY 8(f)-2 asks 3 GB/s)."""
+import time
+
+import pytest
+import torch
+
+from ssc_runtime import data as D
+
+pytestmark = pytest.mark.gpu
+
+
+def test_prefetch_loader_dense_matches_direct_gather_and_resumes():
+    data = D.SyntheticCaptionData(40, 5, 16, 7, 50, seed=3)
+    ld = D.cycle(data, 4, "cuda", rank=1, world=2, seed=9)
+    got = [None] * 12
+    for k in range(12):
+        b = next(ld)          # (a batch lives in the loader's device ring: valid until depth - 1 further batches are requested)
+        idx = D.batch_indices(40, 8, 9, k)[4:8]            # rank 1 of 2
+        assert torch.equal(b["image_features"].cpu(), data.feats[idx])
+        assert torch.equal(b["caption_tokens"].cpu(), data.caps[idx]) and b["caption_tokens"].dtype == torch.int64
+        assert torch.equal(b["sentiment"].cpu(), data.senti[idx]) and b["sentiment"].shape == (4, 1)
+        assert torch.equal(b["image_id"].cpu(), data.image_id[idx])
+        got[k] = {kk: v.clone() for kk, v in b.items()}
+    ld.close()
+    ld2 = D.cycle(data, 4, "cuda", rank=1, world=2, seed=9, start_batch=7)   # resume: continues at batch 7
+    for k in range(7, 10):
+        b = next(ld2)
+        assert torch.equal(b["image_features"], got[k]["image_features"]) and torch.equal(b["caption_tokens"], got[k]["caption_tokens"])
+    ld2.close()
+
+
+def test_prefetch_loader_ragged_zero_pads_each_batch(tmp_path):
+    g = torch.Generator().manual_seed(2)
+    nb = torch.randint(2, 9, (30,), generator=g)
+    flat = torch.randn(int(nb.sum()), 12, generator=g)
+    torch.save({"features": flat, "num_boxes": nb, "caption_tokens": torch.randint(0, 20, (30, 5), generator=g),
+                "sentiment": torch.zeros(30, 1)}, tmp_path / "r.pt")
+    data = D.TensorFileData(str(tmp_path / "r.pt"))
+    off = torch.cat([torch.zeros(1, dtype=torch.long), nb.cumsum(0)])
+    ld = D.cycle(data, 6, "cuda", seed=1)
+    for k in range(8):
+        b = next(ld)
+        idx = D.batch_indices(30, 6, 1, k)
+        R = int(nb[idx].max())
+        f = b["image_features"].cpu()
+        assert f.shape == (6, R, 12) and b["image_features"].is_contiguous()
+        for i, r in enumerate(idx.tolist()):
+            n = int(nb[r])
+            assert torch.equal(f[i, :n], flat[off[r]:off[r] + n]) and not f[i, n:].any()
+    ld.close()
+
+
+def test_prefetch_loader_sustained_rate_and_overlap():
+    """C2-shaped batches (64 x 36 x 2048 f32 = 18.9 MB): the loader alone must sustain well over 3 GB/s, and consuming a batch
+    with GPU work in between must not serialise with the upload."""
+    data = D.SyntheticCaptionData(1024, 36, 2048, 20, 10000, seed=5)
+    ld = D.cycle(data, 64, "cuda", seed=0)
+    for _ in range(3):
+        next(ld)
+    torch.cuda.synchronize()
+    n = 30
+    t0 = time.perf_counter()
+    for _ in range(n):
+        b = next(ld)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    gbs = n * b["image_features"].numel() * 4 / dt / 1e9
+    print(f"PrefetchLoader: {gbs:.1f} GB/s sustained ({dt / n * 1e3:.2f} ms per 64-caption batch)")
+    assert gbs > 3.0, gbs
+    ld.close()
