@@ -283,6 +283,51 @@ def decode_fixture(UpDownCaptioner, name, dims, sv, B=2, R=5, beam=5):
     print(name, "lp0[0,:3]", lp0[0, :3].numpy())
 
 
+def full_size_inputs(seed, B, R=36, F=2048, L=20, V=10000, Z=128, unk=False):
+    """Inputs of the full-size fixtures, regenerated from the seed on both sides (make_golden.py here, tests/test_train_gpu.py
+    on the GPU box): BASELINE.md 4 distributions; `unk` plants @@UNKNOWN@@ (id 0) inside some captions."""
+    g = torch.Generator().manual_seed(seed)
+    feats = torch.randn(B, R, F, generator=g)
+    lens = torch.randint(8, L + 1, (B,), generator=g)
+    ids = torch.randint(2, V, (B, L), generator=g)
+    caps = torch.where(torch.arange(L).unsqueeze(0) < lens.unsqueeze(1), ids, torch.zeros_like(ids))
+    if unk:
+        for b in range(0, B, 3):
+            caps[b, int(lens[b]) // 2] = 0
+    senti = torch.randint(-1, 2, (B, 1), generator=g).float()
+    eps = torch.randn(L + 1, B, Z, generator=g)
+    return feats, caps, senti, eps
+
+
+def full_size_fixture(UpDownCaptioner, name, B, unk):
+    """BASELINE configs[0] / configs[1] at FULL size (V=10000, E=1000, H=1200, A=768, F=2048, Z=128, L=20, SENTIMENT_VAE=1):
+    parameters = the reference's default init under manual_seed(2) (the mirror's init is bit-identical, so they are NOT
+    stored - only per-tensor checksums that prove it), inputs regenerated from the seed; stored: loss, kld and per-gradient
+    {norm, sum, the first 32 and 32 strided entries}.  < 100 KB."""
+    dims = (10000, 1000, 1200, 768, 2048, 128, 20)
+    V, E, H, A, F, Z, L = dims
+    model = build_reference_model(UpDownCaptioner, dims, sv=1, multip=0.5, seed=2)
+    model.train()
+    feats, caps, senti, eps = full_size_inputs(4242 + B, B, unk=unk)
+    with EpsInjector([eps[t] for t in range(L + 1)]):
+        out = model(feats.clone(), None, None, caps, senti)
+    (out["loss"].mean() + out["kld"].mean() / 750.0).backward()
+    data = {"out/loss": out["loss"].detach().numpy(), "out/kld": out["kld"].detach().numpy(), "B": np.array(B),
+            "unk": np.array(int(unk)), "seed": np.array(4242 + B)}
+    for n, p in model.named_parameters():
+        w = p.detach().double()
+        data["psum/" + n] = np.array([float(w.sum()), float(w.abs().sum())])
+        if p.grad is None:
+            continue
+        gflat = p.grad.detach().reshape(-1)
+        stride = max(1, gflat.numel() // 32)
+        data["gnorm/" + n] = np.array([float(gflat.double().norm()), float(gflat.double().sum()), float(gflat.abs().max())])
+        data["ghead/" + n] = gflat[:32].numpy().copy()
+        data["gstride/" + n] = gflat[::stride][:32].numpy().copy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **data)
+    print(name, "loss[:3]", out["loss"][:3].detach().numpy(), "kld[:3]", out["kld"][:3].detach().numpy())
+
+
 FSM_WORDFORMS = "dog\tdog,dogs\ncat\tcat,cats,kitten\nfire\tfire\nhydrant\thydrant,hydrants\nsalt\tsalt\n" \
                 "and\tand\npepper\tpepper,peppers\nred\tred,reddish\nbird\tbird,birds,zzz_not_in_vocab\n"
 FSM_CASES = [[], ["dog"], ["dog", "cat"], ["fire hydrant"], ["dog", "fire hydrant", "salt and pepper"],
@@ -362,6 +407,9 @@ def fsm_fixture(name="g9_fsm"):
 def main():
     UpDownCaptioner = import_reference()
     fsm_fixture()
+    if "--full" in sys.argv or not os.path.exists(os.path.join(HERE, "g10_full_c2.npz")):
+        full_size_fixture(UpDownCaptioner, "g10_full_c1", B=4, unk=False)      # BASELINE configs[0]: batch 4
+        full_size_fixture(UpDownCaptioner, "g10_full_c2", B=64, unk=True)      # BASELINE configs[1]: batch 64, with in-caption UNK
     #        V    E   H   A   F   Z   L
     toy = (300, 40, 48, 32, 64, 16, 6)
     train_fixture(UpDownCaptioner, "g1_train_sv1", toy, sv=1)

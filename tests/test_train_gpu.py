@@ -217,3 +217,128 @@ def test_full_size_c2_batch_permutation_and_padding_invariance():
             assert maxdiff(g1[k], g3[k]) <= 1e-6 * max(g1[k].abs().max().item(), 1e-6), k
         else:
             assert torch.equal(g1[k], g3[k]), k
+
+
+# ---- full-size parity pinned to the REFERENCE (fixtures g10: outputs only; parameters and inputs are regenerated from seeds) ------
+def _full_size_inputs(seed, B, R=36, F=2048, L=20, V=10000, Z=128, unk=False):
+    """Same generator as tests/golden/make_golden.py::full_size_inputs."""
+    g = torch.Generator().manual_seed(seed)
+    feats = torch.randn(B, R, F, generator=g)
+    lens = torch.randint(8, L + 1, (B,), generator=g)
+    ids = torch.randint(2, V, (B, L), generator=g)
+    caps = torch.where(torch.arange(L).unsqueeze(0) < lens.unsqueeze(1), ids, torch.zeros_like(ids))
+    if unk:
+        for b in range(0, B, 3):
+            caps[b, int(lens[b]) // 2] = 0
+    senti = torch.randint(-1, 2, (B, 1), generator=g).float()
+    eps = torch.randn(L + 1, B, Z, generator=g)
+    return feats, caps, senti, eps
+
+
+def _full_size_model():
+    from ssc_runtime.vocab import Vocabulary
+    from var_updown.models import UpDownCaptioner
+    V, F, E, H, A, Z, L = 10000, 2048, 1000, 1200, 768, 128, 20
+    torch.manual_seed(2)
+    return UpDownCaptioner(Vocabulary.synthetic(V), image_feature_size=F, embedding_size=E, hidden_size=H,
+                           attention_projection_size=A, max_caption_length=L, beam_size=5, z_space=Z, prior_std=1.0,
+                           simple_vae=False, latent_embedding="glove", sentiment_vae=1, senti_prior_multip=0.5,
+                           device=torch.device("cuda")).to("cuda")
+
+
+@pytest.mark.parametrize("name", ["g10_full_c1", "g10_full_c2"])
+def test_full_size_matches_reference_fixture(name):
+    """BASELINE configs[0] (B=4) and configs[1] (B=64, with in-caption @@UNKNOWN@@) at FULL size against the reference's own
+    forward / backward (fixture written by tests/golden/make_golden.py from the imported reference): the mirror's seeded
+    init equals the reference's (per-tensor checksums), loss and kld per caption, and every gradient through its norm, sum
+    and 64 sampled entries.  Tolerances: loss / kld 1e-5 relative + 1e-4; gradients 1e-4 of the tensor's largest entry."""
+    import numpy as np
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+    B = int(z["B"])
+    m = _full_size_model()
+    sd = {k: v.detach().double().cpu() for k, v in m.state_dict().items()}
+    for k in [f for f in z.files if f.startswith("psum/")]:
+        w = sd[k[5:]]
+        assert abs(float(w.sum()) - z[k][0]) <= 1e-9 * max(1.0, abs(z[k][0])) and abs(float(w.abs().sum()) - z[k][1]) <= 1e-9 * z[k][1], k
+    eng = m._engine()
+    feats, caps, senti, eps = _full_size_inputs(int(z["seed"]), B, unk=bool(int(z["unk"])))
+    loss, kld = eng.forward(feats.cuda(), caps.cuda(), senti.cuda(), eps.cuda())
+    for got, want in ((loss, z["out/loss"]), (kld, z["out/kld"])):
+        want = torch.from_numpy(want)
+        assert ((got.cpu() - want).abs() <= 1e-5 * want.abs() + 1e-4).all(), (got.cpu() - want).abs().max()
+    eng.backward(torch.full((B,), 1.0 / B, device="cuda"), torch.full((B,), 1.0 / (B * 750.0), device="cuda"))
+    grads = eng.grad_dict()
+    checked = 0
+    for k in [f for f in z.files if f.startswith("gnorm/")]:
+        n = k[6:]
+        g = grads[n].reshape(-1).double().cpu()
+        norm, gsum, gmax = z[k]
+        tol = 1e-4 * gmax + 1e-9
+        stride = max(1, g.numel() // 32)
+        assert (g[:32] - torch.from_numpy(z["ghead/" + n]).double()).abs().max() <= tol, n
+        assert (g[::stride][:32] - torch.from_numpy(z["gstride/" + n]).double()).abs().max() <= tol, n
+        assert abs(float(g.norm()) - norm) <= 1e-4 * norm + 1e-9, (n, float(g.norm()), norm)
+        checked += 1
+    assert checked == len(grads)
+
+
+def test_full_size_c2_matches_oracle_every_gradient():
+    """C2 at full size, captions with in-caption @@UNKNOWN@@: ONE oracle train step on this box's host cores (a few seconds)
+    against the default HIP path: loss, kld and EVERY gradient entry, 1e-4 of the tensor's scale."""
+    m = _full_size_model()
+    eng = m._engine()
+    B = 64
+    feats, caps, senti, eps = _full_size_inputs(777, B, unk=True)
+    cfg = oracle.OracleConfig(vocab_size=10000, image_feature_size=2048, embedding_size=1000, hidden_size=1200,
+                              attention_projection_size=768, z_space=128, max_caption_length=20, sentiment_vae=1,
+                              senti_prior_multip=0.5)
+    prev = torch.get_num_threads()
+    torch.set_num_threads(min(16, prev))       # the default (every core of the box) is oversubscribed for this step
+    try:
+        p = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+        out = oracle.train_forward(p, cfg, feats, caps, senti, eps)
+        oracle.train_objective(out, cfg).backward()
+    finally:
+        torch.set_num_threads(prev)
+    loss, kld = eng.forward(feats.cuda(), caps.cuda(), senti.cuda(), eps.cuda())
+    assert ((loss.cpu() - out["loss"]).abs() <= 1e-5 * out["loss"].abs() + 1e-4).all()
+    assert ((kld.cpu() - out["kld"]).abs() <= 1e-5 * out["kld"].abs() + 1e-4).all()
+    eng.backward(torch.full((B,), 1.0 / B, device="cuda"), torch.full((B,), 1.0 / (B * cfg.kld_weight), device="cuda"))
+    got = eng.grad_dict()
+    for k, v in p.items():
+        scale = max(v.grad.abs().max().item(), 1e-6)
+        assert maxdiff(got[k], v.grad) <= 1e-4 * scale + 1e-7, (k, maxdiff(got[k], v.grad), scale)
+
+
+def test_full_size_c5_properties():
+    """BASELINE configs[4] (stress) at FULL width on one GPU: B=128, R=100 regions, L=40 (T=41), V=30000, E/H/A=1000/1200/768.
+    No CPU run at this size: the default path against the exact-fp32-MFMA mode (independent GEMM kernels, every row
+    computed), bit-identical reruns, and invariance to what lies behind the padding."""
+    from ssc_runtime import lib as L
+    from ssc_runtime.vocab import Vocabulary
+    from var_updown.models import UpDownCaptioner
+    V, F, E, H, A, Z, Lc, B, R = 30000, 2048, 1000, 1200, 768, 128, 40, 128, 100
+    torch.manual_seed(2)
+    m = UpDownCaptioner(Vocabulary.synthetic(V), image_feature_size=F, embedding_size=E, hidden_size=H,
+                        attention_projection_size=A, max_caption_length=Lc, beam_size=5, z_space=Z, prior_std=1.0,
+                        simple_vae=False, latent_embedding="glove", sentiment_vae=1, senti_prior_multip=0.5,
+                        device=torch.device("cuda")).to("cuda")
+    eng = m._engine()
+    feats, caps, senti, eps = _full_size_inputs(99, B, R=R, L=Lc, V=V, unk=True)
+    feats[5, 70:] = 0                      # one image with 70 regions (zero-padded: adaptive features)
+    batch = (feats.cuda(), caps.cuda(), senti.cuda(), eps.cuda())
+    l1, k1, g1 = _step(eng, batch)
+    l2, k2, g2 = _step(eng, batch)
+    assert torch.equal(l1, l2) and torch.equal(k1, k2)
+    lib = L.load()
+    lib.ssc_set_gemm_mode(0)
+    try:
+        l0, k0, g0 = _step(eng, batch)
+    finally:
+        lib.ssc_set_gemm_mode(1)
+    assert ((l1 - l0).abs() <= 2e-5 * l0.abs() + 1e-3).all() and ((k1 - k0).abs() <= 2e-5 * k0.abs() + 1e-3).all()
+    for k in g1:
+        scale = max(g0[k].abs().max().item(), 1e-6)
+        assert maxdiff(g1[k], g0[k]) <= 2e-4 * scale + 1e-7, (k, maxdiff(g1[k], g0[k]), scale)
+    assert float(eng.workspace_view(6)[:, 5, 70:].abs().max()) == 0.0      # no attention weight on the padded regions
