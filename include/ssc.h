@@ -163,6 +163,11 @@ int ssc_attn_fwd(const float* q, int ldq, const float* pv, const float* wa, cons
                  int G, int R, int A, int F, int rows_per_image, float* logits, float* alpha, float* att, int ldatt,
                  void* stream);
 
+/* out (G,D) = sum_r alpha[g,r] x[img(g),r,:]: attention pooling of a per-region tensor x (nimg,R,D) with the step's weights -
+ * the grounded style prior of SENTIMENT_VAE = 2 (updown_cell.py:160-163: per-region attribute means obj_atts, D = 150). */
+int ssc_attn_pool(const float* alpha, const float* x, int G, int R, int D, int rows_per_image, float* out, int ldo,
+                  void* stream);
+
 /* Attention backward: datt (G,F) -> dq (G,A), dpv_acc (G,R,A) += dpre,
  * dwa_acc (G,A) += sum_r dl_r u_r (caller sums over G at the end).  Training only (rows_per_image=1). */
 int ssc_attn_bwd(const float* datt, int lddatt, const float* q, int ldq, const float* pv, const float* wa,

@@ -147,6 +147,18 @@ __global__ __launch_bounds__(64) void attn_apply_kernel(const float* __restrict_
   }
 }
 
+// out[g, d] = sum_r alpha[g, r] x[img(g), r, d]: the attention-pooled per-region attribute means that SENTIMENT_VAE = 2 uses as
+// prior mean and LSTM conditioning (var_updown/var_updown/modules/updown_cell.py:160-163).  D is small (150): thread per (g, d).
+__global__ void attn_pool_kernel(const float* __restrict__ alpha, const float* __restrict__ x, int G, int R, int D,
+                                 int rows_per_image, float* __restrict__ out, int ldo) {
+  const int g = blockIdx.y, d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= D) return;
+  const float* xp = x + (size_t)(g / rows_per_image) * R * D + d;
+  float acc = 0.f;
+  for (int r = 0; r < R; ++r) acc += alpha[(size_t)g * R + r] * xp[(size_t)r * D];
+  out[(size_t)g * ldo + d] = acc;
+}
+
 // ---- backward ---------------------------------------------------------------------------------
 // dalpha[g,r] = datt[g,:] . feats[g,r,:]
 __global__ __launch_bounds__(256) void attn_dalpha_kernel(const float* __restrict__ datt, int lddatt,
@@ -285,6 +297,15 @@ extern "C" int ssc_attn_fwd(const float* q, int ldq, const float* pv, const floa
   SSC_TRY(ssc_attn_logits(q, ldq, pv, wa, G, R, A, rows_per_image, logits, stream));
   SSC_LAUNCH(attn_apply_kernel, dim3(ssc_cdiv(F, 256), G), dim3(64), 0, (hipStream_t)stream, logits, mask, feats,
                      G, R, F, rows_per_image, alpha, att, ldatt);
+  SSC_CHECK_LAUNCH();
+  return SSC_OK;
+}
+
+extern "C" int ssc_attn_pool(const float* alpha, const float* x, int G, int R, int D, int rows_per_image, float* out, int ldo,
+                             void* stream) {
+  if (!alpha || !x || !out || G <= 0 || R <= 0 || D <= 0 || rows_per_image <= 0 || ldo < D) return SSC_EINVAL;
+  SSC_LAUNCH(attn_pool_kernel, dim3(ssc_cdiv(D, 128), G), dim3(128), 0, (hipStream_t)stream, alpha, x, G, R, D, rows_per_image,
+             out, ldo);
   SSC_CHECK_LAUNCH();
   return SSC_OK;
 }

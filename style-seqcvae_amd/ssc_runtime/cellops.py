@@ -41,8 +41,15 @@ def _lstm(lib, pre, b_ih, b_hh, c_prev, sent=None, wcol=None, ldw=1):
 
 
 def cell_train_step(dims: ModelDims, P: Dict[str, torch.Tensor], feats: torch.Tensor, emb: torch.Tensor,
-                    states: Optional[Dict[str, torch.Tensor]], sentiment: Optional[torch.Tensor], eps: torch.Tensor):
-    """-> (h_decoder, states, mean, log_var, alpha).  feats (G,R,F), emb (G,E), sentiment (G,) or None, eps (G,Z)."""
+                    states: Optional[Dict[str, torch.Tensor]], sentiment: Optional[torch.Tensor], eps: torch.Tensor,
+                    obj_atts: Optional[torch.Tensor] = None, training: bool = True, prior_mean: Optional[torch.Tensor] = None,
+                    prior_var: Optional[torch.Tensor] = None):
+    """One UpDownCell step through the op-level C ABI -> (h_decoder, states, mean, log_var, alpha, cond) with cond = the
+    attention-pooled attribute means (G,S) when S > 1, else None.
+    feats (G,R,F), emb (G,E), sentiment (G,) or None, eps (G,Z).
+    dims.S selects the conditioning of the language LSTMs (updown_cell.py:47-81): 0 none, 1 the sentiment column,
+    > 1 (SENTIMENT_VAE = 2: 150) the attention-pooled attribute means c = sum_r alpha_r obj_atts_r (updown_cell.py:160-163),
+    which then is also the prior mean.  training=False: no encoder LSTM, z = eps sqrt(prior_var) + prior_mean (:200-208)."""
     lib = L.load()
     dev = feats.device
     G, R, F = feats.shape
@@ -72,37 +79,62 @@ def cell_train_step(dims: ModelDims, P: Dict[str, torch.Tensor], feats: torch.Te
     logits, alpha, att = torch.empty(G, R, **f32), torch.empty(G, R, **f32), torch.empty(G, F, **f32)
     lib.ssc_attn_fwd(L.ptr(q), A, L.ptr(pv), L.ptr(wa), L.ptr(mask), L.ptr(feats), G, R, A, F, 1, L.ptr(logits), L.ptr(alpha),
                      L.ptr(att), F, L.stream_ptr())
-    sent = sentiment.reshape(G).contiguous().float() if (sentiment is not None and (S or dims.pm_scale != 0.0)) else None
+    sent = sentiment.reshape(G).contiguous().float() if (sentiment is not None and (S == 1 or dims.pm_scale != 0.0)) else None
     hd_prev = st["h_decoder"]
+    cond = None      # (G, S) conditioning block of the language LSTMs when S > 1
+    if S > 1:
+        if obj_atts is None:
+            raise ValueError("SENTIMENT_VAE = 2 needs obj_atts (G, R, %d): per-region attribute means" % S)
+        oa = obj_atts.to(dev, torch.float32).contiguous()
+        cond = torch.empty(G, S, **f32)
+        lib.ssc_attn_pool(L.ptr(alpha), L.ptr(oa), G, R, S, 1, L.ptr(cond), S, L.stream_ptr())
+    csegs_e = csegs_d = []
     w_e, w_ehh = P[P_ENC + "weight_ih"], P[P_ENC + "weight_hh"]
     lde, be = w_e.stride(0), w_e.data_ptr()
-    _gemm(lib, [(att.data_ptr(), F, be, lde, F), (h1.data_ptr(), H, be + 4 * F, lde, H),
-                (hd_prev.data_ptr(), H, be + 4 * (F + H), lde, H),
-                (st["h_encoder"].data_ptr(), H, w_ehh.data_ptr(), w_ehh.stride(0), H)], G, 4 * H, pre, ws=ws)
-    he, ce = _lstm(lib, pre, P[P_ENC + "bias_ih"], P[P_ENC + "bias_hh"], st["c_encoder"], sent if S else None,
-                   be + 4 * (F + 2 * H), lde)
-    mulv = torch.empty(G, 2 * Z, **f32)
-    wm, wl = P[P_CELL + "fc_mean.weight"], P[P_CELL + "fc_log_var.weight"]
-    _gemm(lib, [(he.data_ptr(), H, wm.data_ptr(), wm.stride(0), H)], G, Z, mulv[:, :Z], ws=ws)
-    _gemm(lib, [(he.data_ptr(), H, wl.data_ptr(), wl.stride(0), H)], G, Z, mulv[:, Z:], ws=ws)
-    mu, lv, z = torch.empty(G, Z, **f32), torch.empty(G, Z, **f32), torch.empty(G, Z, **f32)
-    kld = torch.zeros(G, **f32)
-    ones = torch.ones(G, **f32)
+    if cond is not None:
+        csegs_e = [(cond.data_ptr(), S, be + 4 * (F + 2 * H), lde, S)]
     eps = eps.to(dev, torch.float32).contiguous()
-    d = L.LatentFwdDesc()
-    d.B, d.Z, d.mulv, d.ldmulv, d.nslab, d.slab_stride = G, Z, mulv.data_ptr(), 2 * Z, 1, 0
-    d.bmu, d.blv = P[P_CELL + "fc_mean.bias"].data_ptr(), P[P_CELL + "fc_log_var.bias"].data_ptr()
-    d.eps, d.ldeps, d.kld_mode = eps.data_ptr(), Z, dims.kld_mode
-    d.sent = sent.data_ptr() if (sent is not None and dims.pm_scale != 0.0) else None
-    d.pm_scale, d.prior_var, d.w = dims.pm_scale, dims.prior_var, ones.data_ptr()
-    d.mu, d.lv, d.z, d.ldz, d.kld_acc = mu.data_ptr(), lv.data_ptr(), z.data_ptr(), Z, kld.data_ptr()
-    lib.ssc_latent_fwd(C.byref(d), L.stream_ptr())
+    if not training:
+        # eval (updown_cell.py:200-208): the encoder LSTM is skipped, mean / var are the prior's.  A per-row VECTOR prior mean
+        # (SENTIMENT_VAE = 2, or one handed in) is applied with two elementwise torch ops - this stand-alone step is the
+        # module-level API, not the hot path (the fused decode step handles the scalar priors of modes 0 / 1).
+        pm = cond if cond is not None else (prior_mean.to(dev, torch.float32) if prior_mean is not None
+                                            else torch.zeros(G, Z, **f32))
+        pv = prior_var.to(dev, torch.float32) if prior_var is not None else torch.full((G, Z), float(dims.prior_var), **f32)
+        mu, lv = pm, pv.log()
+        z = (eps * pv.sqrt() + pm).contiguous()
+        he, ce = st["h_encoder"], st["c_encoder"]
+    else:
+        _gemm(lib, [(att.data_ptr(), F, be, lde, F), (h1.data_ptr(), H, be + 4 * F, lde, H),
+                    (hd_prev.data_ptr(), H, be + 4 * (F + H), lde, H)] + csegs_e +
+              [(st["h_encoder"].data_ptr(), H, w_ehh.data_ptr(), w_ehh.stride(0), H)], G, 4 * H, pre, ws=ws)
+        he, ce = _lstm(lib, pre, P[P_ENC + "bias_ih"], P[P_ENC + "bias_hh"], st["c_encoder"], sent if S == 1 else None,
+                       be + 4 * (F + 2 * H), lde)
+    mulv = torch.empty(G, 2 * Z, **f32)
+    if training:
+        wm, wl = P[P_CELL + "fc_mean.weight"], P[P_CELL + "fc_log_var.weight"]
+        _gemm(lib, [(he.data_ptr(), H, wm.data_ptr(), wm.stride(0), H)], G, Z, mulv[:, :Z], ws=ws)
+        _gemm(lib, [(he.data_ptr(), H, wl.data_ptr(), wl.stride(0), H)], G, Z, mulv[:, Z:], ws=ws)
+        mu, lv, z = torch.empty(G, Z, **f32), torch.empty(G, Z, **f32), torch.empty(G, Z, **f32)
+        kld = torch.zeros(G, **f32)
+        ones = torch.ones(G, **f32)
+        d = L.LatentFwdDesc()
+        d.B, d.Z, d.mulv, d.ldmulv, d.nslab, d.slab_stride = G, Z, mulv.data_ptr(), 2 * Z, 1, 0
+        d.bmu, d.blv = P[P_CELL + "fc_mean.bias"].data_ptr(), P[P_CELL + "fc_log_var.bias"].data_ptr()
+        d.eps, d.ldeps, d.kld_mode = eps.data_ptr(), Z, dims.kld_mode
+        d.sent = sent.data_ptr() if (sent is not None and dims.pm_scale != 0.0) else None
+        d.pm_scale, d.prior_var, d.w = dims.pm_scale, dims.prior_var, ones.data_ptr()
+        d.mu, d.lv, d.z, d.ldz, d.kld_acc = mu.data_ptr(), lv.data_ptr(), z.data_ptr(), Z, kld.data_ptr()
+        lib.ssc_latent_fwd(C.byref(d), L.stream_ptr())   # (the KL term it also accumulates belongs to the captioner; unused here)
     w_d, w_dhh = P[P_DEC + "weight_ih"], P[P_DEC + "weight_hh"]
     ldd, bd = w_d.stride(0), w_d.data_ptr()
+    if cond is not None:
+        csegs_d = [(cond.data_ptr(), S, bd + 4 * (F + 2 * H), ldd, S)]
     _gemm(lib, [(att.data_ptr(), F, bd, ldd, F), (h1.data_ptr(), H, bd + 4 * F, ldd, H),
-                (hd_prev.data_ptr(), H, bd + 4 * (F + H), ldd, H), (z.data_ptr(), Z, bd + 4 * (F + 2 * H + S), ldd, Z),
-                (hd_prev.data_ptr(), H, w_dhh.data_ptr(), w_dhh.stride(0), H)], G, 4 * H, pre, ws=ws)
-    hd, cd = _lstm(lib, pre, P[P_DEC + "bias_ih"], P[P_DEC + "bias_hh"], st["c_decoder"], sent if S else None,
+                (hd_prev.data_ptr(), H, bd + 4 * (F + H), ldd, H)] + csegs_d +
+          [(z.data_ptr(), Z, bd + 4 * (F + 2 * H + S), ldd, Z),
+           (hd_prev.data_ptr(), H, w_dhh.data_ptr(), w_dhh.stride(0), H)], G, 4 * H, pre, ws=ws)
+    hd, cd = _lstm(lib, pre, P[P_DEC + "bias_ih"], P[P_DEC + "bias_hh"], st["c_decoder"], sent if S == 1 else None,
                    bd + 4 * (F + 2 * H), ldd)
     new = {"h1": h1, "c1": c1, "h_encoder": he, "c_encoder": ce, "h_decoder": hd, "c_decoder": cd}
-    return hd, new, mu, lv, alpha
+    return hd, new, mu, lv, alpha, cond

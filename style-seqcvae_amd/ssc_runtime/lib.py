@@ -116,6 +116,7 @@ SYMBOLS = {
     "ssc_lstm_bwd": (_i, [C.POINTER(LstmBwdDesc), vp]),
     "ssc_attn_logits": (_i, [vp, _i, vp, vp, _i, _i, _i, _i, vp, vp]),
     "ssc_attn_fwd": (_i, [vp, _i, vp, vp, vp, vp, _i, _i, _i, _i, _i, vp, vp, vp, _i, vp]),
+    "ssc_attn_pool": (_i, [vp, vp, _i, _i, _i, _i, vp, _i, vp]),
     "ssc_attn_bwd": (_i, [vp, _i, vp, _i, vp, vp, vp, vp, _i, _i, _i, _i, vp, _i, vp, vp, vp, vp]),
     "ssc_latent_fwd": (_i, [C.POINTER(LatentFwdDesc), vp]),
     "ssc_latent_prior_sample": (_i, [vp, _i, vp, _f, _f, _i, _i, vp, _i, vp]),

@@ -250,8 +250,8 @@ class UpDownCaptioner(nn.Module):
             emb = self._embedding_layer.weight.detach()[previous_predictions.to(eng.device)]
             eps = self._eps_override.pop(0) if self._eps_override is not None else (
                 torch.randn(G, self.z_space, device=eng.device) if self.eps_source == "device" else torch.randn(G, self.z_space))
-            h_dec, states, mean, log_var, alpha = cell_train_step(eng.dims, eng.params.views, image_features.to(eng.device),
-                                                                  emb, states, sentiment, eps)
+            h_dec, states, mean, log_var, alpha, _ = cell_train_step(eng.dims, eng.params.views, image_features.to(eng.device),
+                                                                     emb, states, sentiment, eps)
             d = eng.dims
             logits = torch.empty(G, d.V, device=eng.device)
             lib = _lib.load()
@@ -291,9 +291,9 @@ class UpDownCaptioner(nn.Module):
             G = token_embedding.size(0)
             if eps is None:
                 eps = torch.randn(G, self.z_space)
-            h_dec, new_states, mean, log_var, alpha = cell_train_step(eng.dims, eng.params.views,
-                                                                      image_features.to(eng.device), token_embedding.to(eng.device),
-                                                                      states, sentiment, eps)
+            h_dec, new_states, mean, log_var, alpha, _ = cell_train_step(eng.dims, eng.params.views,
+                                                                         image_features.to(eng.device),
+                                                                         token_embedding.to(eng.device), states, sentiment, eps)
             d = eng.dims
             pm = prior_mean if prior_mean is not None else torch.zeros(G, self.z_space, device=eng.device)
             if self.simple_vae:

@@ -52,7 +52,43 @@ class UpDownCell(nn.Module):
         (updown_cell.py:231).  Runs the HIP decode step without autograd; the differentiable training path is the
         fused sequence kernel behind UpDownCaptioner.forward.  `eps` (G,Z) may be injected; default: CPU
         torch.randn as in updown_cell.py:206."""
-        if self._host is None:
-            raise RuntimeError("UpDownCell.forward needs its UpDownCaptioner host (engine over the parameter store)")
-        return self._host._cell_forward(image_features, token_embedding, states, training, sentiment, prior_mean,
+        if self._host is not None and self.senti_cols <= 1:
+            return self._host._cell_forward(image_features, token_embedding, states, training, sentiment, prior_mean,
+                                            prior_var, eps)
+        return self._standalone_forward(image_features, obj_atts, token_embedding, states, training, sentiment, prior_mean,
                                         prior_var, eps)
+
+    def _standalone_forward(self, image_features, obj_atts, token_embedding, states, training, sentiment, prior_mean,
+                            prior_var, eps):
+        """The cell on its own parameters through the op-level C ABI (ssc_runtime/cellops.py): what a bare `UpDownCell`
+        (no captioner around it) runs, and the only path of SENTIMENT_VAE = 2 - whose captioner wiring cannot be constructed
+        in the reference either (it reads /path/to/sentiglove10.pkl, updown_captioner.py:79) while the cell is complete:
+        c = sum_r alpha_r obj_atts_r conditions both language LSTMs and is the prior mean (updown_cell.py:160-163,185-188,
+        219-222)."""
+        from ssc_runtime.cellops import cell_train_step
+        from ssc_runtime.engine import ModelDims
+        w = self._attention_lstm_cell.weight_ih
+        if not w.is_cuda:
+            raise RuntimeError("UpDownCell.forward runs on the HIP path only (no CPU fallback): move the module to a ROCm device")
+        dev = w.device
+        P = {"_updown_cell." + n: p.detach() for n, p in self.named_parameters()}
+        G = token_embedding.size(0)
+        Z = self.z_space
+        dims = ModelDims(V=2, E=self.embedding_size, H=self.hidden_size, A=self.attention_projection_size,
+                         F=self.image_feature_size, Z=Z, S=self.senti_cols)
+        if eps is None:
+            eps = torch.randn(G, Z)          # CPU generator, as updown_cell.py:206
+        if self.latent_embedding not in ("glove", "senti_word_net"):
+            raise NotImplementedError()
+        sent = sentiment.reshape(G) if (sentiment is not None and self.senti_cols == 1) else None
+        if self.senti_cols == 1 and self.latent_embedding == "senti_word_net" and self.sentiment_vae != 1:
+            sent = prior_mean[:, 0]          # c = prior_mean[:, 0] (updown_cell.py:171-172); the cat uses `sentiment` only for mode 1
+        pm_in = None if prior_mean is None else (torch.zeros_like(prior_mean) if self.simple_vae else prior_mean)
+        h_dec, new_states, mean, log_var, alpha, cond = cell_train_step(
+            dims, P, image_features.to(dev), token_embedding.to(dev), states, sent, eps, obj_atts=obj_atts, training=training,
+            prior_mean=pm_in, prior_var=prior_var)
+        pm = cond if cond is not None else (pm_in.to(dev) if pm_in is not None else torch.zeros(G, Z, device=dev))
+        if self.simple_vae:
+            pm = torch.zeros_like(pm)
+        pv = prior_var.to(dev) if prior_var is not None else torch.ones(G, Z, device=dev)
+        return h_dec, new_states, mean, log_var, pm, pv.log(), alpha

@@ -328,6 +328,47 @@ def full_size_fixture(UpDownCaptioner, name, B, unk):
     print(name, "loss[:3]", out["loss"][:3].detach().numpy(), "kld[:3]", out["kld"][:3].detach().numpy())
 
 
+def cell_fixture(name="g11_cell"):
+    """The reference's UpDownCell on its own (var_updown/var_updown/modules/updown_cell.py:86-231), one training step and one
+    eval step from given states, for SENTIMENT_VAE = 2 (attention-pooled obj_atts as conditioning and prior mean: the branch
+    the captioner cannot reach as shipped) and for modes 0 / 1."""
+    from var_updown.modules import UpDownCell
+    F, E, H, A, R, G = 64, 40, 48, 32, 5, 4
+    data = {}
+    for tag, sv, Z in (("sv2", 2, 150), ("sv1", 1, 16), ("sv0", 0, 16)):
+        torch.manual_seed(7)
+        cell = UpDownCell(F, E, H, A, Z, sv, False, torch.device("cpu"), "glove")
+        g = torch.Generator().manual_seed(40 + sv)
+        feats = torch.randn(G, R, F, generator=g)
+        feats[2, R - 2:] = 0
+        emb = torch.randn(G, E, generator=g)
+        obj = torch.randn(G, R, 150, generator=g) * 0.3 if sv == 2 else None
+        senti = torch.randint(-1, 2, (G, 1), generator=g).float()
+        st_in = {k: torch.randn(G, H, generator=g) * 0.3 for k in ("h1", "c1", "h_encoder", "c_encoder", "h_decoder", "c_decoder")}
+        pm = torch.zeros(G, Z) if sv != 1 else senti.repeat(1, Z) * 0.5
+        pv = torch.full((G, Z), 0.81)
+        for k, v in cell.state_dict().items():
+            data[f"{tag}/param/{k}"] = v.numpy().copy()
+        data.update({f"{tag}/in/feats": feats.numpy(), f"{tag}/in/emb": emb.numpy(), f"{tag}/in/sentiment": senti.numpy(),
+                     f"{tag}/in/prior_mean": pm.numpy(), f"{tag}/in/prior_var": pv.numpy()})
+        if obj is not None:
+            data[f"{tag}/in/obj_atts"] = obj.numpy()
+        for k, v in st_in.items():
+            data[f"{tag}/in/state/{k}"] = v.numpy()
+        for mode, training in (("train", True), ("eval", False)):
+            eps = torch.randn(G, Z, generator=g)
+            with torch.no_grad(), EpsInjector([eps]):
+                hd, st, mean, lv, pmo, plv, al = cell(feats.clone(), obj, emb, {k: v.clone() for k, v in st_in.items()}, training,
+                                                     senti, None, pm.clone(), pv.clone())
+            data[f"{tag}/{mode}/eps"] = eps.numpy()
+            for k, v in st.items():
+                data[f"{tag}/{mode}/state/{k}"] = v.numpy()
+            data.update({f"{tag}/{mode}/mean": mean.numpy(), f"{tag}/{mode}/log_var": lv.numpy(), f"{tag}/{mode}/prior_mean": pmo.numpy(),
+                         f"{tag}/{mode}/prior_log_var": plv.numpy(), f"{tag}/{mode}/alpha": al.numpy(), f"{tag}/{mode}/h_dec": hd.numpy()})
+        print(name, tag, "h_dec[0,:3]", hd[0, :3].numpy())
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **data)
+
+
 FSM_WORDFORMS = "dog\tdog,dogs\ncat\tcat,cats,kitten\nfire\tfire\nhydrant\thydrant,hydrants\nsalt\tsalt\n" \
                 "and\tand\npepper\tpepper,peppers\nred\tred,reddish\nbird\tbird,birds,zzz_not_in_vocab\n"
 FSM_CASES = [[], ["dog"], ["dog", "cat"], ["fire hydrant"], ["dog", "fire hydrant", "salt and pepper"],
@@ -407,6 +448,7 @@ def fsm_fixture(name="g9_fsm"):
 def main():
     UpDownCaptioner = import_reference()
     fsm_fixture()
+    cell_fixture()
     if "--full" in sys.argv or not os.path.exists(os.path.join(HERE, "g10_full_c2.npz")):
         full_size_fixture(UpDownCaptioner, "g10_full_c1", B=4, unk=False)      # BASELINE configs[0]: batch 4
         full_size_fixture(UpDownCaptioner, "g10_full_c2", B=64, unk=True)      # BASELINE configs[1]: batch 64, with in-caption UNK

@@ -156,3 +156,34 @@ def test_standalone_training_cell_step_matches_reference_step0_and_1():
     emb = m._embedding_layer.weight.detach()[tokens[:, 0].cuda()]
     out = m._updown_cell(feats, None, emb, None, True, senti, None, None, None, eps=eps[0])
     assert maxdiff(out[0], group(d, "step0/")["h_decoder"]) < TOL and len(out) == 7
+
+
+@pytest.mark.parametrize("tag,sv,Z", [("sv2", 2, 150), ("sv1", 1, 16), ("sv0", 0, 16)])
+def test_bare_updown_cell_matches_reference_cell(tag, sv, Z):
+    """A bare UpDownCell (no captioner) on the HIP path against the reference's own UpDownCell.forward
+    (var_updown/var_updown/modules/updown_cell.py:86-231; fixture tests/golden/g11_cell.npz from the imported reference):
+    training and eval steps, all three SENTIMENT_VAE modes - including 2, the attention-grounded style prior
+    (c = sum_r alpha_r obj_atts_r as LSTM conditioning and prior mean, :160-163,185-188,219-222).  Tolerance 1e-4 fp32."""
+    import numpy as np
+    import os
+    from var_updown.modules import UpDownCell
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g11_cell.npz"))
+    t = lambda k: torch.from_numpy(z[f"{tag}/{k}"])
+    torch.manual_seed(7)
+    cell = UpDownCell(64, 40, 48, 32, Z, sv, False, torch.device("cuda"), "glove")
+    sd = {k[len(tag) + 7:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(f"{tag}/param/")}
+    for k, v in cell.state_dict().items():
+        assert torch.equal(v, sd[k]), k          # same constructor order -> same seeded default init as the reference
+    cell = cell.cuda()
+    st_in = {k: t("in/state/" + k) for k in ("h1", "c1", "h_encoder", "c_encoder", "h_decoder", "c_decoder")}
+    obj = t("in/obj_atts").cuda() if sv == 2 else None
+    for mode, training in (("train", True), ("eval", False)):
+        hd, st, mean, lv, pm, plv, al = cell(t("in/feats").cuda(), obj, t("in/emb").cuda(), {k: v.cuda() for k, v in st_in.items()},
+                                             training, t("in/sentiment").cuda(), None, t("in/prior_mean").cuda(),
+                                             t("in/prior_var").cuda(), eps=t(f"{mode}/eps"))
+        assert maxdiff(al, t(f"{mode}/alpha")) < 1e-5
+        assert maxdiff(hd, t(f"{mode}/h_dec")) < 1e-4
+        for k in st_in:
+            assert maxdiff(st[k], t(f"{mode}/state/{k}")) < 1e-4, (mode, k)
+        assert maxdiff(mean, t(f"{mode}/mean")) < 1e-4 and maxdiff(lv, t(f"{mode}/log_var")) < 1e-4
+        assert maxdiff(pm, t(f"{mode}/prior_mean")) < 1e-4 and maxdiff(plv, t(f"{mode}/prior_log_var")) < 1e-5
