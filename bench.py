@@ -250,6 +250,12 @@ def main():
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if rank == 0 and not rehearsal:
+            # first look at what RCCL does with the 446 MB gradient all-reduce on this node (ring vs direct, protocol, channels;
+            # a single ring moves it in ~5 ms, a direct reduce-scatter + all-gather over all 7 xGMI links in
+            # ~0.7 ms): rank 0 logs RCCL's init and tuning decisions to stderr
+            os.environ.setdefault("NCCL_DEBUG", "INFO")
+            os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,TUNING,GRAPH")
         if rehearsal:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -289,6 +295,8 @@ def main():
         step(i)
     if world > 1:
         dist.barrier()
+        eng.dp_profile = True     # exposed all-reduce time per step: compute stream idle between its last backward kernel and
+        eng.dp_exposure_ms()      # the reduced gradients (the four gradient ranges are reduced behind their backward phases)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -302,6 +310,17 @@ def main():
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    dp_exposure = None
+    if world > 1:
+        eng.dp_profile = False
+        ex = eng.dp_exposure_ms()
+        t = torch.tensor([sum(ex) / max(1, len(ex)), max(ex) if ex else 0.0], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dp_exposure = {"allreduce_exposed_ms_per_step_mean": float(t[0]), "allreduce_exposed_ms_per_step_max": float(t[1]),
+                       "bytes_per_step": int(eng.grads.flat.numel() * 4), "scheme": "4 phase-ordered ranges, async behind the "
+                       "backward phases (engine.backward_overlapped)"}
+        if rank == 0:
+            print("data-parallel exchange:", json.dumps(dp_exposure), file=sys.stderr, flush=True)
     loss_probe = None if args.timed_only else eng.forward(*batches[0])[0].mean().item()
 
     result = None
@@ -420,7 +439,7 @@ def main():
                                          "Z=128, V=10000, E=1000, H=1200, A=768, SENTIMENT_VAE=1" % c["B"],
                              "global_batch": world * c["B"], "parallelism": f"dp{world}", "loss_probe": loss_probe},
                   "roofline": roofline, "roofline_large_gemm" if roofline is roof_mb else "roofline_minibatch_gemm": roofline_other,
-                  "roofline_step": roofline_step,
+                  "roofline_step": roofline_step, "data_parallel": dp_exposure,
                   "gemm_time_ms_per_step": {names[k]: agg[k]["ms"] / nprof for k in agg}}
         result["attention_roofline"] = attention_roofline(device)
     if rank == 0 and dres is not None:
