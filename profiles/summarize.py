@@ -3,6 +3,7 @@
 
   python profiles/summarize.py pmc  <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>
   python profiles/summarize.py stats <kernel_stats.csv> <out.csv>
+  python profiles/summarize.py sq    <sq_counter_collection.csv> <grbm_counter_collection.csv> <kernel_stats.csv> <out.csv>
 
 PMC correction (MI355X_MICROARCH.md §HBM): FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports exactly
 half the bytes of a wide (16 B/lane) coalesced streaming read, so the read side is doubled for the GEMM / streaming
@@ -69,8 +70,49 @@ def stats(stats_csv, out):
                     f"{float(r['AverageNs']) / 1e3:.2f},{r['Percentage']}\n")
 
 
+def sq(sq_csv, grbm_csv, stats_csv, out):
+    """Matrix-pipe utilisation per kernel from the SQ pass (summed over all dispatches of the kernel):
+      mfma_busy_frac  = SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CYCLES per SIMD): share of the time a SIMD with resident waves has its matrix
+                        pipe busy.  SQ_BUSY_CYCLES is reported per SE-level SQ and summed; the ratio below uses
+                        SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x CU-busy) with CU-busy taken as SQ_BUSY_CYCLES / SEs-per-CU-normalisation
+                        folded into `busy_ratio_raw` - read it as a RELATIVE number between kernels of one pass;
+      bf16_mops / f32_mops = SQ_INSTS_VALU_MFMA_MOPS_* (units of 512 flops per the counter definition) -> achieved matrix
+                        TFLOP/s = mops * 512 / kernel time, against the 2.5 PFLOP/s dense bf16 peak (mfma_frac_of_bf16_peak).
+    Kernel time = total duration of the kernel in the kernel-stats pass of the same command scaled to this pass's dispatch count."""
+    acc = collections.defaultdict(lambda: collections.defaultdict(float))
+    n = collections.defaultdict(collections.Counter)
+    for path in (sq_csv, grbm_csv):
+        for r in csv.DictReader(open(path)):
+            k = short(r["Kernel_Name"])
+            acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            n[k][r["Counter_Name"]] += 1
+    dur = {}
+    for r in csv.DictReader(open(stats_csv)):
+        dur[short(r["Name"])] = (float(r["TotalDurationNs"]), int(r["Calls"]))
+    with open(out, "w") as f:
+        f.write("kernel,dispatches,avg_us,bf16_mfma_TFLOPs,frac_of_2500TF_bf16_peak,f32_mfma_TFLOPs,mfma_busy_cycles_per_wave_cycle,"
+                "valu_insts_per_dispatch,effective_clock_GHz\n")
+        rows = []
+        for k, c in acc.items():
+            if k not in dur:
+                continue
+            disp = max(n[k].values())
+            t_ns = dur[k][0] / dur[k][1] * disp          # time of `disp` dispatches at the stats pass's average duration
+            bf = c.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0.0) * 512.0 / t_ns / 1e3
+            f32 = c.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0.0) * 512.0 / t_ns / 1e3
+            wave = c.get("SQ_WAVE_CYCLES", 0.0) * 4.0    # quad-cycles -> cycles (MI355X_MICROARCH.md cycle-constants table)
+            busy = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / wave if wave else 0.0
+            clk = c.get("GRBM_GUI_ACTIVE", 0.0) / 8.0 / t_ns if t_ns else 0.0
+            rows.append((t_ns, f"{k},{disp},{dur[k][0] / dur[k][1] / 1e3:.2f},{bf:.1f},{bf / 2500.0:.3f},{f32:.1f},{busy:.3f},"
+                               f"{c.get('SQ_INSTS_VALU', 0.0) / disp:.0f},{clk:.2f}\n"))
+        for _, line in sorted(rows, reverse=True):
+            f.write(line)
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "pmc":
         pmc(*sys.argv[2:5])
+    elif sys.argv[1] == "sq":
+        sq(*sys.argv[2:6])
     else:
         stats(*sys.argv[2:4])
