@@ -342,3 +342,40 @@ def test_full_size_c5_properties():
         scale = max(g0[k].abs().max().item(), 1e-6)
         assert maxdiff(g1[k], g0[k]) <= 2e-4 * scale + 1e-7, (k, maxdiff(g1[k], g0[k]), scale)
     assert float(eng.workspace_view(6)[:, 5, 70:].abs().max()) == 0.0      # no attention weight on the padded regions
+
+
+def test_edge_cases_match_oracle():
+    """Empty caption (only the boundary pair), full-length caption, caption that is ALL @@UNKNOWN@@, an image whose regions are
+    all zero (mask all 0: alpha = 0, averaged features 0 - allennlp masked_softmax / masked_mean clamps), an image with one
+    region, against the oracle; and a batch of one."""
+    cfg = oracle.OracleConfig(vocab_size=60, image_feature_size=36, embedding_size=20, hidden_size=28,
+                              attention_projection_size=12, z_space=8, max_caption_length=5, sentiment_vae=1,
+                              senti_prior_multip=0.5)
+    params = oracle.init_params(cfg, seed=19)
+    g = torch.Generator().manual_seed(2)
+    B, R, L = 6, 4, 5
+    feats = torch.randn(B, R, 36, generator=g)
+    feats[1] = 0                    # no region at all
+    feats[2, 1:] = 0                # a single region
+    caps = torch.zeros(B, L, dtype=torch.long)
+    caps[1] = torch.randint(2, 60, (L,), generator=g)         # full length
+    caps[2, :3] = torch.tensor([5, 0, 7])                     # UNK in the middle
+    caps[3, :2] = 0                                           # "two unknown words" = indistinguishable from empty
+    caps[4, :1] = 9
+    caps[5] = torch.tensor([3, 4, 0, 0, 8])                   # UNK run, then a word
+    senti = torch.tensor([[1.0], [0.0], [-1.0], [1.0], [0.0], [-1.0]])
+    eps = torch.randn(L + 1, B, 8, generator=g)
+    for rows in (slice(0, B), slice(2, 3)):                   # the whole batch, then a batch of one
+        f, c, s_, e = feats[rows], caps[rows], senti[rows], eps[:, rows].contiguous()
+        p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+        out = oracle.train_forward(p, cfg, f, c, s_, e)
+        oracle.train_objective(out, cfg).backward()
+        eng = engine_from(cfg, params)
+        loss, kld = eng.forward(dev(f), dev(c), dev(s_), dev(e))
+        n = f.size(0)
+        assert maxdiff(loss, out["loss"]) < TOL and maxdiff(kld, out["kld"]) < TOL
+        eng.backward(torch.full((n,), 1.0 / n, device="cuda"), torch.full((n,), 1.0 / (n * cfg.kld_weight), device="cuda"))
+        got = eng.grad_dict()
+        for k, v in p.items():
+            assert maxdiff(got[k], v.grad) < TOL, k
+        assert torch.isfinite(loss).all() and all(torch.isfinite(x).all() for x in got.values())
