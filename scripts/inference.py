@@ -35,6 +35,11 @@ parser.add_argument("--vocab-size", type=int, default=10000)
 parser.add_argument("--num-boxes", type=int, default=36)
 parser.add_argument("--images-per-call", type=int, default=50)
 parser.add_argument("--sentiment", type=float, default=None, help="override the per-image sentiment (-1, 0, 1)")
+parser.add_argument("--constraints-json", default="",
+                    help='constrained beam search: {"<image_id>": ["dog", "fire hydrant", ...]} - up to DATA.CBS.MAX_GIVEN_CONSTRAINTS '
+                         "constraint classes per image (what the reference's EvaluationDatasetWithConstraints derives from detector "
+                         "boxes, updown-baseline/updown/data/datasets.py:470-620); needs --wordforms-tsv")
+parser.add_argument("--wordforms-tsv", default="", help="class name <TAB> comma separated word forms (data/constraint_wordforms*.tsv)")
 
 
 class _LocalGlove(UpDownCaptioner):
@@ -71,13 +76,38 @@ def main():
     beam = _C.MODEL.BEAM_SIZE
     boundary = vocabulary.get_token_index("@@BOUNDARY@@")
     predictions = []
+    constraints, builder = {}, None
+    per_call = _A.images_per_call
+    if _A.constraints_json:
+        from ssc_runtime.constraints import FiniteStateMachineBuilder
+        if not _A.wordforms_tsv:
+            raise SystemExit("--constraints-json needs --wordforms-tsv")
+        constraints = {int(k): v for k, v in json.load(open(_A.constraints_json)).items()}
+        kmax = max(1, _C.DATA.CBS.MAX_GIVEN_CONSTRAINTS)
+        builder = FiniteStateMachineBuilder(vocabulary, _A.wordforms_tsv, None, max_given_constraints=kmax,
+                                            max_words_per_constraint=_C.DATA.CBS.MAX_WORDS_PER_CONSTRAINT)
+        per_call = min(per_call, 4)   # (B, S, S, V) uint8 per (image, sample): keep the machines of one call within ~1 GB
     with torch.no_grad():
-        for lo in range(0, len(data), _A.images_per_call):
-            feats = data.feats[lo: lo + _A.images_per_call].to(device)
-            senti = data.senti[lo: lo + _A.images_per_call, 0].to(device)
+        for lo in range(0, len(data), per_call):
+            feats = data.feats[lo: lo + per_call].to(device)
+            senti = data.senti[lo: lo + per_call, 0].to(device)
             if _A.sentiment is not None:
                 senti = torch.full_like(senti, _A.sentiment)
-            pred, _ = diverse_decode(model._dec, feats, senti, n_z, beam, _C.DATA.MAX_CAPTION_LENGTH, boundary)
+            fsm = ncons = None
+            if builder is not None:
+                # one machine per image (shared by its N_Z samples), padded to the chunk's largest state count: the states an
+                # image does not use have no incoming transition and never hold a finite beam
+                built = [builder.build([c for c in constraints.get(int(data.image_id[lo + i]), [])][:kmax]) for i in range(feats.size(0))]
+                S = max(b[1] for b in built)
+                V = vocabulary.get_vocab_size()
+                fsm = torch.zeros(feats.size(0), n_z, S, S, V, dtype=torch.uint8)
+                for i, (m, ns, _) in enumerate(built):
+                    fsm[i, :, :ns, :ns] = m[:ns, :ns]
+                fsm = fsm.view(-1, S, S, V).to(device)
+                ncons = torch.tensor([len(constraints.get(int(data.image_id[lo + i]), [])[:kmax]) for i in range(feats.size(0))]
+                                     ).repeat_interleave(n_z)
+            pred, _ = diverse_decode(model._dec, feats, senti, n_z, beam, _C.DATA.MAX_CAPTION_LENGTH, boundary, fsm=fsm,
+                                     num_constraints=ncons, min_constraints_to_satisfy=_C.MODEL.MIN_CONSTRAINTS_TO_SATISFY)
             pred = pred.cpu()
             for i in range(pred.size(0)):
                 for k in range(n_z):

@@ -96,3 +96,29 @@ def test_resume_continues_schedule_momentum_and_data_order(tmp_path, first, seco
     l_ref = [json.loads(x) for x in open(ref_dir / "scalars.jsonl")]
     l_b = [json.loads(x) for x in open(b_dir / "scalars.jsonl")]
     assert l_b[0]["iteration"] == 4 and abs(l_b[0]["4learning_rate"] - 0.015 * (1 - 3 / 6)) < 1e-9
+
+
+def test_inference_script_with_per_image_constraints(tmp_path):
+    """scripts/inference.py --constraints-json: per-image finite state machines from ssc_runtime.constraints (padded to the
+    chunk's largest state count, shared by an image's N_Z samples), constrained beam search on the device, best
+    constraint-satisfying beam selected: every caption of a constrained image contains its constraints' word forms."""
+    cfg = tmp_path / "cfg.yaml"
+    cfg.write_text(YAML)
+    tsv = tmp_path / "wf.tsv"
+    tsv.write_text("w7\tw7,w8\nw20\tw20\nw21\tw21,w22\n")
+    cons = {"0": ["w7"], "1": ["w7", "w20 w21"], "3": ["w20 w21"]}       # image 2 and 4, 5: unconstrained
+    cj = tmp_path / "cons.json"
+    cj.write_text(json.dumps(cons))
+    out = tmp_path / "pred.json"
+    run([os.path.join(ROOT, "scripts", "inference.py"), "--config", str(cfg), "--gpu-ids", "0", "--synthetic", "6",
+         "--vocab-size", "150", "--num-boxes", "5", "--output-path", str(out), "--constraints-json", str(cj), "--wordforms-tsv",
+         str(tsv), "--config-override", "DATA.CBS.MAX_GIVEN_CONSTRAINTS", "2", "MODEL.MIN_CONSTRAINTS_TO_SATISFY", "2"], ROOT)
+    preds = json.load(open(out))
+    assert len(preds) == 6 * 4
+    for p in preds:
+        words = p["caption"].split()
+        for c in cons.get(str(p["image_id"]), []):
+            if c == "w7":
+                assert "w7" in words or "w8" in words, p
+            else:
+                assert any(a == "w20" and b in ("w21", "w22") for a, b in zip(words, words[1:])), p
