@@ -56,7 +56,34 @@ struct KArgs {
   const int* kcount;  // K = min(K, *kcount)            (single segment, m/n-contiguous operands)
   const int* karows;  // A's k-row k is read from row karows[k]
   const int* kbrows;  // B's k-row k is read from row kbrows[k]
+  int tile_gm;        // tile rows per group of the launch's tile order (tile_order)
 };
+
+// Tile order of a launch (speed only; a bijection for any grid).  Workgroups are dealt round-robin over the 8 XCDs, each
+// with its own L2: (1) every XCD gets a CONTIGUOUS run of the linear tile order; (2) the linear order walks the grid in
+// groups of `gm` tile rows, column by column inside a group, so that the ~64 workgroups resident on an XCD at one time
+// form a roughly square patch (gm x 8 tiles) and share their A row-panels AND B column-panels in that L2.  A row-major
+// run of 64 tiles of a 40 x 79 grid touches 64 B panels + 1 A panel per k-step (35 % of the requested bytes hit in L2);
+// an 8 x 8 patch touches 8 + 8 (87 %).  The large 3xBF16 products are bound by the CU's load path, not by the matrix
+// pipe (MFMA busy ~50 % at 21 B/clk requested per CU), so L2 hits are what raises their rate.  gm = 0: row-major.
+__device__ __forceinline__ void tile_order(int lin, int gx, int gy, int gm, int& bx, int& by) {
+  const int total = gx * gy;
+  const int q = total >> 3, rem = total & 7;          // XCD x owns q (+1 if x < rem) tiles
+  const int xcd = lin & 7, slot = lin >> 3;
+  const int nl = xcd * q + (xcd < rem ? xcd : rem) + slot;
+  if (gm <= 1 || gy <= 1) {
+    by = nl / gx;
+    bx = nl - by * gx;
+    return;
+  }
+  const int group_sz = gm * gx;
+  const int g = nl / group_sz;
+  const int first_row = g * gm;
+  const int rows = min(gy - first_row, gm);
+  const int r = nl - g * group_sz;
+  bx = r / rows;
+  by = first_row + (r - bx * rows);
+}
 
 // ---- global -> register staging of one ROWS x 32 operand tile (ROWS/8 floats per thread) --------------
 // Loads are UNCONDITIONAL: out-of-range rows / k are clamped to a valid address and (for k) zeroed with a select
@@ -385,16 +412,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const KArgs a) {
   // XCD-aware tile order (cdna_hip_programming.md T1): workgroups are dealt round-robin over the 8 XCDs, so give
   // each XCD a contiguous run of row-major tile ids - tiles that share an A panel (same M-tile) then share an L2.
   // Speed only; the map is a bijection for any grid size.
-  int bx = blockIdx.x, by = blockIdx.y;
-  {
-    const int gx = gridDim.x, total = gridDim.x * gridDim.y;
-    const int lin = by * gx + bx;
-    const int q = total >> 3, rem = total & 7;          // XCD x owns q (+1 if x < rem) tiles
-    const int xcd = lin & 7, slot = lin >> 3;
-    const int nl = xcd * q + (xcd < rem ? xcd : rem) + slot;
-    by = nl / gx;
-    bx = nl - by * gx;
-  }
+  int bx, by;
+  tile_order(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x, gridDim.y, a.tile_gm, bx, by);
   const int n0 = bx * RB, m0 = by * RA, z = blockIdx.z;
 
   const int s_lo = z * a.steps_per_split;
@@ -552,20 +571,24 @@ constexpr int PL_ROW_B = 80;               // bytes per LDS plane row (32 bf16 +
 
 // split 4 consecutive fp32 (one float4 of k) into the three bf16 planes, packed two bf16 per dword
 __device__ __forceinline__ void split4(const f32x4& v, u32x2& hi, u32x2& mid, u32x2& lo) {
-  unsigned u[4], m[4], l[4];
+  unsigned xu[4], r1u[4], r2u[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const float x = v[i];
-    const unsigned xu = __float_as_uint(x);
-    u[i] = xu & 0xffff0000u;
-    const float r1 = x - __uint_as_float(u[i]);
-    m[i] = __float_as_uint(r1) & 0xffff0000u;
-    const float r2 = r1 - __uint_as_float(m[i]);
-    l[i] = __float_as_uint(r2);  // <= 8 significant bits: exact as bf16 (low 16 bits are zero)
+    xu[i] = __float_as_uint(x);
+    const float r1 = x - __uint_as_float(xu[i] & 0xffff0000u);
+    r1u[i] = __float_as_uint(r1);
+    const float r2 = r1 - __uint_as_float(r1u[i] & 0xffff0000u);
+    r2u[i] = __float_as_uint(r2);  // <= 8 significant bits: exact as bf16 (low 16 bits are zero)
   }
-  hi[0] = (u[0] >> 16) | u[1];  hi[1] = (u[2] >> 16) | u[3];
-  mid[0] = (m[0] >> 16) | m[1]; mid[1] = (m[2] >> 16) | m[3];
-  lo[0] = (l[0] >> 16) | (l[1] & 0xffff0000u); lo[1] = (l[2] >> 16) | (l[3] & 0xffff0000u);
+  // pack the UPPER halves of two dwords into one (element 2j in the low half): one v_perm_b32 per pair and plane - the upper
+  // 16 bits of x / r1 / r2 are the hi / mid / lo pieces themselves, so the masked values are needed for the subtractions only
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    hi[j] = __builtin_amdgcn_perm(xu[2 * j + 1], xu[2 * j], 0x07060302u);
+    mid[j] = __builtin_amdgcn_perm(r1u[2 * j + 1], r1u[2 * j], 0x07060302u);
+    lo[j] = __builtin_amdgcn_perm(r2u[2 * j + 1], r2u[2 * j], 0x07060302u);
+  }
 }
 
 // WN = 32x32 MFMA tiles per wave along N: block tile 64 x (64*WN).  WN = 2 halves the A re-reads per streamed weight
@@ -583,16 +606,8 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const KArgs a) {
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int half = lane >> 5, l31 = lane & 31;
-  int bx = blockIdx.x, by = blockIdx.y;
-  {
-    const int gx = gridDim.x, total = gridDim.x * gridDim.y;
-    const int lin = by * gx + bx;
-    const int q = total >> 3, rem = total & 7;
-    const int xcd = lin & 7, slot = lin >> 3;
-    const int nl = xcd * q + (xcd < rem ? xcd : rem) + slot;
-    by = nl / gx;
-    bx = nl - by * gx;
-  }
+  int bx, by;
+  tile_order(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x, gridDim.y, a.tile_gm, bx, by);
   const int n0 = bx * RB, m0 = by * 64, z = blockIdx.z;
   const int s_lo = z * a.steps_per_split;
   int s_hi = s_lo + a.steps_per_split;
@@ -777,16 +792,8 @@ __global__ __launch_bounds__(256, 2) void gemm_x3b_kernel(const KArgs a) {
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int half = lane >> 5, l31 = lane & 31;
-  int bx = blockIdx.x, by = blockIdx.y;
-  {
-    const int gx = gridDim.x, total = gridDim.x * gridDim.y;
-    const int lin = by * gx + bx;
-    const int q = total >> 3, rem = total & 7;
-    const int xcd = lin & 7, slot = lin >> 3;
-    const int nl = xcd * q + (xcd < rem ? xcd : rem) + slot;
-    by = nl / gx;
-    bx = nl - by * gx;
-  }
+  int bx, by;
+  tile_order(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x, gridDim.y, a.tile_gm, bx, by);
   const int n0 = bx * 128, m0 = by * 128, z = blockIdx.z;
   const int Meff = a.mcount ? min(a.M, *a.mcount) : a.M;  // uniform per launch
   if (m0 >= Meff) return;
@@ -812,6 +819,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3b_kernel(const KArgs a) {
   // ---- staged tile: 4 + 4 float4 per thread --------------------------------------------------------
   f32x4 ra[4], rb[4];
   unsigned oka = 0, okb = 0;
+  bool full_st = false;   // the staged k-step lies inside its segment (workgroup-uniform): no chunk needs zeroing
   const float* pa[4];
   const float* pb[4];
   int ia[4], ib[4];  // KG: gathered k-row numbers of the NEXT step
@@ -873,6 +881,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3b_kernel(const KArgs a) {
   // inside its segment clamps nothing - and remembers which chunks lie past the end of K.
   auto issue_loads = [&]() {
     oka = okb = 0;
+    full_st = cur.k0 + BK <= cur.K;
     const float* qa[4];
     const float* qb[4];
 #pragma unroll
@@ -912,13 +921,13 @@ __global__ __launch_bounds__(256, 2) void gemm_x3b_kernel(const KArgs a) {
     s_ld = min(s_ld + 1, s_last);
     step_ptrs(how);
   };
-  // registers -> three bf16 planes per operand
-  auto put_planes = [&]() {
+  // registers -> three bf16 planes per operand (VALU + LDS only: the uniform branch on `full_st` surrounds no load)
+  auto put_planes_impl = [&](const bool mask) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int idx = tid + 256 * u;
       f32x4 v = ra[u];
-      if (!((oka >> u) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (mask && !((oka >> u) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
       u32x2 hi, mid, lo;
       split4(v, hi, mid, lo);
       unsigned char* p = lds + (A_KC ? (idx >> 3) * PL_ROW_B + (idx & 7) * 8 : (idx >> 5) * X3B_MC_ROW_B + (idx & 31) * 8);
@@ -930,7 +939,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3b_kernel(const KArgs a) {
     for (int u = 0; u < 4; ++u) {
       const int idx = tid + 256 * u;
       f32x4 v = rb[u];
-      if (!((okb >> u) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (mask && !((okb >> u) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
       u32x2 hi, mid, lo;
       split4(v, hi, mid, lo);
       unsigned char* p = lds + 3 * PLN + (B_KC ? (idx >> 3) * PL_ROW_B + (idx & 7) * 8 : (idx >> 5) * X3B_MC_ROW_B + (idx & 31) * 8);
@@ -938,6 +947,10 @@ __global__ __launch_bounds__(256, 2) void gemm_x3b_kernel(const KArgs a) {
       *reinterpret_cast<u32x2*>(p + PLN) = mid;
       *reinterpret_cast<u32x2*>(p + 2 * PLN) = lo;
     }
+  };
+  auto put_planes = [&]() {
+    if (full_st) put_planes_impl(false);
+    else put_planes_impl(true);
   };
 
   if (s_lo < s_hi) {
@@ -1065,7 +1078,8 @@ template <bool A_KC, bool B_KC, bool KG, int TM, int TN, int PF>
 __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const int blk_y, const int blk_z, const int grid_x,
                                          const int grid_y, const int grid_z) {
   static_assert((TM == 128 && TN == 128) || (TM == 64 && TN == 256), "unsupported tile");
-  static_assert(PF == 1 || PF == 2, "prefetch depth");
+  static_assert(PF >= 1 && PF <= 3, "prefetch depth");
+  constexpr int UNR = (PF == 3) ? 6 : 2;         // lcm(LDS stages, register sets)
   static_assert(!KG || PF == 1, "the gather lists' own loads share the vector-memory counter");
   constexpr int PLA = X3wPlane<TM>::BYTES, PLB = X3wPlane<TN>::BYTES, STAGE = 3 * (PLA + PLB);
   constexpr int MCA = X3wPlane<TM>::MC_ROW_B, MCB = X3wPlane<TN>::MC_ROW_B;
@@ -1076,16 +1090,8 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
   const bool producer = wave >= 4;
   const int tid = threadIdx.x & 255;  // index within the role's 256 threads
   const int lane = tid & 63;
-  int bx = blk_x, by = blk_y;
-  {
-    const int gx = grid_x, total = grid_x * grid_y;
-    const int lin = by * gx + bx;
-    const int q = total >> 3, rem = total & 7;
-    const int xcd = lin & 7, slot = lin >> 3;
-    const int nl = xcd * q + (xcd < rem ? xcd : rem) + slot;
-    by = nl / gx;
-    bx = nl - by * gx;
-  }
+  int bx, by;
+  tile_order(blk_y * grid_x + blk_x, grid_x, grid_y, a.tile_gm, bx, by);
   const int n0 = bx * TN, m0 = by * TM, z = blk_z;
   const int Meff = a.mcount ? min(a.M, *a.mcount) : a.M;  // uniform per launch
   if (m0 >= Meff) return;
@@ -1267,13 +1273,17 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
       issue_loads(ra[0], rb[0], oka[0], okb[0]);
     }
     __syncthreads();
-    // Both halves always run (the trip count is rounded up to an even number of k-steps; the consumers take the same
-    // number of barriers): every path issues the same loads and waits; loads past the end re-read the last tile (clamped
-    // cursor) and are never stored.
-    for (int s = s_lo; s < s_hi; s += 2) {
+    // Iteration r = s + h - s_lo: tile r + 1 (register set (r + 1) % PF) has landed once at most PF - 1 younger tiles are
+    // outstanding; it goes to LDS stage (r + 1) & 1 while the consumers work on stage r & 1, and its register set takes tile
+    // r + 1 + PF.  The body is unrolled UNR = lcm(2, PF) times so that set and stage are compile-time.  All UNR parts always
+    // run (the trip count is rounded up to a multiple of UNR; the consumers take the same number of barriers): ONE loop exit,
+    // every path issues the same loads and waits - with a second exit hipcc resolves the register sets' phi at the exits with
+    // copies of in-flight registers (seen with a mid-body break; caught by tools/check_staged_loads.py).  Loads past the end
+    // re-read the last tile (clamped cursor) and are never stored.
+    for (int s = s_lo; s < s_hi; s += UNR) {
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int j = (h + 1) % PF;   // (s + h - s_lo + 1) % PF: s - s_lo is even here
+      for (int h = 0; h < UNR; ++h) {
+        const int j = (h + 1) % PF;   // (s + h - s_lo + 1) % PF: s - s_lo is a multiple of UNR here
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PF - 1) * NL) : "memory");
         pin(ra[j], rb[j]);
         if (s + h + 1 < s_hi) put_planes(lds + ((h + 1) & 1) * STAGE, ra[j], rb[j], oka[j], okb[j]);   // VALU + LDS only
@@ -1354,11 +1364,12 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
   };
 
   __syncthreads();
-  for (int s = s_lo; s < s_hi; s += 2) {   // two barriers per trip, like the producers
-    compute(lds);
-    __syncthreads();
-    if (s + 1 < s_hi) compute(lds + STAGE);
-    __syncthreads();
+  for (int s = s_lo; s < s_hi; s += UNR) {   // UNR barriers per trip, like the producers
+#pragma unroll
+    for (int h = 0; h < UNR; ++h) {
+      if (s + h < s_hi) compute(lds + (h & 1) * STAGE);
+      __syncthreads();
+    }
   }
 #undef SSC_X3W_MFMA
 
@@ -1466,8 +1477,10 @@ ProfRec* g_prof = nullptr;
 int g_prof_n = 0;
 bool g_prof_on = false;
 
+int g_tile_gm = getenv("SSC_TILE_GM") ? atoi(getenv("SSC_TILE_GM")) : 8;   // tile_order(): tile rows per group (0 = row-major)
 int build_args(const ssc_gemm_desc* d, KArgs& k) {
   if (!d || d->nseg < 1 || d->nseg > SSC_MAX_SEG || d->M <= 0 || d->N <= 0) return SSC_EINVAL;
+  k.tile_gm = g_tile_gm;
   k.nseg = d->nseg;
   k.M = d->M;
   k.N = d->N;
@@ -1547,7 +1560,8 @@ int x3w_prepare() {
                      gemm_x3w_kernel<false, false, true, 128, 128, 1>, gemm_x3w_kernel<false, false, false, 128, 128, 2>};
   for (group_fn f : big)
     if (hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, x3w_lds_bytes<128, 128>()) != hipSuccess) return SSC_EHIP;
-  group_fn skinny[2] = {gemm_x3w_kernel<true, true, false, 64, 256, 2>, gemm_x3w_kernel<true, false, false, 64, 256, 2>};
+  group_fn skinny[4] = {gemm_x3w_kernel<true, true, false, 64, 256, 2>, gemm_x3w_kernel<true, false, false, 64, 256, 2>,
+                        gemm_x3w_kernel<true, true, false, 64, 256, 3>, gemm_x3w_kernel<true, false, false, 64, 256, 3>};
   for (group_fn f : skinny)
     if (hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, x3w_lds_bytes<64, 256>()) != hipSuccess) return SSC_EHIP;
   done = true;
@@ -1557,6 +1571,14 @@ int g_x3w_skinny = getenv("SSC_X3W_SKINNY") ? atoi(getenv("SSC_X3W_SKINNY")) : 1
 int g_x3w_min_n = getenv("SSC_X3W_MIN_N") ? atoi(getenv("SSC_X3W_MIN_N")) : 1024;   // narrower products do not fill the chip with 256-column tiles (rocprof: slower than the 64-wide kernels)
 int g_gemm_group = getenv("SSC_GEMM_GROUP") ? atoi(getenv("SSC_GEMM_GROUP")) : 1;   // grouped launches of independent minibatch products
 int g_dw_group = getenv("SSC_DW_GROUP") ? atoi(getenv("SSC_DW_GROUP")) : 1;       // grouped launches of the weight-gradient products (wave-specialised 128x128 form); 0 = one 4-wave launch per product
+// k-steps of operand tiles in flight in the producers' registers of the 64x256 kernels: 2 (default) | 3.  Three (120 staged
+// VGPRs, loop unrolled 6x) measured 2-6 % SLOWER on every gate product (40.5 -> 42.8 us at 64 x 4800 x 5648; train step 9.22 ->
+// 9.45 ms): the k-loop is not short of bytes in flight.
+int g_x3w_pf = getenv("SSC_X3W_PF") ? atoi(getenv("SSC_X3W_PF")) : 2;
+inline group_fn x3w_skinny_fn(bool b_kc) {
+  if (g_x3w_pf == 3) return b_kc ? gemm_x3w_kernel<true, true, false, 64, 256, 3> : gemm_x3w_kernel<true, false, false, 64, 256, 3>;
+  return b_kc ? gemm_x3w_kernel<true, true, false, 64, 256, 2> : gemm_x3w_kernel<true, false, false, 64, 256, 2>;
+}
 inline bool x3w_skinny_shape(int M, int N) { return g_x3w_skinny && gemm_mode() == 1 && M <= 64 && N >= g_x3w_min_n; }
 inline bool x3w_skinny(const ssc_gemm_desc* d, bool vec) {   // 2 = only where the weight matrix is [K][N] (backward dG W)
   return vec && d->a_kc && x3w_skinny_shape(d->M, d->N) && (g_x3w_skinny == 1 || !d->b_kc);
@@ -1586,8 +1608,7 @@ int launch(const ssc_gemm_desc* d, KArgs& k, int splits, hipStream_t st) {
     SSC_TRY(x3w_prepare());
     KGroup g1;
     group_of_one(g1, k, grid);
-    if (d->b_kc) SSC_LAUNCH((gemm_x3w_kernel<true, true, false, 64, 256, 2>), dim3(g1.first[1]), dim3(512), (x3w_lds_bytes<64, 256>()), st, g1);
-    else SSC_LAUNCH((gemm_x3w_kernel<true, false, false, 64, 256, 2>), dim3(g1.first[1]), dim3(512), (x3w_lds_bytes<64, 256>()), st, g1);
+    SSC_LAUNCH(x3w_skinny_fn(d->b_kc), dim3(g1.first[1]), dim3(512), (x3w_lds_bytes<64, 256>()), st, g1);
     if (rec) (void)hipEventRecord(rec->e1, st);
     SSC_CHECK_LAUNCH();
     return SSC_OK;
@@ -1822,8 +1843,7 @@ int ssc_gemm_slabs_group(const ssc_gemm_desc* const* d, int n, float* const* reg
     rec->M = d[0]->M; rec->N = Nmax; rec->splits = nslab[0]; rec->K = Ksum;
     (void)hipEventRecord(rec->e0, st);
   }
-  if (d[0]->b_kc) SSC_LAUNCH((gemm_x3w_kernel<true, true, false, 64, 256, 2>), dim3(g.first[n]), dim3(512), (x3w_lds_bytes<64, 256>()), st, g);
-  else SSC_LAUNCH((gemm_x3w_kernel<true, false, false, 64, 256, 2>), dim3(g.first[n]), dim3(512), (x3w_lds_bytes<64, 256>()), st, g);
+  SSC_LAUNCH(x3w_skinny_fn(d[0]->b_kc), dim3(g.first[n]), dim3(512), (x3w_lds_bytes<64, 256>()), st, g);
   if (rec) (void)hipEventRecord(rec->e1, st);
   SSC_CHECK_LAUNCH();
   return SSC_OK;
@@ -1978,6 +1998,8 @@ const DebugKey g_debug_keys[] = {
     {"wide_min_n", &g_wide_min_n},   // exact-fp32 kernels: 64x128 tile for M <= 64 from this width on
     {"gemm_group", &g_gemm_group},   // grouped launches of independent minibatch products (0 | 1)   (SSC_GEMM_GROUP)
     {"dw_group", &g_dw_group},       // grouped launches of the weight-gradient products (0 | 1)   (SSC_DW_GROUP)
+    {"x3w_pf", &g_x3w_pf},           // 64x256 kernels: k-steps in flight in the producers' registers (2 | 3)   (SSC_X3W_PF)
+    {"tile_gm", &g_tile_gm},         // tile rows per group of the tile order (8; 0 = row-major)   (SSC_TILE_GM)
 };
 }  // namespace
 
