@@ -1080,6 +1080,10 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
   static_assert((TM == 128 && TN == 128) || (TM == 64 && TN == 256), "unsupported tile");
   static_assert(PF >= 1 && PF <= 3, "prefetch depth");
   constexpr int UNR = (PF == 3) ? 6 : 2;         // lcm(LDS stages, register sets)
+  // Device-side row lists (mcount / arows / crows) exist for the 128x128 form only: the minibatch kernels are never launched
+  // with them, and their mere presence costs the k-loop a compiler-visible gather load + `s_waitcnt vmcnt(0)` at every
+  // K-segment change (base_ptrs), which drains the hand-staged prefetch too.
+  constexpr bool RL = TM == 128;
   static_assert(!KG || PF == 1, "the gather lists' own loads share the vector-memory counter");
   constexpr int PLA = X3wPlane<TM>::BYTES, PLB = X3wPlane<TN>::BYTES, STAGE = 3 * (PLA + PLB);
   constexpr int MCA = X3wPlane<TM>::MC_ROW_B, MCB = X3wPlane<TN>::MC_ROW_B;
@@ -1093,7 +1097,7 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
   int bx, by;
   tile_order(blk_y * grid_x + blk_x, grid_x, grid_y, a.tile_gm, bx, by);
   const int n0 = bx * TN, m0 = by * TM, z = blk_z;
-  const int Meff = a.mcount ? min(a.M, *a.mcount) : a.M;  // uniform per launch
+  const int Meff = (RL && a.mcount) ? min(a.M, *a.mcount) : a.M;  // uniform per launch
   if (m0 >= Meff) return;
   const int Kc = a.kcount ? max(0, min(a.seg[0].K, *a.kcount)) : 0;
   int steps_total = a.steps_total, steps_per_split = a.steps_per_split;
@@ -1111,6 +1115,7 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
     // ================================ producer waves ================================
     f32x4 ra[PF][NA], rb[PF][NB];
     unsigned oka[PF], okb[PF];
+    bool fullk[PF];   // uniform: the set's k-step lies wholly inside its K segment (no chunk needs zeroing)
     const float* pa[NA];
     const float* pb[NB];
     int ia[NA], ib[NB];  // KG: gathered k-row numbers of the NEXT step
@@ -1123,7 +1128,7 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
         const int idx = tid + 256 * u;
         if constexpr (A_KC) {
           int r = min(m0 + (idx >> 3), Meff - 1);
-          if (a.arows) r = a.arows[r];
+          if constexpr (RL) { if (a.arows) r = a.arows[r]; }
           pa[u] = cur.A + (size_t)r * cur.lda + cur.k0 + 4 * (idx & 7);
         } else {
           int kr = cur.k0 + idx / QA;
@@ -1180,8 +1185,9 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
     };
     // Branch-free (no branch may surround a staged load: see Stage::load_ptrs): every k-step takes the clamped form - a step
     // inside its segment clamps nothing - and remembers which chunks lie past the end of K.
-    auto issue_loads = [&](f32x4 (&xa)[NA], f32x4 (&xb)[NB], unsigned& ma, unsigned& mb) {
+    auto issue_loads = [&](f32x4 (&xa)[NA], f32x4 (&xb)[NB], unsigned& ma, unsigned& mb, bool& full) {
       ma = mb = 0;
+      full = cur.k0 + BK <= cur.K;
       const float* qa[NA];
       const float* qb[NB];
       // k-contiguous operands: chunk u of this thread starts at k0 + 4*(tid & 7) for every u (idx = tid + 256 u)
@@ -1238,8 +1244,7 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
       *reinterpret_cast<u32x2*>(p + plane) = mid;
       *reinterpret_cast<u32x2*>(p + 2 * plane) = lo;
     };
-    auto put_planes = [&](unsigned char* st, const f32x4 (&xa)[NA], const f32x4 (&xb)[NB], unsigned ma, unsigned mb) {
-      const bool all = (ma == (1u << NA) - 1u) && (mb == (1u << NB) - 1u);  // every chunk of this thread in range: no select
+    auto put_planes_impl = [&](unsigned char* st, const f32x4 (&xa)[NA], const f32x4 (&xb)[NB], unsigned ma, unsigned mb, const bool all) {
 #pragma unroll
       for (int u = 0; u < NA; ++u) {
         const int idx = tid + 256 * u;
@@ -1251,6 +1256,11 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
         put_chunk(st + 3 * PLA + (B_KC ? (idx >> 3) * PL_ROW_B + (idx & 7) * 8 : (idx / QB) * MCB + (idx % QB) * 8), PLB, xb[u], all || ((mb >> u) & 1u));
       }
     };
+    // a k-step inside its segment (uniform test: a scalar branch around VALU + LDS work only) needs no per-chunk select
+    auto put_planes = [&](unsigned char* st, const f32x4 (&xa)[NA], const f32x4 (&xb)[NB], unsigned ma, unsigned mb, bool full) {
+      if (full) put_planes_impl(st, xa, xb, ma, mb, true);
+      else put_planes_impl(st, xa, xb, ma, mb, false);
+    };
     constexpr int NL = NA + NB;
 
     if (s_lo < s_hi) {
@@ -1260,17 +1270,17 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
       prefetch_rows();
       // the first PF tiles are requested back to back (one exposed memory latency, not two); afterwards set (r+1) % PF
       // holds tile s_lo + r + 1 when iteration r starts
-      issue_loads(ra[0], rb[0], oka[0], okb[0]);
+      issue_loads(ra[0], rb[0], oka[0], okb[0], fullk[0]);
 #pragma unroll
       for (int j = 1; j < PF; ++j) {
         advance();
-        issue_loads(ra[j], rb[j], oka[j], okb[j]);
+        issue_loads(ra[j], rb[j], oka[j], okb[j], fullk[j]);
       }
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PF - 1) * NL) : "memory");
       pin(ra[0], rb[0]);
-      put_planes(lds, ra[0], rb[0], oka[0], okb[0]);
+      put_planes(lds, ra[0], rb[0], oka[0], okb[0], fullk[0]);
       advance();
-      issue_loads(ra[0], rb[0], oka[0], okb[0]);
+      issue_loads(ra[0], rb[0], oka[0], okb[0], fullk[0]);
     }
     __syncthreads();
     // Iteration r = s + h - s_lo: tile r + 1 (register set (r + 1) % PF) has landed once at most PF - 1 younger tiles are
@@ -1286,9 +1296,9 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
         const int j = (h + 1) % PF;   // (s + h - s_lo + 1) % PF: s - s_lo is a multiple of UNR here
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PF - 1) * NL) : "memory");
         pin(ra[j], rb[j]);
-        if (s + h + 1 < s_hi) put_planes(lds + ((h + 1) & 1) * STAGE, ra[j], rb[j], oka[j], okb[j]);   // VALU + LDS only
+        if (s + h + 1 < s_hi) put_planes(lds + ((h + 1) & 1) * STAGE, ra[j], rb[j], oka[j], okb[j], fullk[j]);   // VALU + LDS only
         advance();
-        issue_loads(ra[j], rb[j], oka[j], okb[j]);
+        issue_loads(ra[j], rb[j], oka[j], okb[j], fullk[j]);
         __syncthreads();
       }
     }
@@ -1399,7 +1409,7 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
       const int row = c / CPR, col = 4 * (c % CPR);
       const int grow = m0 + row, gcol = n0 + col;
       if (grow >= Meff || gcol >= a.N) continue;
-      const int rr = a.crows ? a.crows[grow] : grow;
+      const int rr = (RL && a.crows) ? a.crows[grow] : grow;
       float4 v = *reinterpret_cast<const float4*>(&ct[row * CT_LD + col]);
       float* dst = out + (size_t)rr * a.ldo + gcol;
       if (wide) {
