@@ -1067,14 +1067,29 @@ __global__ __launch_bounds__(256, 2) void gemm_x3b_kernel(const KArgs a) {
 //              k-step moves 32 KB of weights per CU, so a single workgroup per CU keeps HBM busy.
 // Two LDS stages of six planes: 120 KB / 150 KB of dynamic LDS, one workgroup (8 waves) per CU.
 // =====================================================================================================
+// Diagnostics build only (tools/x3w_stamp.py compiles a second library with -DSSC_X3W_STAMP; the product build has none of
+// this): one workgroup records the shader clock at the phase boundaries of its producer wave 4 and consumer wave 0 into
+// 2 KB of LDS behind the operand stages and dumps them at the end.
+#ifdef SSC_X3W_STAMP
+__device__ unsigned long long* g_stamp_ptr = nullptr;
+__device__ int g_stamp_wg = -1;
+#define SSC_STAMP(i)                                                                                  \
+  do {                                                                                                \
+    if (stamp_on && lane == 0 && (i) < 124) stamp_lds[(i)] = __builtin_readcyclecounter();           \
+  } while (0)
+constexpr int X3W_STAMP_BYTES = 2048;
+#else
+#define SSC_STAMP(i) do {} while (0)
+constexpr int X3W_STAMP_BYTES = 0;
+#endif
 template <int R> struct X3wPlane {   // one bf16 plane of an R-row operand tile: k-contiguous or m/n-contiguous image
   static constexpr int MC_ROW_B = 2 * R + 64;                        // [32 k][R bf16 + 64 B pad]: 4 k-rows x 64 B on 64 banks
   static constexpr int KC_BYTES = R * PL_ROW_B, MC_BYTES = 32 * MC_ROW_B;
   static constexpr int BYTES = KC_BYTES > MC_BYTES ? KC_BYTES : MC_BYTES;
 };
-template <int TM, int TN> constexpr int x3w_lds_bytes() { return 2 * 3 * (X3wPlane<TM>::BYTES + X3wPlane<TN>::BYTES); }
+template <int TM, int TN> constexpr int x3w_lds_bytes() { return 2 * 3 * (X3wPlane<TM>::BYTES + X3wPlane<TN>::BYTES) + X3W_STAMP_BYTES; }
 
-template <bool A_KC, bool B_KC, bool KG, int TM, int TN, int PF>
+template <bool A_KC, bool B_KC, bool KG, int TM, int TN, int PF, int NPW>
 __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const int blk_y, const int blk_z, const int grid_x,
                                          const int grid_y, const int grid_z) {
   static_assert((TM == 128 && TN == 128) || (TM == 64 && TN == 256), "unsupported tile");
@@ -1087,12 +1102,15 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
   static_assert(!KG || PF == 1, "the gather lists' own loads share the vector-memory counter");
   constexpr int PLA = X3wPlane<TM>::BYTES, PLB = X3wPlane<TN>::BYTES, STAGE = 3 * (PLA + PLB);
   constexpr int MCA = X3wPlane<TM>::MC_ROW_B, MCB = X3wPlane<TN>::MC_ROW_B;
-  constexpr int NA = TM / 32, NB = TN / 32;      // float4 chunks per producer thread and k-step
+  static_assert(NPW == 4 || NPW == 8, "producer waves");
+  constexpr int NPT = 64 * NPW;                  // producer threads
+  constexpr int NTHR = 256 + NPT;                // workgroup size: 4 consumer waves + NPW producer waves
+  constexpr int NA = TM * 8 / NPT, NB = TN * 8 / NPT;   // float4 chunks per producer thread and k-step
   constexpr int QA = TM / 4, QB = TN / 4;        // float4 per k-row of an m/n-contiguous tile
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int wave = threadIdx.x >> 6;
   const bool producer = wave >= 4;
-  const int tid = threadIdx.x & 255;  // index within the role's 256 threads
+  const int tid = producer ? (int)threadIdx.x - 256 : (int)threadIdx.x;  // index within the role's threads
   const int lane = tid & 63;
   int bx, by;
   tile_order(blk_y * grid_x + blk_x, grid_x, grid_y, a.tile_gm, bx, by);
@@ -1110,6 +1128,12 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
   if (s_hi > steps_total) s_hi = steps_total;
   const int s_last = s_hi - 1;
   constexpr int CT_LD = TN + 4;   // epilogue C tile in LDS
+#ifdef SSC_X3W_STAMP
+  const bool stamp_on = (int)blockIdx.x == g_stamp_wg && (wave == 0 || wave == 4);
+  unsigned long long* stamp_lds = reinterpret_cast<unsigned long long*>(lds + 2 * STAGE) + (wave == 4 ? 0 : 128);
+  if (stamp_on && lane == 0) { stamp_lds[126] = __builtin_readcyclecounter(); stamp_lds[127] = wall_clock64(); }
+  const unsigned long long stamp_entry = wall_clock64();   // g_stamp_wg == -2: every workgroup reports entry / exit wall clock
+#endif
 
   if (producer) {
     // ================================ producer waves ================================
@@ -1125,7 +1149,7 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
     auto base_ptrs = [&]() {
 #pragma unroll
       for (int u = 0; u < NA; ++u) {
-        const int idx = tid + 256 * u;
+        const int idx = tid + NPT * u;
         if constexpr (A_KC) {
           int r = min(m0 + (idx >> 3), Meff - 1);
           if constexpr (RL) { if (a.arows) r = a.arows[r]; }
@@ -1138,7 +1162,7 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
       }
 #pragma unroll
       for (int u = 0; u < NB; ++u) {
-        const int idx = tid + 256 * u;
+        const int idx = tid + NPT * u;
         if constexpr (B_KC) {
           pb[u] = cur.B + (size_t)min(n0 + (idx >> 3), a.N - 1) * cur.ldb + cur.k0 + 4 * (idx & 7);
         } else {
@@ -1152,12 +1176,12 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
       if constexpr (KG) {
 #pragma unroll
         for (int u = 0; u < NA; ++u) {
-          const int kr = min(cur.k0 + BK + (tid + 256 * u) / QA, cur.K - 1);
+          const int kr = min(cur.k0 + BK + (tid + NPT * u) / QA, cur.K - 1);
           ia[u] = a.karows ? a.karows[kr] : kr;
         }
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
-          const int kr = min(cur.k0 + BK + (tid + 256 * u) / QB, cur.K - 1);
+          const int kr = min(cur.k0 + BK + (tid + NPT * u) / QB, cur.K - 1);
           ib[u] = a.kbrows ? a.kbrows[kr] : kr;
         }
       }
@@ -1168,14 +1192,14 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
       } else if (how == 1) {
 #pragma unroll
         for (int u = 0; u < NA; ++u) {
-          const int idx = tid + 256 * u;
+          const int idx = tid + NPT * u;
           if constexpr (A_KC) pa[u] += BK;
           else if constexpr (KG) pa[u] = cur.A + (size_t)ia[u] * cur.lda + min(m0 + 4 * (idx % QA), Meff - 4);
           else pa[u] += (size_t)BK * cur.lda;
         }
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
-          const int idx = tid + 256 * u;
+          const int idx = tid + NPT * u;
           if constexpr (B_KC) pb[u] += BK;
           else if constexpr (KG) pb[u] = cur.B + (size_t)ib[u] * cur.ldb + min(n0 + 4 * (idx % QB), a.N - 4);
           else pb[u] += (size_t)BK * cur.ldb;
@@ -1196,7 +1220,7 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
       const unsigned kc_ok = kc < cur.K ? 1u : 0u;
 #pragma unroll
       for (int u = 0; u < NA; ++u) {
-        const int idx = tid + 256 * u;
+        const int idx = tid + NPT * u;
         if constexpr (A_KC) {
           qa[u] = pa[u] + kc_adj;
           ma |= kc_ok << u;
@@ -1208,7 +1232,7 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
       }
 #pragma unroll
       for (int u = 0; u < NB; ++u) {
-        const int idx = tid + 256 * u;
+        const int idx = tid + NPT * u;
         if constexpr (B_KC) {
           qb[u] = pb[u] + kc_adj;
           mb |= kc_ok << u;
@@ -1247,12 +1271,12 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
     auto put_planes_impl = [&](unsigned char* st, const f32x4 (&xa)[NA], const f32x4 (&xb)[NB], unsigned ma, unsigned mb, const bool all) {
 #pragma unroll
       for (int u = 0; u < NA; ++u) {
-        const int idx = tid + 256 * u;
+        const int idx = tid + NPT * u;
         put_chunk(st + (A_KC ? (idx >> 3) * PL_ROW_B + (idx & 7) * 8 : (idx / QA) * MCA + (idx % QA) * 8), PLA, xa[u], all || ((ma >> u) & 1u));
       }
 #pragma unroll
       for (int u = 0; u < NB; ++u) {
-        const int idx = tid + 256 * u;
+        const int idx = tid + NPT * u;
         put_chunk(st + 3 * PLA + (B_KC ? (idx >> 3) * PL_ROW_B + (idx & 7) * 8 : (idx / QB) * MCB + (idx % QB) * 8), PLB, xb[u], all || ((mb >> u) & 1u));
       }
     };
@@ -1296,10 +1320,14 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
         const int j = (h + 1) % PF;   // (s + h - s_lo + 1) % PF: s - s_lo is a multiple of UNR here
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PF - 1) * NL) : "memory");
         pin(ra[j], rb[j]);
+        SSC_STAMP(4 * (s + h - s_lo));
         if (s + h + 1 < s_hi) put_planes(lds + ((h + 1) & 1) * STAGE, ra[j], rb[j], oka[j], okb[j], fullk[j]);   // VALU + LDS only
+        SSC_STAMP(4 * (s + h - s_lo) + 1);
         advance();
         issue_loads(ra[j], rb[j], oka[j], okb[j], fullk[j]);
+        SSC_STAMP(4 * (s + h - s_lo) + 2);
         __syncthreads();
+        SSC_STAMP(4 * (s + h - s_lo) + 3);
       }
     }
     // drain the clamped tail loads with the staged registers pinned (see gemm_kernel)
@@ -1377,8 +1405,11 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
   for (int s = s_lo; s < s_hi; s += UNR) {   // UNR barriers per trip, like the producers
 #pragma unroll
     for (int h = 0; h < UNR; ++h) {
+      SSC_STAMP(4 * (s + h - s_lo));
       if (s + h < s_hi) compute(lds + (h & 1) * STAGE);
+      SSC_STAMP(4 * (s + h - s_lo) + 1);
       __syncthreads();
+      SSC_STAMP(4 * (s + h - s_lo) + 2);
     }
   }
 #undef SSC_X3W_MFMA
@@ -1404,8 +1435,9 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
                       !(reinterpret_cast<uintptr_t>(a.bias) & 15);
     constexpr int CPR = TN / 4;  // float4 chunks per tile row
 #pragma unroll
-    for (int i = 0; i < TM * CPR / 512; ++i) {
-      const int c = (int)threadIdx.x + 512 * i;
+    for (int i = 0; i < (TM * CPR + NTHR - 1) / NTHR; ++i) {
+      const int c = (int)threadIdx.x + NTHR * i;
+      if (TM * CPR % NTHR != 0 && c >= TM * CPR) break;
       const int row = c / CPR, col = 4 * (c % CPR);
       const int grow = m0 + row, gcol = n0 + col;
       if (grow >= Meff || gcol >= a.N) continue;
@@ -1425,6 +1457,16 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
       }
     }
   }
+#ifdef SSC_X3W_STAMP
+  if (stamp_on && lane == 0) { stamp_lds[124] = __builtin_readcyclecounter(); stamp_lds[125] = wall_clock64(); }
+  __syncthreads();
+  if ((int)blockIdx.x == g_stamp_wg && threadIdx.x < 256 && g_stamp_ptr)
+    g_stamp_ptr[threadIdx.x] = reinterpret_cast<const unsigned long long*>(lds + 2 * STAGE)[threadIdx.x];
+  if (g_stamp_wg == -2 && threadIdx.x == 0 && g_stamp_ptr && blockIdx.x < 1024) {
+    g_stamp_ptr[2 * blockIdx.x] = stamp_entry;
+    g_stamp_ptr[2 * blockIdx.x + 1] = wall_clock64();
+  }
+#endif
 }
 
 
@@ -1439,8 +1481,8 @@ struct KGroup {
   int first[SSC_GROUP_MAX + 1];
   int gx[SSC_GROUP_MAX], gy[SSC_GROUP_MAX], gz[SSC_GROUP_MAX];
 };
-template <bool A_KC, bool B_KC, bool KG, int TM, int TN, int PF>
-__global__ __launch_bounds__(512) void gemm_x3w_kernel(const KGroup g) {
+template <bool A_KC, bool B_KC, bool KG, int TM, int TN, int PF, int NPW = 4>
+__global__ __launch_bounds__(256 + 64 * NPW) void gemm_x3w_kernel(const KGroup g) {
   const int w = blockIdx.x;
   int p = 0;
 #pragma unroll
@@ -1449,7 +1491,7 @@ __global__ __launch_bounds__(512) void gemm_x3w_kernel(const KGroup g) {
   const int local = w - g.first[p];
   const int gx = g.gx[p], gy = g.gy[p], gz = g.gz[p];
   const int x = local % gx, yz = local / gx;
-  x3w_body<A_KC, B_KC, KG, TM, TN, PF>(g.a[p], x, yz % gy, yz / gy, gx, gy, gz);
+  x3w_body<A_KC, B_KC, KG, TM, TN, PF, NPW>(g.a[p], x, yz % gy, yz / gy, gx, gy, gz);
 }
 
 __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int nslab, size_t slab_stride, int M, int N,
@@ -1566,12 +1608,15 @@ inline void group_of_one(KGroup& g, const KArgs& k, dim3 grid) {
 int x3w_prepare() {
   static bool done = false;
   if (done) return SSC_OK;
-  group_fn big[4] = {gemm_x3w_kernel<true, true, false, 128, 128, 2>, gemm_x3w_kernel<true, false, false, 128, 128, 2>,
-                     gemm_x3w_kernel<false, false, true, 128, 128, 1>, gemm_x3w_kernel<false, false, false, 128, 128, 2>};
+  group_fn big[8] = {gemm_x3w_kernel<true, true, false, 128, 128, 2>, gemm_x3w_kernel<true, false, false, 128, 128, 2>,
+                     gemm_x3w_kernel<false, false, true, 128, 128, 1>, gemm_x3w_kernel<false, false, false, 128, 128, 2>,
+                     gemm_x3w_kernel<true, true, false, 128, 128, 2, 8>, gemm_x3w_kernel<true, false, false, 128, 128, 2, 8>,
+                     gemm_x3w_kernel<false, false, true, 128, 128, 1, 8>, gemm_x3w_kernel<false, false, false, 128, 128, 2, 8>};
   for (group_fn f : big)
     if (hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, x3w_lds_bytes<128, 128>()) != hipSuccess) return SSC_EHIP;
-  group_fn skinny[4] = {gemm_x3w_kernel<true, true, false, 64, 256, 2>, gemm_x3w_kernel<true, false, false, 64, 256, 2>,
-                        gemm_x3w_kernel<true, true, false, 64, 256, 3>, gemm_x3w_kernel<true, false, false, 64, 256, 3>};
+  group_fn skinny[6] = {gemm_x3w_kernel<true, true, false, 64, 256, 2>, gemm_x3w_kernel<true, false, false, 64, 256, 2>,
+                        gemm_x3w_kernel<true, true, false, 64, 256, 3>, gemm_x3w_kernel<true, false, false, 64, 256, 3>,
+                        gemm_x3w_kernel<true, true, false, 64, 256, 2, 8>, gemm_x3w_kernel<true, false, false, 64, 256, 2, 8>};
   for (group_fn f : skinny)
     if (hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, x3w_lds_bytes<64, 256>()) != hipSuccess) return SSC_EHIP;
   done = true;
@@ -1585,7 +1630,23 @@ int g_dw_group = getenv("SSC_DW_GROUP") ? atoi(getenv("SSC_DW_GROUP")) : 1;     
 // VGPRs, loop unrolled 6x) measured 2-6 % SLOWER on every gate product (40.5 -> 42.8 us at 64 x 4800 x 5648; train step 9.22 ->
 // 9.45 ms): the k-loop is not short of bytes in flight.
 int g_x3w_pf = getenv("SSC_X3W_PF") ? atoi(getenv("SSC_X3W_PF")) : 2;
+int g_x3w_npw = getenv("SSC_X3W_NPW") ? atoi(getenv("SSC_X3W_NPW")) : 8;   // producer waves of the 64x256 kernels (4 | 8)
+int g_x3w_big_npw = getenv("SSC_X3W_BIG_NPW") ? atoi(getenv("SSC_X3W_BIG_NPW")) : 8;   // producer waves of the wave-specialised 128x128 kernels (4 | 8)
+inline int x3w_big_threads() { return g_x3w_big_npw == 8 ? 768 : 512; }
+inline group_fn x3w_big_fn(bool a_kc, bool b_kc, bool kg) {   // layouts NT, NN, TN (+ k-row gather lists)
+  if (g_x3w_big_npw == 8)
+    return (a_kc && b_kc) ? gemm_x3w_kernel<true, true, false, 128, 128, 2, 8>
+           : a_kc         ? gemm_x3w_kernel<true, false, false, 128, 128, 2, 8>
+           : kg           ? gemm_x3w_kernel<false, false, true, 128, 128, 1, 8>
+                          : gemm_x3w_kernel<false, false, false, 128, 128, 2, 8>;
+  return (a_kc && b_kc) ? gemm_x3w_kernel<true, true, false, 128, 128, 2>
+         : a_kc         ? gemm_x3w_kernel<true, false, false, 128, 128, 2>
+         : kg           ? gemm_x3w_kernel<false, false, true, 128, 128, 1>
+                        : gemm_x3w_kernel<false, false, false, 128, 128, 2>;
+}
+inline int x3w_skinny_threads() { return g_x3w_npw == 8 && g_x3w_pf != 3 ? 768 : 512; }
 inline group_fn x3w_skinny_fn(bool b_kc) {
+  if (x3w_skinny_threads() == 768) return b_kc ? gemm_x3w_kernel<true, true, false, 64, 256, 2, 8> : gemm_x3w_kernel<true, false, false, 64, 256, 2, 8>;
   if (g_x3w_pf == 3) return b_kc ? gemm_x3w_kernel<true, true, false, 64, 256, 3> : gemm_x3w_kernel<true, false, false, 64, 256, 3>;
   return b_kc ? gemm_x3w_kernel<true, true, false, 64, 256, 2> : gemm_x3w_kernel<true, false, false, 64, 256, 2>;
 }
@@ -1618,7 +1679,7 @@ int launch(const ssc_gemm_desc* d, KArgs& k, int splits, hipStream_t st) {
     SSC_TRY(x3w_prepare());
     KGroup g1;
     group_of_one(g1, k, grid);
-    SSC_LAUNCH(x3w_skinny_fn(d->b_kc), dim3(g1.first[1]), dim3(512), (x3w_lds_bytes<64, 256>()), st, g1);
+    SSC_LAUNCH(x3w_skinny_fn(d->b_kc), dim3(g1.first[1]), dim3(x3w_skinny_threads()), (x3w_lds_bytes<64, 256>()), st, g1);
     if (rec) (void)hipEventRecord(rec->e1, st);
     SSC_CHECK_LAUNCH();
     return SSC_OK;
@@ -1639,14 +1700,11 @@ int launch(const ssc_gemm_desc* d, KArgs& k, int splits, hipStream_t st) {
     // 1520 tiles, +10 % tokens/s).  g_x3b: 1 = choose by grid size, 2 = always wave-specialised, 3 = always 4-wave.
     const long wgs = (long)grid.x * grid.y * grid.z;
     if (g_x3b == 2 || (g_x3b == 1 && wgs >= 768)) {  // wave-specialised form: 8 waves, 120 KB of dynamic LDS
-      group_fn fn = (d->a_kc && d->b_kc) ? gemm_x3w_kernel<true, true, false, 128, 128, 2>
-                    : d->a_kc            ? gemm_x3w_kernel<true, false, false, 128, 128, 2>
-                    : kg                 ? gemm_x3w_kernel<false, false, true, 128, 128, 1>
-                                         : gemm_x3w_kernel<false, false, false, 128, 128, 2>;
+      group_fn fn = x3w_big_fn(d->a_kc, d->b_kc, kg);
       SSC_TRY(x3w_prepare());
       KGroup g1;
       group_of_one(g1, k, grid);
-      SSC_LAUNCH(fn, dim3(g1.first[1]), dim3(512), (x3w_lds_bytes<128, 128>()), st, g1);
+      SSC_LAUNCH(fn, dim3(g1.first[1]), dim3(x3w_big_threads()), (x3w_lds_bytes<128, 128>()), st, g1);
     } else
     if (d->a_kc && d->b_kc) SSC_LAUNCH((gemm_x3b_kernel<true, true, false>), grid, dim3(256), 0, st, k);
     else if (d->a_kc) SSC_LAUNCH((gemm_x3b_kernel<true, false, false>), grid, dim3(256), 0, st, k);
@@ -1853,7 +1911,7 @@ int ssc_gemm_slabs_group(const ssc_gemm_desc* const* d, int n, float* const* reg
     rec->M = d[0]->M; rec->N = Nmax; rec->splits = nslab[0]; rec->K = Ksum;
     (void)hipEventRecord(rec->e0, st);
   }
-  SSC_LAUNCH(x3w_skinny_fn(d[0]->b_kc), dim3(g.first[n]), dim3(512), (x3w_lds_bytes<64, 256>()), st, g);
+  SSC_LAUNCH(x3w_skinny_fn(d[0]->b_kc), dim3(g.first[n]), dim3(x3w_skinny_threads()), (x3w_lds_bytes<64, 256>()), st, g);
   if (rec) (void)hipEventRecord(rec->e1, st);
   SSC_CHECK_LAUNCH();
   return SSC_OK;
@@ -1903,8 +1961,7 @@ int ssc_gemm_dw_group(const ssc_gemm_desc* const* d, int n, hipStream_t st) {
         rec->M = (int)(MN / d[i]->N); rec->N = d[i]->N; rec->splits = 1; rec->K = (int)Ksum;
         (void)hipEventRecord(rec->e0, st);
       }
-      if (kg0) SSC_LAUNCH((gemm_x3w_kernel<false, false, true, 128, 128, 1>), dim3(g.first[m]), dim3(512), (x3w_lds_bytes<128, 128>()), st, g);
-      else SSC_LAUNCH((gemm_x3w_kernel<false, false, false, 128, 128, 2>), dim3(g.first[m]), dim3(512), (x3w_lds_bytes<128, 128>()), st, g);
+      SSC_LAUNCH(x3w_big_fn(false, false, kg0), dim3(g.first[m]), dim3(x3w_big_threads()), (x3w_lds_bytes<128, 128>()), st, g);
       if (rec) (void)hipEventRecord(rec->e1, st);
       SSC_CHECK_LAUNCH();
       i += m;
@@ -2008,6 +2065,8 @@ const DebugKey g_debug_keys[] = {
     {"wide_min_n", &g_wide_min_n},   // exact-fp32 kernels: 64x128 tile for M <= 64 from this width on
     {"gemm_group", &g_gemm_group},   // grouped launches of independent minibatch products (0 | 1)   (SSC_GEMM_GROUP)
     {"dw_group", &g_dw_group},       // grouped launches of the weight-gradient products (0 | 1)   (SSC_DW_GROUP)
+    {"x3w_big_npw", &g_x3w_big_npw}, // wave-specialised 128x128 kernels: producer waves (4 | 8)   (SSC_X3W_BIG_NPW)
+    {"x3w_npw", &g_x3w_npw},         // 64x256 kernels: producer waves per workgroup (4 | 8)   (SSC_X3W_NPW)
     {"x3w_pf", &g_x3w_pf},           // 64x256 kernels: k-steps in flight in the producers' registers (2 | 3)   (SSC_X3W_PF)
     {"tile_gm", &g_tile_gm},         // tile rows per group of the tile order (8; 0 = row-major)   (SSC_TILE_GM)
 };
@@ -2027,6 +2086,15 @@ extern "C" int ssc_debug_get(const char* key, int* value) {
 }
 
 // diagnostic: resident workgroups per CU the runtime reports for the GEMM kernels (tools/, not used by the product path)
+#ifdef SSC_X3W_STAMP
+// diagnostics build only: device buffer of 256 u64 and the workgroup (flat blockIdx.x of the grouped launch) that fills it
+extern "C" int ssc_debug_stamp_setup(void* buf, int wg) {
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_ptr), &buf, sizeof(buf)) != hipSuccess) return SSC_EHIP;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_wg), &wg, sizeof(wg)) != hipSuccess) return SSC_EHIP;
+  return SSC_OK;
+}
+#endif
+
 extern "C" int ssc_debug_gemm_occupancy(int* out4) {
   int n = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_x3_kernel<2, 1, 2>, 256, 0) != hipSuccess) return SSC_EHIP;
