@@ -1140,127 +1140,143 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
     f32x4 ra[PF][NA], rb[PF][NB];
     unsigned oka[PF], okb[PF];
     bool fullk[PF];   // uniform: the set's k-step lies wholly inside its K segment (no chunk needs zeroing)
-    const float* pa[NA];
-    const float* pb[NB];
-    int ia[NA], ib[NB];  // KG: gathered k-row numbers of the NEXT step
+    // Addresses: a UNIFORM base per operand and k-step (scalar registers: segment base + k0, recomputed from the cursor by
+    // scalar arithmetic) plus a 32-bit byte offset per chunk that only changes with the segment (`global_load ... v_off,
+    // s[base]`): the per-k-step address work of a thread is one select per chunk instead of two 64-bit vector adds (the stamps
+    // of tools/x3w_stamp.py put 0.3-0.5 us per k-step into pointer arithmetic + issue).  Operand spans < 4 GB: checked on
+    // the host (x3w_span_ok).
+    unsigned oa[NA], ob[NB];  // offset of the chunk at a k-step inside the segment
+    unsigned za[NA], zb[NB];  // offset used when the chunk lies past the end of K (same row / column, first k of the step: in range)
+    int ia[NA], ib[NB];       // KG: gathered k-row numbers of the NEXT step
     Cursor cur;
     int s_ld = s_lo;
     // chunk idx: k-contiguous operand -> (row idx>>3, k 4*(idx&7)); m/n-contiguous -> (k idx/Q, column 4*(idx%Q))
-    auto base_ptrs = [&]() {
+    auto base_ptrs = [&]() __attribute__((always_inline)) {
+      const unsigned lda4 = (unsigned)cur.lda * 4u, ldb4 = (unsigned)cur.ldb * 4u;
 #pragma unroll
       for (int u = 0; u < NA; ++u) {
         const int idx = tid + NPT * u;
         if constexpr (A_KC) {
           int r = min(m0 + (idx >> 3), Meff - 1);
           if constexpr (RL) { if (a.arows) r = a.arows[r]; }
-          pa[u] = cur.A + (size_t)r * cur.lda + cur.k0 + 4 * (idx & 7);
+          za[u] = (unsigned)r * lda4;
+          oa[u] = za[u] + 16u * (idx & 7);
         } else {
-          int kr = cur.k0 + idx / QA;
-          if constexpr (KG) { if (a.karows) kr = a.karows[min(kr, cur.K - 1)]; }
-          pa[u] = cur.A + (size_t)kr * cur.lda + min(m0 + 4 * (idx % QA), Meff - 4);
+          za[u] = 4u * (unsigned)min(m0 + 4 * (idx % QA), Meff - 4);
+          if constexpr (KG) {   // oa = the gathered row NUMBER of the current step (the offset is formed at issue time)
+            int kr = cur.k0 + idx / QA;
+            kr = a.karows[min(kr, cur.K - 1)];   // KG kernels are launched with BOTH lists (launch())
+            oa[u] = (unsigned)kr;
+          } else {
+            oa[u] = (unsigned)(idx / QA) * lda4 + za[u];
+          }
         }
       }
 #pragma unroll
       for (int u = 0; u < NB; ++u) {
         const int idx = tid + NPT * u;
         if constexpr (B_KC) {
-          pb[u] = cur.B + (size_t)min(n0 + (idx >> 3), a.N - 1) * cur.ldb + cur.k0 + 4 * (idx & 7);
+          zb[u] = (unsigned)min(n0 + (idx >> 3), a.N - 1) * ldb4;
+          ob[u] = zb[u] + 16u * (idx & 7);
         } else {
-          int kr = cur.k0 + idx / QB;
-          if constexpr (KG) { if (a.kbrows) kr = a.kbrows[min(kr, cur.K - 1)]; }
-          pb[u] = cur.B + (size_t)kr * cur.ldb + min(n0 + 4 * (idx % QB), a.N - 4);
+          zb[u] = 4u * (unsigned)min(n0 + 4 * (idx % QB), a.N - 4);
+          if constexpr (KG) {
+            int kr = cur.k0 + idx / QB;
+            kr = a.kbrows[min(kr, cur.K - 1)];
+            ob[u] = (unsigned)kr;
+          } else {
+            ob[u] = (unsigned)(idx / QB) * ldb4 + zb[u];
+          }
         }
       }
     };
-    auto prefetch_rows = [&]() {  // KG: row numbers of the k-step after the cursor's (clamped)
+    auto prefetch_rows = [&]() __attribute__((always_inline)) {  // KG: row numbers of the k-step after the cursor's (clamped)
       if constexpr (KG) {
 #pragma unroll
         for (int u = 0; u < NA; ++u) {
           const int kr = min(cur.k0 + BK + (tid + NPT * u) / QA, cur.K - 1);
-          ia[u] = a.karows ? a.karows[kr] : kr;
+          ia[u] = a.karows[kr];
         }
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
           const int kr = min(cur.k0 + BK + (tid + NPT * u) / QB, cur.K - 1);
-          ib[u] = a.kbrows ? a.kbrows[kr] : kr;
+          ib[u] = a.kbrows[kr];
         }
       }
     };
-    auto step_ptrs = [&](int how) {
-      if (how == 2) {
-        base_ptrs();
-      } else if (how == 1) {
+    auto step_ptrs = [&](int how) __attribute__((always_inline)) {
+      if constexpr (KG) {
+        // gathered k-rows (single segment by construction: how is 0 or 1): the row numbers follow the lists, the base stays at
+        // the segment start.  No base_ptrs() here: a second site that stores list entries into the same arrays makes hipcc
+        // sink the two stores into one store through a pointer phi, which keeps the arrays in scratch memory (a scratch reload
+        // is a vector-memory operation and its wait drains the staged loads).
+        if (how != 0) {
 #pragma unroll
-        for (int u = 0; u < NA; ++u) {
-          const int idx = tid + NPT * u;
-          if constexpr (A_KC) pa[u] += BK;
-          else if constexpr (KG) pa[u] = cur.A + (size_t)ia[u] * cur.lda + min(m0 + 4 * (idx % QA), Meff - 4);
-          else pa[u] += (size_t)BK * cur.lda;
-        }
+          for (int u = 0; u < NA; ++u) oa[u] = (unsigned)ia[u];
 #pragma unroll
-        for (int u = 0; u < NB; ++u) {
-          const int idx = tid + NPT * u;
-          if constexpr (B_KC) pb[u] += BK;
-          else if constexpr (KG) pb[u] = cur.B + (size_t)ib[u] * cur.ldb + min(n0 + 4 * (idx % QB), a.N - 4);
-          else pb[u] += (size_t)BK * cur.ldb;
+          for (int u = 0; u < NB; ++u) ob[u] = (unsigned)ib[u];
+          prefetch_rows();
         }
-        prefetch_rows();
+      } else {
+        if (how == 2) base_ptrs();   // offsets only change with the segment; the bases follow the cursor
       }
     };
-    // Branch-free (no branch may surround a staged load: see Stage::load_ptrs): every k-step takes the clamped form - a step
-    // inside its segment clamps nothing - and remembers which chunks lie past the end of K.
-    auto issue_loads = [&](f32x4 (&xa)[NA], f32x4 (&xb)[NB], unsigned& ma, unsigned& mb, bool& full) {
+    // Branch-free (no branch may surround a staged load: see Stage::load_ptrs): every k-step takes the same form - a chunk
+    // past the end of K reads the first k of the step instead (always in range) and is zeroed at LDS-store time.
+    auto issue_loads = [&](f32x4 (&xa)[NA], f32x4 (&xb)[NB], unsigned& ma, unsigned& mb, bool& full) __attribute__((always_inline)) {
       ma = mb = 0;
       full = cur.k0 + BK <= cur.K;
-      const float* qa[NA];
-      const float* qb[NB];
-      // k-contiguous operands: chunk u of this thread starts at k0 + 4*(tid & 7) for every u (idx = tid + 256 u)
-      const int kc = cur.k0 + 4 * (tid & 7);
-      const int kc_adj = min(kc, cur.K - 4) - kc;
-      const unsigned kc_ok = kc < cur.K ? 1u : 0u;
+      // uniform bases of this k-step
+      const float* sa = cur.A + (A_KC ? (size_t)cur.k0 : (KG ? (size_t)0 : (size_t)cur.k0 * cur.lda));
+      const float* sb = cur.B + (B_KC ? (size_t)cur.k0 : (KG ? (size_t)0 : (size_t)cur.k0 * cur.ldb));
+      unsigned ea[NA], eb[NB];
+      // k-contiguous operands: chunk u of this thread starts at k0 + 4*(tid & 7) for every u (idx = tid + NPT u)
+      const bool kc_in = cur.k0 + 4 * (tid & 7) < cur.K;
 #pragma unroll
       for (int u = 0; u < NA; ++u) {
         const int idx = tid + NPT * u;
         if constexpr (A_KC) {
-          qa[u] = pa[u] + kc_adj;
-          ma |= kc_ok << u;
+          ea[u] = kc_in ? oa[u] : za[u];
+          ma |= (kc_in ? 1u : 0u) << u;
         } else {
-          const int gk = cur.k0 + idx / QA;
-          qa[u] = KG ? pa[u] : pa[u] + (ptrdiff_t)(min(gk, cur.K - 1) - gk) * cur.lda;
-          ma |= (gk < cur.K ? 1u : 0u) << u;
+          const bool in = cur.k0 + idx / QA < cur.K;
+          if constexpr (KG) ea[u] = oa[u] * ((unsigned)cur.lda * 4u) + za[u];
+          else ea[u] = in ? oa[u] : za[u];
+          ma |= (in ? 1u : 0u) << u;
         }
       }
 #pragma unroll
       for (int u = 0; u < NB; ++u) {
         const int idx = tid + NPT * u;
         if constexpr (B_KC) {
-          qb[u] = pb[u] + kc_adj;
-          mb |= kc_ok << u;
+          eb[u] = kc_in ? ob[u] : zb[u];
+          mb |= (kc_in ? 1u : 0u) << u;
         } else {
-          const int gk = cur.k0 + idx / QB;
-          qb[u] = KG ? pb[u] : pb[u] + (ptrdiff_t)(min(gk, cur.K - 1) - gk) * cur.ldb;
-          mb |= (gk < cur.K ? 1u : 0u) << u;
+          const bool in = cur.k0 + idx / QB < cur.K;
+          if constexpr (KG) eb[u] = ob[u] * ((unsigned)cur.ldb * 4u) + zb[u];
+          else eb[u] = in ? ob[u] : zb[u];
+          mb |= (in ? 1u : 0u) << u;
         }
       }
 #pragma unroll
-      for (int u = 0; u < NA; ++u) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(xa[u]) : "v"(qa[u]) : "memory");
+      for (int u = 0; u < NA; ++u) asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(xa[u]) : "v"(ea[u]), "s"(sa) : "memory");
 #pragma unroll
-      for (int u = 0; u < NB; ++u) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(xb[u]) : "v"(qb[u]) : "memory");
+      for (int u = 0; u < NB; ++u) asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(xb[u]) : "v"(eb[u]), "s"(sb) : "memory");
     };
     // wait until at most YOUNGER of the hand-issued loads are outstanding; "+v" pins every use of this stage's registers
     // behind the wait (cdna_hip_programming.md 5.7)
-    auto pin = [&](f32x4 (&xa)[NA], f32x4 (&xb)[NB]) {
+    auto pin = [&](f32x4 (&xa)[NA], f32x4 (&xb)[NB]) __attribute__((always_inline)) {
 #pragma unroll
       for (int u = 0; u < NA; ++u) asm volatile("" : "+v"(xa[u])::"memory");
 #pragma unroll
       for (int u = 0; u < NB; ++u) asm volatile("" : "+v"(xb[u])::"memory");
     };
-    auto advance = [&]() {
+    auto advance = [&]() __attribute__((always_inline)) {
       const int how = cur.advance(a, s_ld >= s_last);
       s_ld = min(s_ld + 1, s_last);
       step_ptrs(how);
     };
-    auto put_chunk = [&](unsigned char* p, int plane, f32x4 v, bool ok) {
+    auto put_chunk = [&](unsigned char* p, int plane, f32x4 v, bool ok) __attribute__((always_inline)) {
       if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
       u32x2 hi, mid, lo;
       split4(v, hi, mid, lo);
@@ -1268,7 +1284,7 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
       *reinterpret_cast<u32x2*>(p + plane) = mid;
       *reinterpret_cast<u32x2*>(p + 2 * plane) = lo;
     };
-    auto put_planes_impl = [&](unsigned char* st, const f32x4 (&xa)[NA], const f32x4 (&xb)[NB], unsigned ma, unsigned mb, const bool all) {
+    auto put_planes_impl = [&](unsigned char* st, const f32x4 (&xa)[NA], const f32x4 (&xb)[NB], unsigned ma, unsigned mb, const bool all) __attribute__((always_inline)) {
 #pragma unroll
       for (int u = 0; u < NA; ++u) {
         const int idx = tid + NPT * u;
@@ -1281,7 +1297,7 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
       }
     };
     // a k-step inside its segment (uniform test: a scalar branch around VALU + LDS work only) needs no per-chunk select
-    auto put_planes = [&](unsigned char* st, const f32x4 (&xa)[NA], const f32x4 (&xb)[NB], unsigned ma, unsigned mb, bool full) {
+    auto put_planes = [&](unsigned char* st, const f32x4 (&xa)[NA], const f32x4 (&xb)[NB], unsigned ma, unsigned mb, bool full) __attribute__((always_inline)) {
       if (full) put_planes_impl(st, xa, xb, ma, mb, true);
       else put_planes_impl(st, xa, xb, ma, mb, false);
     };
@@ -1349,7 +1365,7 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
       for (int i = 0; i < 16; ++i) acc[mi][ni][i] = 0.f;
 
   // fragment = 8 consecutive k (16*kk + 8*half ...) of tile row/column rc0 + (lane & 31) of one plane
-  auto frag = [&](const unsigned char* plane, bool kc, int mc_row_b, int rc0, int kk) -> bf16x8 {
+  auto frag = [&](const unsigned char* plane, bool kc, int mc_row_b, int rc0, int kk) __attribute__((always_inline)) -> bf16x8 {
     if (kc) {
       return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(plane + (rc0 + l31) * PL_ROW_B + kk * 32 + half * 16));
     } else {
@@ -1367,13 +1383,13 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
 #define SSC_X3W_MFMA(FA, FB, PA, PB)                                                                                 \
   _Pragma("unroll") for (int mi = 0; mi < 2; ++mi) _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = \
       __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[mi][PA], FB[ni][PB], acc[mi][ni], 0, 0, 0);
-  auto compute = [&](const unsigned char* st) {
+  auto compute = [&](const unsigned char* st) __attribute__((always_inline)) {
     bf16x8 fa[2][2][3], fb[2][2][3];  // [kk][tile][plane]
-    auto rda = [&](int kk, int pl) {
+    auto rda = [&](int kk, int pl) __attribute__((always_inline)) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) fa[kk][t][pl] = frag(st + pl * PLA, A_KC, MCA, wm * 64 + t * 32, kk);
     };
-    auto rdb = [&](int kk, int pl) {
+    auto rdb = [&](int kk, int pl) __attribute__((always_inline)) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) fb[kk][t][pl] = frag(st + 3 * PLA + pl * PLB, B_KC, MCB, wn * 64 + t * 32, kk);
     };
@@ -1655,6 +1671,23 @@ inline bool x3w_skinny(const ssc_gemm_desc* d, bool vec) {   // 2 = only where t
   return vec && d->a_kc && x3w_skinny_shape(d->M, d->N) && (g_x3w_skinny == 1 || !d->b_kc);
 }
 
+// the wave-specialised kernels address an operand as (uniform 64-bit base) + (32-bit byte offset per lane)
+inline bool x3w_span_ok(const ssc_gemm_desc* d) {
+  const size_t lim = (size_t)1 << 30;   // floats
+  for (int i = 0; i < d->nseg; ++i) {
+    const size_t K = (size_t)d->seg[i].K;
+    if (K == 0) continue;
+    const size_t sa = d->a_kc ? (size_t)(d->M - 1) * d->seg[i].lda + K : (K - 1) * d->seg[i].lda + d->M;
+    const size_t sb = d->b_kc ? (size_t)(d->N - 1) * d->seg[i].ldb + K : (K - 1) * d->seg[i].ldb + d->N;
+    if (sa >= lim || sb >= lim) return false;
+  }
+  return true;
+}
+inline bool x3w_group_member(const ssc_gemm_desc* d, bool vec) {
+  return vec && d->a_kc && g_x3w_skinny && gemm_mode() == 1 && d->M <= 64 && d->N >= 64 && (g_x3w_skinny == 1 || !d->b_kc) &&
+         x3w_span_ok(d);
+}
+
 int launch(const ssc_gemm_desc* d, KArgs& k, int splits, hipStream_t st) {
   k.steps_per_split = ssc_cdiv(k.steps_total, splits);
   bool vec = true;  // every segment of both operands must allow 16 B/lane loads, else the 4 B/lane kernel runs
@@ -1666,7 +1699,7 @@ int launch(const ssc_gemm_desc* d, KArgs& k, int splits, hipStream_t st) {
     if ((k.kcount || k.karows || k.kbrows) && (k.nseg != 1 || d->a_kc || d->b_kc)) return SSC_EINVAL;
     if ((k.mcount || k.arows || k.crows) && !d->a_kc) return SSC_EINVAL;
   }
-  if (x3w_skinny(d, vec) && !compact) {  // M = minibatch against a wide weight matrix: 64 x 256 wave-specialised tile
+  if (x3w_skinny(d, vec) && !compact && x3w_span_ok(d)) {  // M = minibatch against a wide weight matrix: 64 x 256 wave-specialised tile
     dim3 grid(ssc_cdiv(d->N, 256), ssc_cdiv(d->M, 64), splits);
     ProfRec* rec = nullptr;
     if (g_prof_on && g_prof && g_prof_n < PROF_MAX) {
@@ -1695,11 +1728,12 @@ int launch(const ssc_gemm_desc* d, KArgs& k, int splits, hipStream_t st) {
       (void)hipEventRecord(rec->e0, st);
     }
     const bool kg = k.karows || k.kbrows;
+    const bool kg_both = k.karows && k.kbrows;   // the wave-specialised gather kernel reads both lists unconditionally
     // Form: the 4-wave kernel keeps two workgroups per CU, which evens out small grids (380 tiles on 256 CUs); the
     // wave-specialised one runs ~13 % fewer cycles per k-step and wins once the grid is several rounds deep (decode:
     // 1520 tiles, +10 % tokens/s).  g_x3b: 1 = choose by grid size, 2 = always wave-specialised, 3 = always 4-wave.
     const long wgs = (long)grid.x * grid.y * grid.z;
-    if (g_x3b == 2 || (g_x3b == 1 && wgs >= 768)) {  // wave-specialised form: 8 waves, 120 KB of dynamic LDS
+    if ((g_x3b == 2 || (g_x3b == 1 && wgs >= 768)) && x3w_span_ok(d) && (!kg || kg_both)) {  // wave-specialised form: 12 waves, 120 KB of dynamic LDS
       group_fn fn = x3w_big_fn(d->a_kc, d->b_kc, kg);
       SSC_TRY(x3w_prepare());
       KGroup g1;
@@ -1761,6 +1795,17 @@ int launch(const ssc_gemm_desc* d, KArgs& k, int splits, hipStream_t st) {
 // Split-K choice by a small cost model fitted to rocprof timings (profiles/r01_c_gemm_shapes.csv, tools/gemm_probe.py):
 // time ~ (workgroups on the busiest CU) x (k-steps per workgroup + fixed per-workgroup cost) / efficiency(occupancy)
 //        + per-slab cost.  One wave per SIMD leaves the MFMA pipe ~45 % busy, three or four ~85-90 %.
+// C (+)= sum of `nslab` partial slabs (M x N, ld N, `stride` floats apart), fixed order
+int ssc_reduce_slabs(const float* slabs, int nslab, size_t stride, int M, int N, float* C, int ldc, const float* bias,
+                     int accumulate, hipStream_t st) {
+  if (!slabs || nslab < 1 || M <= 0 || N <= 0 || !C) return SSC_EINVAL;
+  const size_t total = (size_t)M * N;
+  SSC_LAUNCH(reduce_slabs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, slabs, nslab, stride, M, N, C, ldc, bias,
+             accumulate, (const int*)nullptr, (const int*)nullptr);
+  SSC_CHECK_LAUNCH();
+  return SSC_OK;
+}
+
 extern "C" int ssc_gemm_auto_splits(int M, int N, int ksteps) {
   if (x3w_skinny_shape(M, N)) {
     // one workgroup per CU: split K until the grid covers the chip once, at least 4 k-steps per workgroup
@@ -1852,7 +1897,7 @@ int ssc_gemm_slabs_group(const ssc_gemm_desc* const* d, int n, float* const* reg
   if (!d || n < 1 || n > SSC_GROUP_MAX || !regions || !caps || !nslab) return SSC_EINVAL;
   const bool group_on = g_gemm_group != 0;
   KGroup g;
-  bool ok = n >= 2 && group_on;
+  bool ok = n >= 2 && group_on, any_wide = false;
   long work = 0;
   for (int i = 0; i < n && ok; ++i) {
     SSC_TRY(build_args(d[i], g.a[i]));
@@ -1860,9 +1905,13 @@ int ssc_gemm_slabs_group(const ssc_gemm_desc* const* d, int n, float* const* reg
     bool vec = true;
     for (int s = 0; s < k.nseg; ++s) vec = vec && k.seg[s].avec && k.seg[s].bvec;
     const bool compact = k.mcount || k.arows || k.crows || k.kcount || k.karows || k.kbrows;
-    ok = !compact && x3w_skinny(d[i], vec) && d[i]->b_kc == d[0]->b_kc && regions[i];
+    // a member needs the minibatch shape and 16 B/lane operands; a NARROW member (N < the 256-column kernels' minimum width,
+    // e.g. the 128-column dz product) may ride along in a group that has at least one wide member
+    ok = !compact && x3w_group_member(d[i], vec) && d[i]->b_kc == d[0]->b_kc && regions[i];
+    any_wide = any_wide || x3w_skinny(d[i], vec);
     work += (long)ssc_cdiv(d[i]->N, 256) * k.steps_total;
   }
+  ok = ok && any_wide;
   if (!ok) {
     for (int i = 0; i < n; ++i) SSC_TRY(ssc_gemm_slabs_auto(d[i], regions[i], caps[i], &nslab[i], st));
     return SSC_OK;
@@ -1938,7 +1987,8 @@ int ssc_gemm_dw_group(const ssc_gemm_desc* const* d, int n, hipStream_t st) {
       const bool vec = k.nseg == 1 && k.seg[0].avec && k.seg[0].bvec;
       const bool kg = k.karows || k.kbrows;
       const bool ok = group_on && gemm_mode() == 1 && vec && !dj->a_kc && !dj->b_kc && dj->C && dj->ldc >= dj->N && !k.mcount &&
-                      !k.arows && !k.crows && (kg ? (k.kcount && k.karows && k.kbrows) : !k.kcount) && (m == 0 || kg == kg0);
+                      !k.arows && !k.crows && (kg ? (k.kcount && k.karows && k.kbrows) : !k.kcount) && (m == 0 || kg == kg0) &&
+                      x3w_span_ok(dj);
       if (!ok) break;
       kg0 = kg;
       k.steps_per_split = k.steps_total;

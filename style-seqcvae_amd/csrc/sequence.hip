@@ -32,7 +32,7 @@ struct Layout {
   size_t tok, w, nvalid, sent_all, wcol_e, wcol_d, mask, avg, pv, emb, ga_static, ga_avg;
   size_t h1, c1, he, ce, hd, cd, gates_a, gates_e, gates_d, q, attn_logits, alpha, att, mu, lv, z, mulv;
   size_t slabs, slab_floats, logits, lse, proj;
-  size_t sl_q, sl_mulv, sl_gh1, sl_ghd, sl_ghe, sl_dqw, sl_dhe, sl_dz, small_floats, wsum_att, wsum_dec, wz;
+  size_t sl_q, sl_mulv, sl_gh1, sl_ghd, sl_ghd2, sl_ghe, sl_dqw, sl_dhe, sl_dz, small_floats, wsum_att, wsum_dec, wz;
   // backward
   size_t dhdv, dga, dge, dgd, dga_sum, g_h1, g_c1, g_he, g_ce, g_cd, dz, dmulv, dx, dalpha, dq, dpv, dwa, demb, dproj;
 
@@ -85,6 +85,7 @@ Layout make_layout(const ssc_model_cfg* c, int B, int R, int L) {
     l.small_floats = (size_t)40 * B * w;
     l.sl_q = l.take(l.small_floats); l.sl_mulv = l.take(l.small_floats);
     l.sl_gh1 = l.take(l.small_floats); l.sl_ghd = l.take(l.small_floats); l.sl_ghe = l.take(l.small_floats);
+    l.sl_ghd2 = l.take(l.small_floats);
     l.sl_dqw = l.take(l.small_floats); l.sl_dhe = l.take(l.small_floats); l.sl_dz = l.take(l.small_floats);
   }
   l.wsum_att = l.take((size_t)l.H4 * l.Hp);   // W_ih^att[:, h1-block] + W_hh^att  (both multiply h1')
@@ -587,8 +588,13 @@ static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const s
   SSC_TRY(ssc_fill(W + l.dga_sum, (size_t)B * H4, 0.f, st));
   // wsum_att / wz were prepared by ssc_train_fwd of the same minibatch (parameters are unchanged until the update)
   float* dx = W + l.dx;            // [datt (F) | dh1 (H) | dhd' (H)], ld XW
-  int n_gh1 = 0, n_ghd = 0, n_ghe = 0;  // slab counts carried from step t+1 (none at t = T-1)
+  int n_gh1 = 0, n_ghd = 0, n_ghd2 = 0, n_ghe = 0;  // slab counts carried from step t+1 (none at t = T-1)
   const size_t sBH = (size_t)B * H;
+  const size_t sBX = (size_t)B * (F + 2 * H);
+  // Launch order of one step (every product streams its weight block once; a product is issued as soon as its dG exists and
+  // shares a launch with the latency-bound small product of the dependency chain that sits at the same place):
+  //   dec cell -> {dz, dGd W_ih^dec[:, :F+2H], dGd W_hh^dec} -> latent -> dhe -> enc cell -> {dGe W_ih^enc[:, :F+2H]} -> sum
+  //   -> attention -> {dq Wq, dGe W_hh^enc} -> att cell -> {dGa (W_ih^att[h1] + W_hh^att), dGa W_ih^att[hd]}
 
   if (g_loop.on) { (void)hipEventRecord(g_loop.e[2], st); }
   for (int t = T - 1; t >= 0; --t) {
@@ -597,14 +603,16 @@ static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const s
     float* dga = W + l.dga + (size_t)t * B * H4;
     float* dmulv = W + l.dmulv + (size_t)t * B * 2 * Z;
     float* dq = W + l.dq + (size_t)t * B * l.Ap;
-    int ns = 0;
-    // 1. decoder LSTM: dh = dx[hd' block] (step t+1's dGd W_ih^dec[hd] + dGe W_ih^enc[hd]) + g_hd' slabs + vocabulary path
+    int ns = 0, n_dxd = 0, n_dxe = 0;
+    // 1. decoder LSTM: dh = dx[hd' block] (step t+1's dGd W_ih^dec[hd] + dGe W_ih^enc[hd]) + g_hd' slabs (step t+1's
+    //    dGa W_ih^att[hd] and dGd W_hh^dec) + vocabulary path
     {
       ssc_lstm_bwd_desc d{};
       d.B = B; d.H = H;
       d.dh = dx + F + H; d.ld_dh = XW;
       d.dh2 = W + l.dhdv + (size_t)t * B * l.Hp; d.ld_dh2 = l.Hp;
       d.slabsA = W + l.sl_ghd; d.nA = n_ghd; d.strideA = sBH;
+      d.slabsB = W + l.sl_ghd2; d.nB = n_ghd2; d.strideB = sBH;
       d.dc_in = W + l.g_cd; d.ld_dcin = l.Hp;
       d.gates = W + l.gates_d + (size_t)t * B * H4;
       d.c_prev = W + l.cd + t * sH; d.ld_cprev = l.Hp;
@@ -612,8 +620,20 @@ static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const s
       d.dG = dgd; d.dc_prev = W + l.g_cd; d.ld_dcprev = l.Hp;
       SSC_TRY(ssc_lstm_bwd(&d, st));
     }
-    // 2-3. dz = dGd W_ih^dec[:, z-block] (aligned copy), summed inside the latent backward
-    SSC_TRY(gemm_to_slabs(c, W + l.sl_dz, l.small_floats, true, false, {{dgd, H4, W + l.wz, l.Zp, H4}}, B, Z, &ns));
+    // 2. everything dGd feeds, in one launch: dz = dGd W_ih^dec[:, z-block] (aligned copy; summed inside the latent backward),
+    //    the decoder half of [datt | dh1 | dhd'] (slabs; the encoder half follows in 6), and dGd W_hh^dec for step t-1
+    {
+      ssc_gemm_desc d3[3];
+      fill_desc(d3[0], true, false, {{dgd, H4, W + l.wz, l.Zp, H4}}, B, Z);
+      fill_desc(d3[1], true, false, {{dgd, H4, p->dec_w_ih, p->ld_dec_w_ih, H4}}, B, F + 2 * H);
+      fill_desc(d3[2], true, false, {{dgd, H4, p->dec_w_hh, p->ld_dec_w_hh, H4}}, B, H);
+      const ssc_gemm_desc* dp[3] = {&d3[0], &d3[1], &d3[2]};
+      float* regions[3] = {W + l.sl_dz, c.slabs, W + l.sl_ghd2};
+      const size_t caps[3] = {l.small_floats, c.slab_floats / 2, l.small_floats};
+      int ns3[3] = {0, 0, 0};
+      SSC_TRY(ssc_gemm_slabs_group(dp, t > 0 ? 3 : 2, regions, caps, ns3, st));
+      ns = ns3[0]; n_dxd = ns3[1]; n_ghd2 = ns3[2];
+    }
     {
       ssc_latent_bwd_desc d{};
       d.B = B; d.Z = Z;
@@ -642,14 +662,26 @@ static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const s
       d.dG = dge; d.dc_prev = W + l.g_ce; d.ld_dcprev = l.Hp;
       SSC_TRY(ssc_lstm_bwd(&d, st));
     }
-    // 6. [datt | dh1 | dhd'] = dGd W_ih^dec[:, :F+2H] + dGe W_ih^enc[:, :F+2H]
-    SSC_TRY(gemm(c, true, false, {{dgd, H4, p->dec_w_ih, p->ld_dec_w_ih, H4}, {dge, H4, p->enc_w_ih, p->ld_enc_w_ih, H4}}, B,
-                 F + 2 * H, dx, XW));
+    // 6. [datt | dh1 | dhd'] = dGd W_ih^dec[:, :F+2H] (slabs of launch 2) + dGe W_ih^enc[:, :F+2H] (appended here), one sum
+    SSC_TRY(gemm_to_slabs(c, c.slabs + (size_t)n_dxd * sBX, c.slab_floats - (size_t)n_dxd * sBX, true, false,
+                          {{dge, H4, p->enc_w_ih, p->ld_enc_w_ih, H4}}, B, F + 2 * H, &n_dxe));
+    SSC_TRY(ssc_reduce_slabs(c.slabs, n_dxd + n_dxe, sBX, B, F + 2 * H, dx, XW, nullptr, 0, st));
     // 7. attention backward
     SSC_TRY(ssc_attn_bwd(dx, XW, W + l.q + (size_t)t * B * l.Ap, l.Ap, W + l.pv, p->wa, W + l.alpha + (size_t)t * B * R,
                          bt->feats, B, R, A, F, dq, l.Ap, W + l.dpv, W + l.dwa, W + l.dalpha, st));
-    // 8-9. attention LSTM: dh1 = dx[h1 block] + g_h1' slabs + (dq Wq) slabs
-    SSC_TRY(gemm_to_slabs(c, W + l.sl_dqw, l.small_floats, true, false, {{dq, l.Ap, p->wq, p->ld_wq, A}}, B, H, &ns));
+    // 8. dq Wq (summed inside the attention LSTM backward) together with dGe W_hh^enc for step t-1
+    {
+      ssc_gemm_desc d2[2];
+      fill_desc(d2[0], true, false, {{dq, l.Ap, p->wq, p->ld_wq, A}}, B, H);
+      fill_desc(d2[1], true, false, {{dge, H4, p->enc_w_hh, p->ld_enc_w_hh, H4}}, B, H);
+      const ssc_gemm_desc* dp[2] = {&d2[0], &d2[1]};
+      float* regions[2] = {W + l.sl_dqw, W + l.sl_ghe};
+      const size_t caps[2] = {l.small_floats, l.small_floats};
+      int ns2[2] = {0, 0};
+      SSC_TRY(ssc_gemm_slabs_group(dp, t > 0 ? 2 : 1, regions, caps, ns2, st));
+      ns = ns2[0]; n_ghe = ns2[1];
+    }
+    // 9. attention LSTM: dh1 = dx[h1 block] + g_h1' slabs + (dq Wq) slabs
     {
       ssc_lstm_bwd_desc d{};
       d.B = B; d.H = H;
@@ -664,20 +696,18 @@ static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const s
       d.dgsum = W + l.dga_sum;
       SSC_TRY(ssc_lstm_bwd(&d, st));
     }
-    // 10. gradients carried to step t-1 (left as slabs for their consumers)
+    // 10. what dGa carries to step t-1 (left as slabs for their consumers)
     if (t > 0) {
       const float* wr = p->att_w_ih + E + F;
-      // three independent products: one grouped launch (each alone covers 150 of the 256 CUs and pays its own ramp)
-      ssc_gemm_desc d3[3];
-      fill_desc(d3[0], true, false, {{dga, H4, W + l.wsum_att, l.Hp, H4}}, B, H);
-      fill_desc(d3[1], true, false, {{dga, H4, wr + H, p->ld_att_w_ih, H4}, {dgd, H4, p->dec_w_hh, p->ld_dec_w_hh, H4}}, B, H);
-      fill_desc(d3[2], true, false, {{dge, H4, p->enc_w_hh, p->ld_enc_w_hh, H4}}, B, H);
-      const ssc_gemm_desc* dp[3] = {&d3[0], &d3[1], &d3[2]};
-      float* regions[3] = {W + l.sl_gh1, W + l.sl_ghd, W + l.sl_ghe};
-      const size_t caps[3] = {l.small_floats, l.small_floats, l.small_floats};
-      int ns3[3] = {0, 0, 0};
-      SSC_TRY(ssc_gemm_slabs_group(dp, 3, regions, caps, ns3, st));
-      n_gh1 = ns3[0]; n_ghd = ns3[1]; n_ghe = ns3[2];
+      ssc_gemm_desc d2[2];
+      fill_desc(d2[0], true, false, {{dga, H4, W + l.wsum_att, l.Hp, H4}}, B, H);
+      fill_desc(d2[1], true, false, {{dga, H4, wr + H, p->ld_att_w_ih, H4}}, B, H);
+      const ssc_gemm_desc* dp[2] = {&d2[0], &d2[1]};
+      float* regions[2] = {W + l.sl_gh1, W + l.sl_ghd};
+      const size_t caps[2] = {l.small_floats, l.small_floats};
+      int ns2[2] = {0, 0};
+      SSC_TRY(ssc_gemm_slabs_group(dp, 2, regions, caps, ns2, st));
+      n_gh1 = ns2[0]; n_ghd = ns2[1];
     }
   }
 

@@ -63,3 +63,6 @@ int ssc_gemm_slabs_group(const ssc_gemm_desc* const* d, int n, float* const* reg
                          hipStream_t st);
 // the independent weight-gradient products of one backward phase (C_i = A_i^T B_i, direct outputs) as grouped launches
 int ssc_gemm_dw_group(const ssc_gemm_desc* const* d, int n, hipStream_t st);
+// C (+)= sum of split-K slabs (M x N, ld N) in index order (+ bias)
+int ssc_reduce_slabs(const float* slabs, int nslab, size_t stride, int M, int N, float* C, int ldc, const float* bias,
+                     int accumulate, hipStream_t st);

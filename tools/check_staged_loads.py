@@ -233,6 +233,23 @@ def check(path, pat, strict=False):
     return sorted(bad), stats
 
 
+def scratch_users(path, pat):
+    """Kernels (matching pat) with a private segment: a stack object or a spill.  In a kernel with hand-counted vmcnt waits a
+    scratch reload is one more vector-memory operation: hipcc waits for it with vmcnt(0), which also drains the staged loads
+    (seen: two stores of gathered row numbers sunk into one store through a pointer phi kept a 2-element array in scratch and
+    made the grouped weight-gradient launches 20 % slower)."""
+    out, name = [], None
+    for line in open(path):
+        t = line.strip()
+        m = re.match(r"\.amdhsa_kernel (\S+)", t)
+        if m:
+            name = m.group(1)
+        m = re.match(r"\.amdhsa_private_segment_fixed_size (\d+)", t)
+        if m and name and int(m.group(1)) > 0 and re.search(pat, name):
+            out.append((name, int(m.group(1))))
+    return out
+
+
 def main():
     global DBG_OFF, PRUNE
     argv = sys.argv[1:]
@@ -252,8 +269,11 @@ def main():
     if verbose:
         for k, (nb, ns, nc) in stats.items():
             print(f"  {k[-80:]}: {nb} blocks, {ns} (block, state) pairs, {nc} edges crossed with loads in flight")
-    print(f"staged-load hazard check (CFG-aware): {len(stats)} kernel(s), {len(bad)} finding(s)")
-    return 1 if bad else 0
+    scr = scratch_users(path, pat)
+    for kname, n in scr:
+        print(f"SCRATCH {kname[-70:]}: {n} bytes/lane of private memory (stack object or spill) in a hand-scheduled kernel")
+    print(f"staged-load hazard check (CFG-aware): {len(stats)} kernel(s), {len(bad)} finding(s), {len(scr)} kernel(s) with scratch")
+    return 1 if (bad or scr) else 0
 
 
 if __name__ == "__main__":
