@@ -1595,7 +1595,15 @@ inline int gemm_mode() {
 inline bool use_x3(const ssc_gemm_desc* d, bool vec) { return gemm_mode() == 1 && d->a_kc && d->b_kc && vec; }
 // Tuning / diagnostic switches (include/ssc_debug.h: ssc_debug_set / ssc_debug_get; environment defaults in parentheses).
 // They select between kernel forms that compute the same product; none is part of the product ABI.
-int g_x3b = getenv("SSC_X3B") ? atoi(getenv("SSC_X3B")) : 3;  // large products (M, N >= 512): 0 = 64x64 kernels, 3 (default) = the 4-wave 128x128 3xBF16 kernel, 2 = its wave-specialised form, 1 = chosen by grid size (hooks -8, -9, -10, -14).  The wave-specialised 128x128 form is opt-in: it is ~5-10 % faster on grids several rounds deep (decode), but one long decode run ended in an unexplained GPU memory fault with it
+// Large products (M, N >= 512): 0 = 64x64 kernels, 3 = always the 4-wave 128x128 3xBF16 kernel, 2 = always its wave-specialised
+// form, 1 (default since round 2) = by grid size: wave-specialised from 768 workgroups on (three rounds of the chip: decode
+// +13 % tokens/s), 4-wave below (two workgroups per CU even out grids of one or two rounds).  History: round 1 kept the
+// wave-specialised form opt-in after ONE unexplained GPU memory fault in a long decode run.  Since then its loop
+// structure, addressing and register discipline were rebuilt (branch-free staged loads, uniform loops, 12 waves, scalar bases)
+// under an exact ISA gate, the same kernel family has run the grouped weight gradients of every train step, and the 3000-image
+// decode of the fault ran clean with it twice (before and after the rebuild).  `ssc_debug_set("large_form", 3)` / SSC_X3B=3
+// selects the 4-wave kernel everywhere.
+int g_x3b = getenv("SSC_X3B") ? atoi(getenv("SSC_X3B")) : 1;
 int g_x3_nbuf = 1;  // single LDS stage: 31 KB per workgroup -> four resident workgroups per CU (rocprof r01: 37 vs 43 us)
 int g_x3_wide = 0;
 int g_x3_pf = 2;  // tuning hook: 1 = 64x128 block tile for skinny (M <= 64, N >= 1024) 3xBF16 products
