@@ -60,7 +60,9 @@ def _worker(rank, world, port, ret):
     w = dp.allreduce_flat(store.flat, n_buckets=3)
     store.flat.mul_(dp.gscale(w))
     if rank == 0:
-        ret.put({k: v.clone() for k, v in store.views.items()})
+        # numpy arrays travel through the queue by value; torch tensors would be handed over as shared-memory file descriptors,
+        # which needs this process alive until the parent has received them (a race once the worker exits)
+        ret.put({k: v.clone().numpy() for k, v in store.views.items()})
     dist.barrier()
     dist.destroy_process_group()
 
@@ -72,7 +74,7 @@ def test_dp_gradients_equal_full_batch():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, ret)) for r in range(2)]
     for p in procs:
         p.start()
-    got = ret.get()
+    got = {k: torch.from_numpy(v) for k, v in ret.get().items()}
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
