@@ -57,6 +57,8 @@ struct KArgs {
   const int* karows;  // A's k-row k is read from row karows[k]
   const int* kbrows;  // B's k-row k is read from row kbrows[k]
   int tile_gm;        // tile rows per group of the launch's tile order (tile_order)
+  int store_wt;       // x3w epilogue: 1 = write-through (sc1) stores of the output tile (split-K slabs: nothing left dirty in L2
+                      // for the kernel boundary to write back)
 };
 
 // Tile order of a launch (speed only; a bijection for any grid).  Workgroups are dealt round-robin over the 8 XCDs, each
@@ -1310,14 +1312,17 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
       prefetch_rows();
       // the first PF tiles are requested back to back (one exposed memory latency, not two); afterwards set (r+1) % PF
       // holds tile s_lo + r + 1 when iteration r starts
+      SSC_STAMP(120);   // setup done, nothing requested yet
       issue_loads(ra[0], rb[0], oka[0], okb[0], fullk[0]);
 #pragma unroll
       for (int j = 1; j < PF; ++j) {
         advance();
         issue_loads(ra[j], rb[j], oka[j], okb[j], fullk[j]);
       }
+      SSC_STAMP(121);   // first PF tiles requested
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PF - 1) * NL) : "memory");
       pin(ra[0], rb[0]);
+      SSC_STAMP(122);   // first tile landed
       put_planes(lds, ra[0], rb[0], oka[0], okb[0], fullk[0]);
       advance();
       issue_loads(ra[0], rb[0], oka[0], okb[0], fullk[0]);
@@ -1463,7 +1468,12 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
       if (wide) {
         if (a.bias) { const float4 b4 = *reinterpret_cast<const float4*>(a.bias + gcol); v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w; }
         if (a.accumulate) { const float4 o4 = *reinterpret_cast<const float4*>(dst); v.x += o4.x; v.y += o4.y; v.z += o4.z; v.w += o4.w; }
-        *reinterpret_cast<float4*>(dst) = v;
+        if (a.store_wt) {
+          const f32x4 v4 = {v.x, v.y, v.z, v.w};
+          asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v4) : "memory");
+        } else {
+          *reinterpret_cast<float4*>(dst) = v;
+        }
       } else {
         const float e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -1545,10 +1555,16 @@ ProfRec* g_prof = nullptr;
 int g_prof_n = 0;
 bool g_prof_on = false;
 
+// Write-through (sc1) output stores of the wave-specialised kernels: the 16 MB of split-K slabs a gate product leaves behind
+// reach memory while the kernel is still running instead of being written back at the kernel boundary (rocprof timeline:
+// 1-3.5 us between such a kernel's end and its consumer's start).  Train step 8.76 -> 8.57-8.65 ms (same-box A/B, twice).  Round
+// 2's first try of this showed no difference: the 8-wave kernels were slower then and their own tail hid the write-back.
+int g_store_wt = getenv("SSC_STORE_WT") ? atoi(getenv("SSC_STORE_WT")) : 1;
 int g_tile_gm = getenv("SSC_TILE_GM") ? atoi(getenv("SSC_TILE_GM")) : 8;   // tile_order(): tile rows per group (0 = row-major)
 int build_args(const ssc_gemm_desc* d, KArgs& k) {
   if (!d || d->nseg < 1 || d->nseg > SSC_MAX_SEG || d->M <= 0 || d->N <= 0) return SSC_EINVAL;
   k.tile_gm = g_tile_gm;
+  k.store_wt = g_store_wt;
   k.nseg = d->nseg;
   k.M = d->M;
   k.N = d->N;
@@ -2126,6 +2142,7 @@ const DebugKey g_debug_keys[] = {
     {"x3w_big_npw", &g_x3w_big_npw}, // wave-specialised 128x128 kernels: producer waves (4 | 8)   (SSC_X3W_BIG_NPW)
     {"x3w_npw", &g_x3w_npw},         // 64x256 kernels: producer waves per workgroup (4 | 8)   (SSC_X3W_NPW)
     {"x3w_pf", &g_x3w_pf},           // 64x256 kernels: k-steps in flight in the producers' registers (2 | 3)   (SSC_X3W_PF)
+    {"store_wt", &g_store_wt},       // wave-specialised kernels: write-through (sc1) output stores (0 | 1)   (SSC_STORE_WT)
     {"tile_gm", &g_tile_gm},         // tile rows per group of the tile order (8; 0 = row-major)   (SSC_TILE_GM)
 };
 }  // namespace

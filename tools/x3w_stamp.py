@@ -86,9 +86,11 @@ def run(shape, wg):
     print(f"{shape} workgroup {wg}: kernel entry -> exit {cyc} shader cycles, {wall * 0.01:.2f} us wall -> {ghz:.2f} GHz shader clock")
     t0 = prod[126]
     us = lambda c: c / (ghz * 1e3)
+    print(f"prologue (us since kernel entry): setup done {us(prod[120] - t0):.2f} | first tiles requested {us(prod[121] - t0):.2f} | "
+          f"first tile landed {us(prod[122] - t0):.2f}")
     print("producer wave 4  (us since kernel entry: data landed | planes stored | next loads issued | barrier passed)")
     r = 0
-    while 4 * r + 3 < 124 and t0 < prod[4 * r] < prod[124]:
+    while 4 * r + 3 < 120 and t0 < prod[4 * r] < prod[124]:
         p = prod[4 * r: 4 * r + 4]
         prev = prod[4 * r - 1] if r else t0
         print(f"  k-step {r:2d}: {us(p[0] - t0):7.2f} {us(p[1] - t0):7.2f} {us(p[2] - t0):7.2f} {us(p[3] - t0):7.2f}   "
