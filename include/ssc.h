@@ -128,6 +128,10 @@ typedef struct {
   float* h_out; int ld_hout;
 } ssc_lstm_fwd_desc;
 int ssc_lstm_fwd(const ssc_lstm_fwd_desc* d, void* stream);
+/* The same with one more addend formed inside the kernel: pre[b,n] += z[b,:Z] . wz[n,:Z]  (z (B,Z) ld ldz; wz (4H,Z) ld ldwz;
+ * exact-fp32 MFMA).  Used for the latent block of the decoder LSTM input (updown_cell.py:211-229): z exists only after the
+ * latent head of the same step, the rest of the gate product does not wait for it. */
+int ssc_lstm_fwd_z(const ssc_lstm_fwd_desc* d, const float* z, int ldz, const float* wz, int ldwz, int Z, void* stream);
 
 /* LSTMCell pointwise backward (SURVEY Appendix A.4 "LSTM^-1"):
  *   dh (B,H) (+ dh2 optional second addend), dc_in (B,H), gates (activated), c_prev, c_new

@@ -27,7 +27,7 @@ def short(name):
         a, b, kg = m.groups()
         kind = {("true", "true"): "NT", ("true", "false"): "NN", ("false", "false"): "TN"}[(a, b)]
         return f"gemm_x3b_kernel<{kind},128x128{',rowgather' if kg == 'true' else ''}>"
-    m = re.search(r"gemm_x3w_kernel<(\w+), (\w+), (\w+), (\d+), (\d+), (\d)>", name)
+    m = re.search(r"gemm_x3w_kernel<(\w+), (\w+), (\w+), (\d+), (\d+), (\d)(?:, \d)?>", name)   # (+ producer waves since r02_b)
     if m:
         a, b, kg, tm, tn, pf = m.groups()
         kind = {("true", "true"): "NT", ("true", "false"): "NN", ("false", "false"): "TN"}[(a, b)]

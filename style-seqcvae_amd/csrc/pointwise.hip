@@ -137,6 +137,136 @@ __global__ void lstm_fwd_kernel(const ssc_lstm_fwd_desc d) {
   d.c_out[(size_t)b * d.ld_cout + j] = c;
   d.h_out[(size_t)b * d.ld_hout + j] = h;
 }
+// lstm_fwd_kernel plus one more addend of the gate pre-activations computed IN the kernel: pre[b,n] += z[b,:] . wz[n,:]
+// (K = Z: the latent block of the decoder LSTM's input, updown_cell.py:211-229).  z only exists after the latent head of the
+// same step, so as a K-segment of the gate product it would tie the whole 88 MB product to the end of the step's dependency
+// chain; here the product's other segments are issued earlier (grouped with the encoder product) and the small z block costs
+// no launch of its own.  One 512-thread workgroup per (32 batch rows x 16 hidden units) = one cell per thread; every load of
+// the kernel (the z rows and the 64 wz rows of the tile, cell operands, slab values) is requested up front, so one memory
+// latency is exposed as in lstm_fwd_kernel; wave (rt, g) then forms the 16 x 16 block of row tile rt and gate g on the
+// exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) from LDS images and hands it to the cell threads through LDS.  150 workgroups at
+// C2: one round of the chip (a first form with 256-thread workgroups of 16 x 16 cells needed 254 VGPRs, one workgroup per CU,
+// and its 300 workgroups took two rounds: 16.8 us).
+typedef float ssc_f32x4v __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(512, 2) void lstm_fwd_z_kernel(const ssc_lstm_fwd_desc d, const float* __restrict__ z, int ldz,
+                                                            const float* __restrict__ wz, int ldwz, int Z) {
+  constexpr int TB = 32, TJ = 16, KT = 128, LD = KT + 4, NT = 512;   // k-tile of 128 (one pass for Z <= 128); rows padded by 4 floats
+  __shared__ __attribute__((aligned(16))) float sz[TB * LD];       // z[b0 + r, k]
+  __shared__ __attribute__((aligned(16))) float sw[4 * TJ * LD];   // wz[g*H + j0 + jj, k], row = g*16 + jj
+  __shared__ float st[TB * 65];                                    // product tile [row b][column g*16 + jj]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int H = d.H, H4 = 4 * d.H;
+  const int j0 = blockIdx.x * TJ, b0 = blockIdx.y * TB;
+  const int bb = tid >> 4, jj = tid & 15;
+  const int b = b0 + bb, j = j0 + jj;
+  const bool live = b < d.B && j < H;
+  const int bc = live ? b : 0, jc = live ? j : 0;   // clamped: every thread runs the same loads
+  // ---- operand tiles of the product: requested first (they are needed first) ---------------------------------------------------
+  float zr[TB * KT / NT], wr[4 * TJ * KT / NT];
+  auto request_tiles = [&](int k0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < TB * KT / NT; ++u) {   // 8 floats per thread, coalesced along k
+      const int idx = tid + NT * u, row = idx / KT, kk = idx % KT, k = k0 + kk, zb = b0 + row;
+      zr[u] = (zb < d.B && k < Z) ? z[(size_t)zb * ldz + k] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4 * TJ * KT / NT; ++u) {   // 16 floats per thread
+      const int idx = tid + NT * u, row = idx / KT, kk = idx % KT, k = k0 + kk, wj = j0 + (row & 15);
+      wr[u] = (wj < H && k < Z) ? wz[(size_t)((row >> 4) * H + wj) * ldwz + k] : 0.f;
+    }
+  };
+  request_tiles(0);
+  // ---- this thread's cell: operands that do not depend on the product ----------------------------------------------------------
+  float a0[4], a1[4], bi[4], bh[4], sw4[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int n = g * H + jc;
+    a0[g] = d.add0 ? d.add0[(size_t)bc * d.ld_add0 + n] : 0.f;
+    a1[g] = d.add1 ? d.add1[(size_t)(bc / d.rows_per_add1) * d.ld_add1 + n] : 0.f;
+    bi[g] = d.b_ih ? d.b_ih[n] : 0.f;
+    bh[g] = d.b_hh ? d.b_hh[n] : 0.f;
+    sw4[g] = d.sent ? d.wcol[(size_t)n * d.ldwcol] : 0.f;
+  }
+  const float sv = d.sent ? d.sent[bc] : 0.f;
+  const float cp = d.c_prev ? d.c_prev[(size_t)bc * d.ld_cprev + jc] : 0.f;
+  float t0[4][16];   // first batch of slab values (later batches, if any, after the product)
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const float* sp = d.slabs + (size_t)min(u, max(d.nslab - 1, 0)) * d.slab_stride + (size_t)bc * H4 + jc;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) t0[g][u] = d.nslab > 0 ? sp[g * H] : 0.f;
+  }
+  // ---- z . wz^T for the workgroup's 32 rows x (4 gates x 16 units) ----------------------------------------------------------
+  // fragment convention: lane (r = lane & 15, q = lane >> 4) reads 4 consecutive k at 16 c + 4 q of row r; MFMA i of chunk c
+  // takes element i of every lane, i.e. contracts k in {16 c + 4 q + i : q = 0..3} - the same for both operands
+  ssc_f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+  const int r16 = lane & 15, q4 = lane >> 4;
+  const int rt = wave >> 2, gw = wave & 3;   // 8 waves: row tile (0, 1) x gate
+  for (int k0 = 0; k0 < Z; k0 += KT) {
+    if (k0 > 0) {
+      __syncthreads();   // the previous k-tile has been consumed
+      request_tiles(k0);
+    }
+#pragma unroll
+    for (int u = 0; u < TB * KT / NT; ++u) { const int idx = tid + NT * u; sz[(idx / KT) * LD + idx % KT] = zr[u]; }
+#pragma unroll
+    for (int u = 0; u < 4 * TJ * KT / NT; ++u) { const int idx = tid + NT * u; sw[(idx / KT) * LD + idx % KT] = wr[u]; }
+    __syncthreads();
+    const int kend = min(KT, (Z - k0 + 15) / 16 * 16);   // whole 16-wide chunks; the tail is zero-filled
+    for (int c = 0; c < kend; c += 16) {
+      const float4 av = *reinterpret_cast<const float4*>(&sz[(rt * 16 + r16) * LD + c + 4 * q4]);
+      const float4 bv = *reinterpret_cast<const float4*>(&sw[(gw * 16 + r16) * LD + c + 4 * q4]);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc, 0, 0, 0);
+    }
+  }
+  // output layout of the 16x16 MFMA: lane holds rows 4 q + i (i = 0..3) of column r
+#pragma unroll
+  for (int i = 0; i < 4; ++i) st[(rt * 16 + 4 * q4 + i) * 65 + gw * 16 + r16] = acc[i];
+  __syncthreads();
+  // ---- cell update (same arithmetic and summation order as lstm_fwd_kernel, the z term added last) ------------------------------
+  float pre[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < 16; ++u)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) pre[g] += (u < d.nslab) ? t0[g][u] : 0.f;
+  for (int s0 = 16; s0 < d.nslab; s0 += 16) {
+    float t[4][16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const float* sp = d.slabs + (size_t)min(s0 + u, d.nslab - 1) * d.slab_stride + (size_t)bc * H4 + jc;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) t[g][u] = sp[g * H];
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) pre[g] += (s0 + u < d.nslab) ? t[g][u] : 0.f;
+  }
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    float v = pre[g];
+    v += a0[g];
+    v += a1[g];
+    v += bi[g];
+    v += bh[g];
+    if (d.sent) v += sv * sw4[g];
+    v += st[bb * 65 + g * 16 + jj];
+    pre[g] = v;
+  }
+  if (!live) return;
+  float ig = ssc_sigmoid(pre[0]), fg = ssc_sigmoid(pre[1]), gg = tanhf(pre[2]), og = ssc_sigmoid(pre[3]);
+  float c = fg * cp + ig * gg;
+  float h = og * tanhf(c);
+  if (d.gates_out) {
+    float* go = d.gates_out + (size_t)b * H4 + j;
+    go[0] = ig; go[H] = fg; go[2 * H] = gg; go[3 * H] = og;
+  }
+  d.c_out[(size_t)b * d.ld_cout + j] = c;
+  d.h_out[(size_t)b * d.ld_hout + j] = h;
+}
 __global__ void lstm_bwd_kernel(const ssc_lstm_bwd_desc d) {
   int j = blockIdx.x * blockDim.x + threadIdx.x;
   int b = blockIdx.y;
@@ -539,6 +669,17 @@ extern "C" int ssc_lstm_fwd(const ssc_lstm_fwd_desc* d, void* stream) {
   if (d->sent && !d->wcol) return SSC_EINVAL;
   if (d->add1 && d->rows_per_add1 <= 0) return SSC_EINVAL;
   SSC_LAUNCH(lstm_fwd_kernel, dim3(ssc_cdiv(d->H, 128), d->B), dim3(128), 0, S(stream), *d);
+  SSC_CHECK_LAUNCH();
+  return SSC_OK;
+}
+
+extern "C" int ssc_lstm_fwd_z(const ssc_lstm_fwd_desc* d, const float* z, int ldz, const float* wz, int ldwz, int Z, void* stream) {
+  if (!d || d->B <= 0 || d->H <= 0 || !d->c_out || !d->h_out) return SSC_EINVAL;
+  if (d->nslab < 0 || (d->nslab > 0 && !d->slabs)) return SSC_EINVAL;
+  if (d->sent && !d->wcol) return SSC_EINVAL;
+  if (d->add1 && d->rows_per_add1 <= 0) return SSC_EINVAL;
+  if (!z || !wz || Z <= 0 || ldz < Z || ldwz < Z) return SSC_EINVAL;
+  SSC_LAUNCH(lstm_fwd_z_kernel, dim3(ssc_cdiv(d->H, 16), ssc_cdiv(d->B, 32)), dim3(512), 0, S(stream), *d, z, ldz, wz, ldwz, Z);
   SSC_CHECK_LAUNCH();
   return SSC_OK;
 }

@@ -33,6 +33,7 @@ struct Layout {
   size_t h1, c1, he, ce, hd, cd, gates_a, gates_e, gates_d, q, attn_logits, alpha, att, mu, lv, z, mulv;
   size_t slabs, slab_floats, logits, lse, proj;
   size_t sl_q, sl_mulv, sl_gh1, sl_ghd, sl_ghd2, sl_ghe, sl_dqw, sl_dhe, sl_dz, small_floats, wsum_att, wsum_dec, wz;
+  size_t sl_ga, sl_ge, sl_gd, gate_floats;   // split-K slab regions of the three gate products (forward)
   // backward
   size_t dhdv, dga, dge, dgd, dga_sum, g_h1, g_c1, g_he, g_ce, g_cd, dz, dmulv, dx, dalpha, dq, dpv, dwa, demb, dproj;
 
@@ -88,6 +89,10 @@ Layout make_layout(const ssc_model_cfg* c, int B, int R, int L) {
     l.sl_ghd2 = l.take(l.small_floats);
     l.sl_dqw = l.take(l.small_floats); l.sl_dhe = l.take(l.small_floats); l.sl_dz = l.take(l.small_floats);
   }
+  // forward gate products: a product's recurrent part (issued at the start of the step) and its attention-dependent part
+  // (issued after the attention) leave their slabs back to back in one region, the cell kernel sums them as one list
+  l.gate_floats = (size_t)34 * B * l.H4;
+  l.sl_ga = l.take(l.gate_floats); l.sl_ge = l.take(l.gate_floats); l.sl_gd = l.take(l.gate_floats);
   l.wsum_att = l.take((size_t)l.H4 * l.Hp);   // W_ih^att[:, h1-block] + W_hh^att  (both multiply h1')
   l.wsum_dec = l.take((size_t)l.H4 * l.Hp);   // W_ih^dec[:, hd-block] + W_hh^dec  (both multiply hd')
   l.wz = l.take((size_t)l.H4 * l.Zp);         // 16-B aligned copy of the z-block of W_ih^dec
@@ -434,16 +439,30 @@ extern "C" int ssc_train_fwd(const ssc_model_cfg* cfg, const ssc_params* p, cons
     float* qt = W + l.q + (size_t)t * B * l.Ap;
     float* zt = W + l.z + (size_t)t * B * l.Zp;
     int ns = 0;
+    const size_t sG = (size_t)B * H4;   // one gate slab
+    int n_ga = 0, n_ge_r = 0, n_gd_r = 0, n_ge_a = 0, n_gd_a = 0;
 
-    // (i) attention LSTM: x_a = [emb, avg, h1', hd'] (updown_cell.py:143-148)
+    // (0) everything that only needs the states of step t-1, in ONE launch: the attention LSTM's gate product and the
+    // recurrent K-segments of the encoder / decoder products (hd', he').  All recurrent inputs are zero at t = 0.
+    if (t > 0) {
+      const float* wr = p->att_w_ih + E + F;
+      ssc_gemm_desc d3[3];
+      // attention LSTM: x_a = [emb, avg, h1', hd'] (updown_cell.py:143-148); h1' meets the pre-summed W_ih[:,h1]+W_hh block
+      fill_desc(d3[0], true, true, {{h1p, l.Hp, W + l.wsum_att, l.Hp, H}, {hdp, l.Hp, wr + H, p->ld_att_w_ih, H}}, B, H4);
+      fill_desc(d3[1], true, true, {{hdp, l.Hp, p->enc_w_ih + F + H, p->ld_enc_w_ih, H}, {hep, l.Hp, p->enc_w_hh, p->ld_enc_w_hh, H}}, B, H4);
+      fill_desc(d3[2], true, true, {{hdp, l.Hp, W + l.wsum_dec, l.Hp, H}}, B, H4);   // hd' meets W_ih^dec[:,hd] + W_hh^dec
+      const ssc_gemm_desc* dp[3] = {&d3[0], &d3[1], &d3[2]};
+      float* regions[3] = {W + l.sl_ga, W + l.sl_ge, W + l.sl_gd};
+      const size_t caps[3] = {l.gate_floats, l.gate_floats / 2, l.gate_floats / 2};
+      int ns3[3] = {0, 0, 0};
+      SSC_TRY(ssc_gemm_slabs_group(dp, 3, regions, caps, ns3, st));
+      n_ga = ns3[0]; n_ge_r = ns3[1]; n_gd_r = ns3[2];
+    }
+    // (i) attention LSTM cell
     {
       ssc_lstm_fwd_desc d{};
       d.B = B; d.H = H;
-      if (t > 0) {  // all recurrent inputs are zero at t = 0; h1' meets the pre-summed W_ih[:,h1]+W_hh block
-        const float* wr = p->att_w_ih + E + F;
-        SSC_TRY(gemm_to_slabs(c, {{h1p, l.Hp, W + l.wsum_att, l.Hp, H}, {hdp, l.Hp, wr + H, p->ld_att_w_ih, H}}, B, H4, &ns));
-        d.slabs = c.slabs; d.nslab = ns; d.slab_stride = (size_t)B * H4;
-      }
+      if (n_ga > 0) { d.slabs = W + l.sl_ga; d.nslab = n_ga; d.slab_stride = sG; }
       d.add0 = W + l.ga_static + (size_t)t * B * H4; d.ld_add0 = H4;
       d.add1 = W + l.ga_avg; d.ld_add1 = H4; d.rows_per_add1 = 1;
       d.b_ih = p->att_b_ih; d.b_hh = p->att_b_hh;
@@ -457,14 +476,24 @@ extern "C" int ssc_train_fwd(const ssc_model_cfg* cfg, const ssc_params* p, cons
     SSC_TRY(gemm_to_slabs(c, W + l.sl_q, l.small_floats, true, true, {{h1n, l.Hp, p->wq, p->ld_wq, H}}, B, A, &ns));
     SSC_TRY(ssc_attn_fwd_qslabs(W + l.sl_q, ns, (size_t)B * A, qt, l.Ap, W + l.pv, p->wa, W + l.mask, bt->feats, B, R, A, F, 1,
                                 W + l.attn_logits, W + l.alpha + (size_t)t * B * R, att, l.Fp, st));
-    // (iv) encoder LSTM: x_e = [att, h1, hd', (s)] (updown_cell.py:176-194)
+    // (iv) the attention-dependent K-segments [att, h1] of the encoder AND decoder products in one launch; their slabs follow
+    // the recurrent ones.  x_e = [att, h1, hd', (s)] + he' (updown_cell.py:176-194); x_d = [att, h1, hd', (s), z] (:211-229)
     {
-      SSC_TRY(gemm_to_slabs(c, {{att, l.Fp, p->enc_w_ih, p->ld_enc_w_ih, F}, {h1n, l.Hp, p->enc_w_ih + F, p->ld_enc_w_ih, H},
-                                {hdp, l.Hp, p->enc_w_ih + F + H, p->ld_enc_w_ih, t > 0 ? H : 0},
-                                {hep, l.Hp, p->enc_w_hh, p->ld_enc_w_hh, t > 0 ? H : 0}}, B, H4, &ns));
+      ssc_gemm_desc d2[2];
+      fill_desc(d2[0], true, true, {{att, l.Fp, p->enc_w_ih, p->ld_enc_w_ih, F}, {h1n, l.Hp, p->enc_w_ih + F, p->ld_enc_w_ih, H}}, B, H4);
+      fill_desc(d2[1], true, true, {{att, l.Fp, p->dec_w_ih, p->ld_dec_w_ih, F}, {h1n, l.Hp, p->dec_w_ih + F, p->ld_dec_w_ih, H}}, B, H4);
+      const ssc_gemm_desc* dp[2] = {&d2[0], &d2[1]};
+      float* regions[2] = {W + l.sl_ge + (size_t)n_ge_r * sG, W + l.sl_gd + (size_t)n_gd_r * sG};
+      const size_t caps[2] = {l.gate_floats - (size_t)n_ge_r * sG, l.gate_floats - (size_t)n_gd_r * sG};
+      int ns2[2] = {0, 0};
+      SSC_TRY(ssc_gemm_slabs_group(dp, 2, regions, caps, ns2, st));
+      n_ge_a = ns2[0]; n_gd_a = ns2[1];
+    }
+    // encoder LSTM cell
+    {
       ssc_lstm_fwd_desc d{};
       d.B = B; d.H = H;
-      d.slabs = c.slabs; d.nslab = ns; d.slab_stride = (size_t)B * H4;
+      d.slabs = W + l.sl_ge; d.nslab = n_ge_r + n_ge_a; d.slab_stride = sG;
       d.b_ih = p->enc_b_ih; d.b_hh = p->enc_b_hh;
       if (S) { d.sent = bt->sentiment; d.wcol = W + l.wcol_e; d.ldwcol = 1; }
       d.c_prev = cep; d.ld_cprev = l.Hp;
@@ -495,20 +524,17 @@ extern "C" int ssc_train_fwd(const ssc_model_cfg* cfg, const ssc_params* p, cons
       d.kld_acc = kld;
       SSC_TRY(ssc_latent_fwd(&d, st));
     }
-    // (vi) decoder LSTM: x_d = [att, h1, hd', (s), z] (updown_cell.py:211-229)
+    // (vi) decoder LSTM cell; its z block (K = Z, the only operand that waits for the latent head) is formed inside the kernel
     {
-      // hd' meets the pre-summed W_ih[:,hd]+W_hh block; z meets the aligned copy of its weight block
-      SSC_TRY(gemm_to_slabs(c, {{att, l.Fp, p->dec_w_ih, p->ld_dec_w_ih, F}, {h1n, l.Hp, p->dec_w_ih + F, p->ld_dec_w_ih, H},
-                                {hdp, l.Hp, W + l.wsum_dec, l.Hp, t > 0 ? H : 0}, {zt, l.Zp, W + l.wz, l.Zp, Z}}, B, H4, &ns));
       ssc_lstm_fwd_desc d{};
       d.B = B; d.H = H;
-      d.slabs = c.slabs; d.nslab = ns; d.slab_stride = (size_t)B * H4;
+      d.slabs = W + l.sl_gd; d.nslab = n_gd_r + n_gd_a; d.slab_stride = sG;
       d.b_ih = p->dec_b_ih; d.b_hh = p->dec_b_hh;
       if (S) { d.sent = bt->sentiment; d.wcol = W + l.wcol_d; d.ldwcol = 1; }
       d.c_prev = cdp; d.ld_cprev = l.Hp;
       d.gates_out = W + l.gates_d + (size_t)t * B * H4;
       d.c_out = cdn; d.ld_cout = l.Hp; d.h_out = hdn; d.ld_hout = l.Hp;
-      SSC_TRY(ssc_lstm_fwd(&d, st));
+      SSC_TRY(ssc_lstm_fwd_z(&d, zt, l.Zp, W + l.wz, l.Zp, Z, st));
     }
   }
 

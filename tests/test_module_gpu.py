@@ -187,3 +187,58 @@ def test_bare_updown_cell_matches_reference_cell(tag, sv, Z):
             assert maxdiff(st[k], t(f"{mode}/state/{k}")) < 1e-4, (mode, k)
         assert maxdiff(mean, t(f"{mode}/mean")) < 1e-4 and maxdiff(lv, t(f"{mode}/log_var")) < 1e-4
         assert maxdiff(pm, t(f"{mode}/prior_mean")) < 1e-4 and maxdiff(plv, t(f"{mode}/prior_log_var")) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,Z,nslab", [(64, 1200, 128, 13), (5, 37, 13, 3), (70, 50, 6, 0)])
+def test_lstm_fwd_z_equals_cell_with_precomputed_latent_block(B, H, Z, nslab):
+    """ssc_lstm_fwd_z (decoder cell with the K = Z latent block z . Wz^T formed inside the kernel) against ssc_lstm_fwd fed the
+    same block through add0, and against the LSTMCell pointwise formulas in float64 (updown_cell.py:211-229).  1e-5: the two
+    kernels sum in a different order; the in-kernel product is exact-fp32 MFMA."""
+    import ctypes as C
+    from ssc_runtime import lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(B * 1000 + H)
+    dev = "cuda"
+    Zp = (Z + 3) // 4 * 4
+    slabs = (torch.randn(max(nslab, 1), B, 4 * H, generator=g) * 0.3).to(dev)
+    z = torch.zeros(B, Zp)
+    z[:, :Z] = torch.randn(B, Z, generator=g)
+    wz = torch.full((4 * H, Zp), float("nan"))      # pad columns must never be read
+    wz[:, :Z] = torch.randn(4 * H, Z, generator=g) * 0.2
+    z, wz = z.to(dev), wz.to(dev)
+    b_ih, b_hh = torch.randn(4 * H, generator=g).to(dev), torch.randn(4 * H, generator=g).to(dev)
+    sent, wcol = torch.randn(B, generator=g).to(dev), torch.randn(4 * H, generator=g).to(dev)
+    c_prev = torch.randn(B, H, generator=g).to(dev)
+
+    def run(with_z):
+        h, c, gates = (torch.empty(B, H, device=dev), torch.empty(B, H, device=dev), torch.empty(B, 4 * H, device=dev))
+        d = L.LstmFwdDesc()
+        d.B, d.H = B, H
+        if nslab:
+            d.slabs, d.nslab, d.slab_stride = slabs.data_ptr(), nslab, B * 4 * H
+        d.b_ih, d.b_hh = b_ih.data_ptr(), b_hh.data_ptr()
+        d.sent, d.wcol, d.ldwcol = sent.data_ptr(), wcol.data_ptr(), 1
+        d.c_prev, d.ld_cprev = c_prev.data_ptr(), H
+        d.gates_out = gates.data_ptr()
+        d.c_out, d.ld_cout, d.h_out, d.ld_hout = c.data_ptr(), H, h.data_ptr(), H
+        if with_z:
+            lib.ssc_lstm_fwd_z(C.byref(d), z.data_ptr(), Zp, wz.data_ptr(), Zp, Z, L.stream_ptr())
+        else:
+            blk = (z[:, :Z].double() @ wz[:, :Z].double().t()).float().contiguous()
+            d.add0, d.ld_add0 = blk.data_ptr(), 4 * H
+            lib.ssc_lstm_fwd(C.byref(d), L.stream_ptr())
+        torch.cuda.synchronize()
+        return h, c, gates
+
+    hz, cz, gz = run(True)
+    h0, c0, g0 = run(False)
+    for a, b in ((hz, h0), (cz, c0), (gz, g0)):
+        assert torch.isfinite(a).all()
+        assert (a - b).abs().max().item() < 1e-5
+    pre = (slabs[:nslab].double().sum(0) if nslab else 0) + z[:, :Z].double() @ wz[:, :Z].double().t() + b_ih.double() + b_hh.double() \
+        + sent.double()[:, None] * wcol.double()[None, :]
+    i, f, gg, o = pre.split(H, dim=1)
+    cw = torch.sigmoid(f) * c_prev.double() + torch.sigmoid(i) * torch.tanh(gg)
+    hw = torch.sigmoid(o) * torch.tanh(cw)
+    assert (cz.double() - cw).abs().max().item() < 1e-5 and (hz.double() - hw).abs().max().item() < 1e-5
