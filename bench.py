@@ -281,7 +281,7 @@ def main():
     # length; after a few SGD steps on synthetic captions the model emits BOUNDARY at once).
     dres = None
     if not args.timed_only and not args.no_decode:
-        dres = measure_decode(model, c, rank, world, device, 200 * world, 2)
+        dres = measure_decode(model, c, rank, world, device, 400 * world, 5)   # 5 warm-up calls: the leg runs first, on a GPU coming out of idle (2 gave 188k instead of 290k tokens/s)
     batches = [synth_batch(1234 + rank + 100 * i, c["B"], c["R"], c["F"], c["L"], c["V"], c["Z"], device) for i in range(4)]
     total_iters = 70000
 

@@ -297,15 +297,58 @@ int add2d(const float* a, int lda, const float* b, int ldb, int rows, int cols, 
   SSC_CHECK_LAUNCH();
   return SSC_OK;
 }
-// once per call: pre-summed recurrent blocks and the aligned z-block copy
+// once per call, ONE launch: the pre-summed recurrent blocks W_ih[:, h-block] + W_hh of the attention / decoder LSTM (SURVEY
+// A.5), the 16-byte aligned copy of the z-block of W_ih^dec, and the rank-1 sentiment columns of W_ih^enc / W_ih^dec made
+// contiguous.  One workgroup per gate row n.
+struct ViewArgs {
+  const float *att_ih, *att_hh, *dec_ih, *dec_hh, *dec_z, *enc_s, *dec_s;   // row-n bases: [n * ld + column offset]
+  int ld_att_ih, ld_att_hh, ld_dec_ih, ld_dec_hh, ld_enc_ih;
+  int H, Hp, Z, Zp, S;
+  float *wsum_att, *wsum_dec, *wz, *wcol_e, *wcol_d;
+};
+__global__ void weight_views_kernel(const ViewArgs a) {
+  const int n = blockIdx.x, tid = threadIdx.x;
+  for (int k = tid; k < a.H; k += blockDim.x) {
+    a.wsum_att[(size_t)n * a.Hp + k] = a.att_ih[(size_t)n * a.ld_att_ih + k] + a.att_hh[(size_t)n * a.ld_att_hh + k];
+    a.wsum_dec[(size_t)n * a.Hp + k] = a.dec_ih[(size_t)n * a.ld_dec_ih + k] + a.dec_hh[(size_t)n * a.ld_dec_hh + k];
+  }
+  for (int k = tid; k < a.Z; k += blockDim.x) a.wz[(size_t)n * a.Zp + k] = a.dec_z[(size_t)n * a.ld_dec_ih + k];
+  if (a.S && tid == 0) {
+    a.wcol_e[n] = a.enc_s[(size_t)n * a.ld_enc_ih];
+    a.wcol_d[n] = a.dec_s[(size_t)n * a.ld_dec_ih];
+  }
+}
 int prepare_weight_views(const Layout& l, const ssc_params* p, float* W, hipStream_t st) {
-  const int E = l.E, F = l.F, H = l.H, Z = l.Z, S = l.S, H4 = l.H4;
-  SSC_TRY(add2d(p->att_w_ih + E + F, p->ld_att_w_ih, p->att_w_hh, p->ld_att_w_hh, H4, H, W + l.wsum_att, l.Hp, st));
-  SSC_TRY(add2d(p->dec_w_ih + F + H, p->ld_dec_w_ih, p->dec_w_hh, p->ld_dec_w_hh, H4, H, W + l.wsum_dec, l.Hp, st));
-  if (hipMemcpy2DAsync(W + l.wz, (size_t)l.Zp * sizeof(float), p->dec_w_ih + F + 2 * H + S,
-                       (size_t)p->ld_dec_w_ih * sizeof(float), (size_t)Z * sizeof(float), H4, hipMemcpyDeviceToDevice,
-                       st) != hipSuccess)
-    return SSC_EHIP;
+  const int E = l.E, F = l.F, H = l.H, S = l.S;
+  ViewArgs a;
+  a.att_ih = p->att_w_ih + E + F; a.att_hh = p->att_w_hh; a.dec_ih = p->dec_w_ih + F + H; a.dec_hh = p->dec_w_hh;
+  a.dec_z = p->dec_w_ih + F + 2 * H + S; a.enc_s = p->enc_w_ih + F + 2 * H; a.dec_s = p->dec_w_ih + F + 2 * H;
+  a.ld_att_ih = p->ld_att_w_ih; a.ld_att_hh = p->ld_att_w_hh; a.ld_dec_ih = p->ld_dec_w_ih; a.ld_dec_hh = p->ld_dec_w_hh;
+  a.ld_enc_ih = p->ld_enc_w_ih;
+  a.H = H; a.Hp = l.Hp; a.Z = l.Z; a.Zp = l.Zp; a.S = S;
+  a.wsum_att = W + l.wsum_att; a.wsum_dec = W + l.wsum_dec; a.wz = W + l.wz; a.wcol_e = W + l.wcol_e; a.wcol_d = W + l.wcol_d;
+  SSC_LAUNCH(weight_views_kernel, dim3(l.H4), dim3(256), 0, st, a);
+  SSC_CHECK_LAUNCH();
+  return SSC_OK;
+}
+
+// several buffers set to one value in ONE launch (the per-call zero fills: 16 launches of ~5 us each before)
+struct FillList {
+  static constexpr int MAX = 16;
+  float* p[MAX];
+  size_t n[MAX];
+  int count = 0;
+  void add(float* ptr, size_t len) { if (len && count < MAX) { p[count] = ptr; n[count] = len; ++count; } }
+};
+__global__ void fill_many_kernel(const FillList f, float v) {
+  float* p = f.p[blockIdx.y];
+  const size_t n = f.n[blockIdx.y];
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+int fill_many(const FillList& f, float v, hipStream_t st) {
+  if (f.count == 0) return SSC_OK;
+  SSC_LAUNCH(fill_many_kernel, dim3(256, f.count), dim3(256), 0, st, f, v);
+  SSC_CHECK_LAUNCH();
   return SSC_OK;
 }
 
@@ -411,18 +454,18 @@ extern "C" int ssc_train_fwd(const ssc_model_cfg* cfg, const ssc_params* p, cons
   SSC_TRY(ssc_embed_gather(p->emb, p->ld_emb, tok, TB, E, W + l.emb, l.Ep, st));
   SSC_TRY(gemm(c, true, true, {{W + l.emb, l.Ep, p->att_w_ih, p->ld_att_w_ih, E}}, TB, H4, W + l.ga_static, H4));
   SSC_TRY(gemm(c, true, true, {{W + l.avg, F, p->att_w_ih + E, p->ld_att_w_ih, F}}, B, H4, W + l.ga_avg, H4));
-  // initial states (index 0 of every history) and the KL accumulator
-  for (size_t off : {l.h1, l.c1, l.he, l.ce, l.hd, l.cd}) SSC_TRY(ssc_fill(W + off, sH, 0.f, st));
-  SSC_TRY(ssc_fill(kld, B, 0.f, st));
-  if (l.Zp != Z) {  // keep pad columns of z finite (they are never read as K, but are memcpy'd in tests)
-    SSC_TRY(ssc_fill(W + l.z, (size_t)TB * l.Zp, 0.f, st));
-    SSC_TRY(ssc_fill(W + l.mu, (size_t)TB * l.Zp, 0.f, st));
-    SSC_TRY(ssc_fill(W + l.lv, (size_t)TB * l.Zp, 0.f, st));
+  // initial states (index 0 of every history), the KL accumulator, pad columns: one launch
+  {
+    FillList f;
+    for (size_t off : {l.h1, l.c1, l.he, l.ce, l.hd, l.cd}) f.add(W + off, sH);
+    f.add(kld, (size_t)B);
+    if (l.Zp != Z) {  // keep pad columns of z finite (they are never read as K, but are memcpy'd in tests)
+      f.add(W + l.z, (size_t)TB * l.Zp); f.add(W + l.mu, (size_t)TB * l.Zp); f.add(W + l.lv, (size_t)TB * l.Zp);
+    }
+    if (cfg->tied) f.add(W + l.proj, (size_t)TB * l.Ep);  // padded rows stay finite through the tanh
+    SSC_TRY(fill_many(f, 0.f, st));
   }
-  if (S) {  // the rank-1 sentiment columns of W_ih^enc / W_ih^dec, made contiguous once per call
-    SSC_TRY(ssc_copy_strided(p->enc_w_ih + F + 2 * H, p->ld_enc_w_ih, H4, W + l.wcol_e, st));
-    SSC_TRY(ssc_copy_strided(p->dec_w_ih + F + 2 * H, p->ld_dec_w_ih, H4, W + l.wcol_d, st));
-  }
+  // (the rank-1 sentiment columns of W_ih^enc / W_ih^dec are made contiguous by prepare_weight_views)
   SSC_TRY(prepare_weight_views(l, p, W, st));
   const bool fc_adjacent = (p->fc_lv_w == p->fc_mean_w + (size_t)Z * p->ld_fc_mean_w) && p->ld_fc_lv_w == p->ld_fc_mean_w;
 
@@ -544,7 +587,7 @@ extern "C" int ssc_train_fwd(const ssc_model_cfg* cfg, const ssc_params* p, cons
   const float* hd_all = W + l.hd + sH;  // rows t*B+b = h_dec after step t
   // only the rows with a real target are projected (ssc_ce_fwd skips the others)
   if (cfg->tied) {
-    SSC_TRY(ssc_fill(W + l.proj, (size_t)TB * l.Ep, 0.f, st));  // padded rows stay finite through the tanh
+    // (l.proj was zeroed with the initial states: padded rows stay finite through the tanh)
     SSC_TRY(gemm_rows(c, true, {{hd_all, l.Hp, p->proj_w, p->ld_proj_w, H}}, TB, E, W + l.proj, l.Ep));
     SSC_TRY(ssc_bias_tanh(W + l.proj, l.Ep, TB, E, p->proj_b, st));
     SSC_TRY(gemm_rows(c, true, {{W + l.proj, l.Ep, p->emb, p->ld_emb, E}}, TB, V, W + l.logits, l.Vp));
@@ -588,10 +631,22 @@ static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const s
   // ---- vocabulary head ------------------------------------------------------------------------------
   SSC_TRY(ssc_ce_bwd(W + l.logits, l.Vp, tok + B, W + l.w, W + l.nvalid, W + l.lse, gl, T, B, V, st));
   const float* dlog = W + l.logits;
-  SSC_TRY(ssc_fill(W + l.dhdv, (size_t)TB * l.Hp, 0.f, st));  // the padded rows receive no gradient
+  {  // every zero-initialised buffer of this phase in one launch
+    FillList f;
+    f.add(W + l.dhdv, (size_t)TB * l.Hp);   // the padded rows receive no gradient
+    if (cfg->tied) f.add(W + l.dproj, (size_t)TB * l.Ep);
+    // carried gradients start at zero.  g_c1 / g_ce / g_cd are plain (B,H) buffers.  The carried hidden-state gradients are NOT
+    // reduced into buffers: the split-K slabs of the GEMMs that produce them (g_h1', g_hd', g_he', dq Wq, dmu Wmu + dlv Wlv) stay
+    // in per-consumer slab regions and are summed, in a fixed order, inside the LSTM backward kernel that consumes them.
+    for (size_t off : {l.g_c1, l.g_ce, l.g_cd}) f.add(W + off, sH);
+    f.add(W + l.dx, (size_t)B * XW);
+    f.add(W + l.dpv, (size_t)B * R * A);
+    f.add(W + l.dwa, (size_t)B * A);
+    f.add(W + l.dga_sum, (size_t)B * H4);
+    SSC_TRY(fill_many(f, 0.f, st));
+  }
   if (cfg->tied) {
     float* dP = W + l.dproj;
-    SSC_TRY(ssc_fill(dP, (size_t)TB * l.Ep, 0.f, st));
     SSC_TRY(gemm_rows(c, false, {{dlog, l.Vp, p->emb, p->ld_emb, V}}, TB, E, dP, l.Ep));
     SSC_TRY(ssc_tanh_bwd(dP, l.Ep, W + l.proj, l.Ep, TB, E, st));
     SSC_TRY(gemm_rows(c, false, {{dP, l.Ep, p->proj_w, p->ld_proj_w, E}}, TB, H, W + l.dhdv, l.Hp));
@@ -603,15 +658,6 @@ static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const s
     if (g->out_b) SSC_TRY(ssc_colsum2(dlog, l.Vp, TB, V, nullptr, g->out_b, 1, nullptr, 0, c.slabs, st));
   }
 
-  // ---- carried gradients start at zero ----------------------------------------------------------------
-  // g_c1 / g_ce / g_cd are plain (B,H) buffers.  The carried hidden-state gradients are NOT reduced into buffers: the
-  // split-K slabs of the GEMMs that produce them (g_h1', g_hd', g_he', dq Wq, dmu Wmu + dlv Wlv) stay in per-consumer
-  // slab regions and are summed, in a fixed order, inside the LSTM backward kernel that consumes them.
-  for (size_t off : {l.g_c1, l.g_ce, l.g_cd}) SSC_TRY(ssc_fill(W + off, sH, 0.f, st));
-  SSC_TRY(ssc_fill(W + l.dx, (size_t)B * XW, 0.f, st));
-  SSC_TRY(ssc_fill(W + l.dpv, (size_t)B * R * A, 0.f, st));
-  SSC_TRY(ssc_fill(W + l.dwa, (size_t)B * A, 0.f, st));
-  SSC_TRY(ssc_fill(W + l.dga_sum, (size_t)B * H4, 0.f, st));
   // wsum_att / wz were prepared by ssc_train_fwd of the same minibatch (parameters are unchanged until the update)
   float* dx = W + l.dx;            // [datt (F) | dh1 (H) | dhd' (H)], ld XW
   int n_gh1 = 0, n_ghd = 0, n_ghd2 = 0, n_ghe = 0;  // slab counts carried from step t+1 (none at t = T-1)
