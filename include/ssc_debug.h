@@ -25,14 +25,19 @@ int ssc_prof_loop_ms(float* fwd_loop_ms, float* bwd_loop_ms);
 
 /* Named switches between kernel forms that compute the same product (A/B measurements, kernel-form tests).
  * Keys (default; environment variable read once at load):
- *   "large_form"  large products: 0 64-wide kernels | 3 4-wave 128x128 3xBF16 kernel (default) | 2 wave-specialised
- *                 128x128 | 1 by grid size                                                        (SSC_X3B)
+ *   "large_form"  large products: 0 64-wide kernels | 3 4-wave 128x128 3xBF16 kernel | 2 wave-specialised 128x128 |
+ *                 1 by grid size: wave-specialised from 768 workgroups on (default)               (SSC_X3B)
  *   "x3w_skinny"  minibatch products on the wave-specialised 64x256 kernel: 0 | 1 NT+NN (default) | 2 NN only (SSC_X3W_SKINNY)
  *   "x3w_min_n"   ... from this output width on (1024)                                             (SSC_X3W_MIN_N)
  *   "x3_wide" (0), "x3_nbuf" (1), "x3_pf" (2)   forms of the 64-wide 3xBF16 kernel
  *   "wide_min_n"  exact-fp32 kernels: 64x128 tile for M <= 64 from this width on (1024)
  *   "gemm_group"  grouped launches of independent minibatch products (1)                          (SSC_GEMM_GROUP)
  *   "dw_group"    grouped launches of the weight-gradient products (1)                            (SSC_DW_GROUP)
+ *   "x3w_npw" (8), "x3w_big_npw" (8)   producer waves of the wave-specialised 64x256 / 128x128 kernels: 4 | 8
+ *                                                                                    (SSC_X3W_NPW, SSC_X3W_BIG_NPW)
+ *   "x3w_pf"      k-steps in flight in the producers' registers of the 64x256 kernels: 2 (default) | 3   (SSC_X3W_PF)
+ *   "store_wt"    write-through (sc1) output stores of the wave-specialised kernels (1)            (SSC_STORE_WT)
+ *   "tile_gm"     tile rows per group of the XCD-aware tile order (8; 0 = row-major)               (SSC_TILE_GM)
  * Returns SSC_EINVAL for an unknown key. */
 int ssc_debug_set(const char* key, int value);
 int ssc_debug_get(const char* key, int* value);
