@@ -14,25 +14,43 @@
 
 namespace {
 
-// q may arrive as `nslab` split-K partial slabs of the q-projection GEMM ((G,A), ld A each): every wave sums the slabs
-// for the a-range it needs (fixed order) and the r == 0 wave of each row writes the reduced q for the backward pass -
-// this replaces a separate reduce launch per timestep.
+// q may arrive as `nslab` split-K partial slabs of the q-projection GEMM ((G,A), ld A each).  One 256-thread workgroup per
+// (row g, group of RG = 8 regions): the workgroup sums the slabs ONCE into LDS (fixed order; round 1 had every (row, region)
+// wave re-sum them: 36 x 24 KB of L2 reads per row at C2), the first group of each row writes the reduced q for the backward
+// pass, and every wave takes two of the group's regions - their pv rows are requested before the q sum is waited for.
+constexpr int ATTN_RG = 8;
+constexpr int ATTN_MAXA = 4096;   // floats of q kept in LDS
 __global__ __launch_bounds__(256) void attn_logits_kernel(const float* __restrict__ q, int ldq, int nslab, size_t slab_stride,
                                                           float* __restrict__ q_out, int ldqo,
                                                           const float* __restrict__ pv, const float* __restrict__ wa,
                                                           int G, int R, int A, int rows_per_image,
                                                           float* __restrict__ logits) {
-  int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
-  int lane = threadIdx.x & 63;
-  if (wid >= G * R) return;
-  int g = wid / R, r = wid - g * R;
-  int img = g / rows_per_image;
+  __shared__ __attribute__((aligned(16))) float sq[ATTN_MAXA];
+  const int groups = (R + ATTN_RG - 1) / ATTN_RG;
+  const int g = blockIdx.x / groups, grp = blockIdx.x - g * groups;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int img = g / rows_per_image;
   const float* qp = q + (size_t)g * ldq;
-  const float* pp = pv + ((size_t)img * R + r) * A;
-  float s = 0.f;
-  if (((A & 3) == 0) && ((ldq & 3) == 0) && ((ldqo & 3) == 0) && ((slab_stride & 3) == 0) && ssc_aligned16_dev(qp) &&
-      ssc_aligned16_dev(pp) && ssc_aligned16_dev(wa) && ssc_aligned16_dev(q_out)) {
-    for (int a = lane * 4; a < A; a += 256) {
+  const bool vec = ((A & 3) == 0) && ((ldq & 3) == 0) && ((ldqo & 3) == 0) && ((slab_stride & 3) == 0) && ssc_aligned16_dev(qp) &&
+                   ssc_aligned16_dev(pv) && ssc_aligned16_dev(wa) && (!q_out || ssc_aligned16_dev(q_out));
+  // ---- this wave's pv rows are requested first (A <= 1024: 4 float4 per lane and region, 2 regions per wave) ----------------
+  const bool pre_ok = vec && A <= 1024;
+  float4 pre[ATTN_RG / 4][4];
+  if (pre_ok) {
+#pragma unroll
+    for (int j = 0; j < ATTN_RG / 4; ++j) {
+      const int r = min(grp * ATTN_RG + wave + 4 * j, R - 1);
+      const float* pp = pv + ((size_t)img * R + r) * A;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int a = min(lane * 4 + 256 * u, A - 4);
+        pre[j][u] = *reinterpret_cast<const float4*>(pp + a);
+      }
+    }
+  }
+  // ---- q: slab sum into LDS -------------------------------------------------------------------------------------------
+  if (vec) {
+    for (int a = tid * 4; a < A; a += 1024) {
       float4 qv = make_float4(0.f, 0.f, 0.f, 0.f);
       for (int s0 = 0; s0 < nslab; s0 += 8) {  // fixed order, 8 slab loads in flight
         float4 t[8];
@@ -42,21 +60,49 @@ __global__ __launch_bounds__(256) void attn_logits_kernel(const float* __restric
         for (int u = 0; u < 8; ++u)
           if (s0 + u < nslab) { qv.x += t[u].x; qv.y += t[u].y; qv.z += t[u].z; qv.w += t[u].w; }
       }
-      if (q_out && r == 0) *reinterpret_cast<float4*>(q_out + (size_t)g * ldqo + a) = qv;
-      float4 p4 = *reinterpret_cast<const float4*>(pp + a);
-      float4 w4 = *reinterpret_cast<const float4*>(wa + a);
-      s += w4.x * tanhf(qv.x + p4.x) + w4.y * tanhf(qv.y + p4.y) + w4.z * tanhf(qv.z + p4.z) + w4.w * tanhf(qv.w + p4.w);
+      if (q_out && grp == 0) *reinterpret_cast<float4*>(q_out + (size_t)g * ldqo + a) = qv;
+      *reinterpret_cast<float4*>(&sq[a]) = qv;
     }
   } else {
-    for (int a = lane; a < A; a += 64) {
+    for (int a = tid; a < A; a += 256) {
       float qv = qp[a];
       for (int sl = 1; sl < nslab; ++sl) qv += qp[sl * slab_stride + a];
-      if (q_out && r == 0) q_out[(size_t)g * ldqo + a] = qv;
-      s += wa[a] * tanhf(qv + pp[a]);
+      if (q_out && grp == 0) q_out[(size_t)g * ldqo + a] = qv;
+      sq[a] = qv;
     }
   }
-  s = ssc_wave_sum(s);
-  if (lane == 0) logits[wid] = s;
+  __syncthreads();
+  // ---- this wave's regions -----------------------------------------------------------------------------------------------
+#pragma unroll
+  for (int j = 0; j < ATTN_RG / 4; ++j) {
+    const int r = grp * ATTN_RG + wave + 4 * j;
+    if (r >= R) break;
+    const float* pp = pv + ((size_t)img * R + r) * A;
+    float s = 0.f;
+    if (pre_ok) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int a = lane * 4 + 256 * u;
+        if (a < A) {
+          const float4 qv = *reinterpret_cast<const float4*>(&sq[a]);
+          const float4 p4 = pre[j][u];
+          const float4 w4 = *reinterpret_cast<const float4*>(wa + a);
+          s += w4.x * tanhf(qv.x + p4.x) + w4.y * tanhf(qv.y + p4.y) + w4.z * tanhf(qv.z + p4.z) + w4.w * tanhf(qv.w + p4.w);
+        }
+      }
+    } else if (vec) {
+      for (int a = lane * 4; a < A; a += 256) {
+        const float4 qv = *reinterpret_cast<const float4*>(&sq[a]);
+        const float4 p4 = *reinterpret_cast<const float4*>(pp + a);
+        const float4 w4 = *reinterpret_cast<const float4*>(wa + a);
+        s += w4.x * tanhf(qv.x + p4.x) + w4.y * tanhf(qv.y + p4.y) + w4.z * tanhf(qv.z + p4.z) + w4.w * tanhf(qv.w + p4.w);
+      }
+    } else {
+      for (int a = lane; a < A; a += 64) s += wa[a] * tanhf(sq[a] + pp[a]);
+    }
+    s = ssc_wave_sum(s);
+    if (lane == 0) logits[(size_t)g * R + r] = s;
+  }
 }
 
 // masked softmax of one row held across the wave's lanes (R strided by 64), allennlp semantics:
@@ -99,49 +145,71 @@ __device__ __forceinline__ void wave_masked_softmax(const float* __restrict__ l,
 
 constexpr int MAXR_LANE = 4;  // R <= 256
 
-__global__ __launch_bounds__(64) void attn_apply_kernel(const float* __restrict__ logits, const float* __restrict__ mask,
-                                                        const float* __restrict__ feats, int G, int R, int F,
-                                                        int rows_per_image, float* __restrict__ alpha_out,
-                                                        float* __restrict__ att, int ldatt) {
-  __shared__ float sa[64 * MAXR_LANE];
-  int g = blockIdx.y, chunk = blockIdx.x;
-  int lane = threadIdx.x;
-  int img = g / rows_per_image;
+// One 256-thread workgroup per (row, 256-float feature chunk): every wave derives the row's softmax (R is small) and takes a
+// contiguous quarter of the regions - four times the loads in flight of the one-wave form, which kept 2 waves per CU at C2
+// and was bound by latency, not bandwidth (6.4 us for 19 MB); the four partial sums meet in LDS and are added in wave order.
+__global__ __launch_bounds__(256) void attn_apply_kernel(const float* __restrict__ logits, const float* __restrict__ mask,
+                                                         const float* __restrict__ feats, int G, int R, int F,
+                                                         int rows_per_image, float* __restrict__ alpha_out,
+                                                         float* __restrict__ att, int ldatt) {
+  __shared__ float sa[4][64 * MAXR_LANE];
+  __shared__ __attribute__((aligned(16))) float part[4][256];
+  const int g = blockIdx.y, chunk = blockIdx.x;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int img = g / rows_per_image;
   float al[MAXR_LANE];
   wave_masked_softmax<MAXR_LANE>(logits + (size_t)g * R, mask + (size_t)img * R, R, lane, al);
 #pragma unroll
   for (int i = 0; i < MAXR_LANE; ++i) {
     int r = lane + 64 * i;
     if (r < R) {
-      sa[r] = al[i];
-      if (chunk == 0) alpha_out[(size_t)g * R + r] = al[i];
+      sa[wave][r] = al[i];   // a wave only reads its own copy: no workgroup barrier before the loads
+      if (chunk == 0 && wave == 0) alpha_out[(size_t)g * R + r] = al[i];
     }
   }
-  __syncthreads();
+  const int per = (R + 3) / 4;
+  const int r_lo = wave * per, r_hi = min(R, r_lo + per);
   const float* fp = feats + (size_t)img * R * F;
-  int f = chunk * 256 + lane * 4;
-  if (((F & 3) == 0) && ssc_aligned16_dev(fp) && ((ldatt & 3) == 0) && ssc_aligned16_dev(att)) {
+  const bool vec = ((F & 3) == 0) && ssc_aligned16_dev(fp) && ((ldatt & 3) == 0) && ssc_aligned16_dev(att);
+  if (vec) {
+    const int f = chunk * 256 + lane * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (f < F) {
-      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int r0 = 0; r0 < R; r0 += 12) {  // 12 region rows in flight (the kernel is latency-bound), summed in region order
+      for (int r0 = r_lo; r0 < r_hi; r0 += 12) {  // up to 12 region rows in flight per wave, summed in region order
         float4 v[12];
 #pragma unroll
         for (int u = 0; u < 12; ++u) v[u] = *reinterpret_cast<const float4*>(fp + (size_t)min(r0 + u, R - 1) * F + f);
 #pragma unroll
         for (int u = 0; u < 12; ++u) {
-          const float a = (r0 + u < R) ? sa[r0 + u] : 0.f;
+          const float a = (r0 + u < r_hi) ? sa[wave][r0 + u] : 0.f;
           acc.x += a * v[u].x; acc.y += a * v[u].y; acc.z += a * v[u].z; acc.w += a * v[u].w;
         }
       }
-      *reinterpret_cast<float4*>(att + (size_t)g * ldatt + f) = acc;
+    }
+    *reinterpret_cast<float4*>(&part[wave][lane * 4]) = acc;
+    __syncthreads();
+    if (wave == 0 && f < F) {
+      float4 o = *reinterpret_cast<const float4*>(&part[0][lane * 4]);
+#pragma unroll
+      for (int w = 1; w < 4; ++w) {
+        const float4 t = *reinterpret_cast<const float4*>(&part[w][lane * 4]);
+        o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w;
+      }
+      *reinterpret_cast<float4*>(att + (size_t)g * ldatt + f) = o;
     }
   } else {
     for (int k = 0; k < 4; ++k) {
-      int ff = chunk * 256 + k * 64 + lane;
-      if (ff < F) {
-        float acc = 0.f;
-        for (int r = 0; r < R; ++r) acc += sa[r] * fp[(size_t)r * F + ff];
-        att[(size_t)g * ldatt + ff] = acc;
+      const int ff = chunk * 256 + k * 64 + lane;
+      float acc = 0.f;
+      if (ff < F)
+        for (int r = r_lo; r < r_hi; ++r) acc += sa[wave][r] * fp[(size_t)r * F + ff];
+      part[wave][k * 64 + lane] = acc;
+    }
+    __syncthreads();
+    if (wave == 0) {
+      for (int k = 0; k < 4; ++k) {
+        const int ff = chunk * 256 + k * 64 + lane;
+        if (ff < F) att[(size_t)g * ldatt + ff] = ((part[0][k * 64 + lane] + part[1][k * 64 + lane]) + part[2][k * 64 + lane]) + part[3][k * 64 + lane];
       }
     }
   }
@@ -282,8 +350,8 @@ __global__ __launch_bounds__(256) void attn_bwd_apply_kernel(const float* __rest
 
 extern "C" int ssc_attn_logits(const float* q, int ldq, const float* pv, const float* wa, int G, int R, int A,
                                int rows_per_image, float* logits, void* stream) {
-  if (!q || !pv || !wa || !logits || G <= 0 || R <= 0 || A <= 0 || rows_per_image <= 0 || ldq < A) return SSC_EINVAL;
-  SSC_LAUNCH(attn_logits_kernel, dim3(ssc_cdiv(G * R, 4)), dim3(256), 0, (hipStream_t)stream, q, ldq, 1, (size_t)0,
+  if (!q || !pv || !wa || !logits || G <= 0 || R <= 0 || A <= 0 || A > ATTN_MAXA || rows_per_image <= 0 || ldq < A) return SSC_EINVAL;
+  SSC_LAUNCH(attn_logits_kernel, dim3(G * ssc_cdiv(R, ATTN_RG)), dim3(256), 0, (hipStream_t)stream, q, ldq, 1, (size_t)0,
                      (float*)nullptr, 0, pv, wa, G, R, A, rows_per_image, logits);
   SSC_CHECK_LAUNCH();
   return SSC_OK;
@@ -295,7 +363,7 @@ extern "C" int ssc_attn_fwd(const float* q, int ldq, const float* pv, const floa
   if (!mask || !feats || !alpha || !att || !logits || F <= 0 || ldatt < F) return SSC_EINVAL;
   if (R > 64 * MAXR_LANE) return SSC_EINVAL;
   SSC_TRY(ssc_attn_logits(q, ldq, pv, wa, G, R, A, rows_per_image, logits, stream));
-  SSC_LAUNCH(attn_apply_kernel, dim3(ssc_cdiv(F, 256), G), dim3(64), 0, (hipStream_t)stream, logits, mask, feats,
+  SSC_LAUNCH(attn_apply_kernel, dim3(ssc_cdiv(F, 256), G), dim3(256), 0, (hipStream_t)stream, logits, mask, feats,
                      G, R, F, rows_per_image, alpha, att, ldatt);
   SSC_CHECK_LAUNCH();
   return SSC_OK;
@@ -315,11 +383,11 @@ int ssc_attn_fwd_qslabs(const float* qslabs, int nslab, size_t slab_stride, floa
                         const float* wa, const float* mask, const float* feats, int G, int R, int A, int F,
                         int rows_per_image, float* logits, float* alpha, float* att, int ldatt, hipStream_t st) {
   if (!qslabs || nslab < 1 || !q_out || !pv || !wa || !mask || !feats || !alpha || !att || !logits) return SSC_EINVAL;
-  if (G <= 0 || R <= 0 || A <= 0 || F <= 0 || ldatt < F || ldqo < A || R > 64 * MAXR_LANE) return SSC_EINVAL;
-  SSC_LAUNCH(attn_logits_kernel, dim3(ssc_cdiv(G * R, 4)), dim3(256), 0, st, qslabs, A, nslab, slab_stride, q_out,
+  if (G <= 0 || R <= 0 || A <= 0 || A > ATTN_MAXA || F <= 0 || ldatt < F || ldqo < A || R > 64 * MAXR_LANE) return SSC_EINVAL;
+  SSC_LAUNCH(attn_logits_kernel, dim3(G * ssc_cdiv(R, ATTN_RG)), dim3(256), 0, st, qslabs, A, nslab, slab_stride, q_out,
                      ldqo, pv, wa, G, R, A, rows_per_image, logits);
   SSC_CHECK_LAUNCH();
-  SSC_LAUNCH(attn_apply_kernel, dim3(ssc_cdiv(F, 256), G), dim3(64), 0, st, logits, mask, feats, G, R, F,
+  SSC_LAUNCH(attn_apply_kernel, dim3(ssc_cdiv(F, 256), G), dim3(256), 0, st, logits, mask, feats, G, R, F,
                      rows_per_image, alpha, att, ldatt);
   SSC_CHECK_LAUNCH();
   return SSC_OK;
