@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void attn_logits_kernel(const float* __restric
           const float4 qv = *reinterpret_cast<const float4*>(&sq[a]);
           const float4 p4 = pre[j][u];
           const float4 w4 = *reinterpret_cast<const float4*>(wa + a);
-          s += w4.x * tanhf(qv.x + p4.x) + w4.y * tanhf(qv.y + p4.y) + w4.z * tanhf(qv.z + p4.z) + w4.w * tanhf(qv.w + p4.w);
+          s += w4.x * ssc_tanh_fast(qv.x + p4.x) + w4.y * ssc_tanh_fast(qv.y + p4.y) + w4.z * ssc_tanh_fast(qv.z + p4.z) + w4.w * ssc_tanh_fast(qv.w + p4.w);
         }
       }
     } else if (vec) {
@@ -95,10 +95,10 @@ __global__ __launch_bounds__(256) void attn_logits_kernel(const float* __restric
         const float4 qv = *reinterpret_cast<const float4*>(&sq[a]);
         const float4 p4 = *reinterpret_cast<const float4*>(pp + a);
         const float4 w4 = *reinterpret_cast<const float4*>(wa + a);
-        s += w4.x * tanhf(qv.x + p4.x) + w4.y * tanhf(qv.y + p4.y) + w4.z * tanhf(qv.z + p4.z) + w4.w * tanhf(qv.w + p4.w);
+        s += w4.x * ssc_tanh_fast(qv.x + p4.x) + w4.y * ssc_tanh_fast(qv.y + p4.y) + w4.z * ssc_tanh_fast(qv.z + p4.z) + w4.w * ssc_tanh_fast(qv.w + p4.w);
       }
     } else {
-      for (int a = lane; a < A; a += 64) s += wa[a] * tanhf(sq[a] + pp[a]);
+      for (int a = lane; a < A; a += 64) s += wa[a] * ssc_tanh_fast(sq[a] + pp[a]);
     }
     s = ssc_wave_sum(s);
     if (lane == 0) logits[(size_t)g * R + r] = s;
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256) void attn_bwd_apply_kernel(const float* __rest
             const float dl = sdl[r];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-              float u = tanhf(qa[k] + pp[k]);
+              float u = ssc_tanh_fast(qa[k] + pp[k]);
               dp[k] = dl * ww[k] * (1.f - u * u);
               dqa[k] += dp[k];
               dw[k] += dl * u;
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256) void attn_bwd_apply_kernel(const float* __rest
       float qa = q[(size_t)g * ldq + a], w = wa[a];
       for (int r = wave; r < R; r += 4) {
         size_t off = ((size_t)g * R + r) * A + a;
-        float u = tanhf(qa + pv[off]);
+        float u = ssc_tanh_fast(qa + pv[off]);
         float dl = sdl[r];
         float dpre = dl * w * (1.f - u * u);
         dpv_acc[off] += dpre;

@@ -149,10 +149,20 @@ __device__ __forceinline__ const float* row_prepare(const float* __restrict__ ro
   lse = 0.f;
   if (!NORM) return row;
   float mx = -INFINITY;
-  for (int v = threadIdx.x; v < V; v += blockDim.x) {
-    const float x = row[v];
-    if (staged) srow[v] = x;
-    mx = fmaxf(mx, x);
+  // thread t owns v = t, t + 256, ... (the same assignment and order as log_softmax_kernel: bit-identical sums); its loads are
+  // issued eight at a time - one at a time, this 40 KB row cost ~40 dependent memory round trips per thread
+  for (int v0 = threadIdx.x; v0 < V; v0 += 8 * blockDim.x) {
+    float x[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) x[u] = row[min(v0 + u * (int)blockDim.x, V - 1)];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int v = v0 + u * (int)blockDim.x;
+      if (v < V) {
+        if (staged) srow[v] = x[u];
+        mx = fmaxf(mx, x[u]);
+      }
+    }
   }
   mx = dec_block_reduce(mx, shr, true);   // (its barriers also publish srow)
   const float* src = staged ? srow : row;

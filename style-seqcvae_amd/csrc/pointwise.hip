@@ -1,6 +1,8 @@
 // Elementwise / small-reduction kernels of the var_updown hot path (gfx950, wave64).
 // All of them are HBM-bound byte movers; they are written for coalesced access along the contiguous
 // axis and 64-lane shuffle reductions.  Reference citations are on the C entry points in ssc.h.
+#include <type_traits>
+
 #include "ssc_common.h"
 
 thread_local int ssc_tls_hip_error = 0;
@@ -103,20 +105,28 @@ __global__ void lstm_fwd_kernel(const ssc_lstm_fwd_desc d) {
   const float cp = d.c_prev ? d.c_prev[(size_t)b * d.ld_cprev + j] : 0.f;
   float pre[4] = {0.f, 0.f, 0.f, 0.f};
   // split-K slabs: summed in index order per gate (a `v += load` loop with a dynamic trip count would serialise one
-  // memory latency per slab)
-  for (int s0 = 0; s0 < d.nslab; s0 += 16) {
-    float t[4][16];
+  // memory latency per slab), U loads per gate in flight.  U follows the slab count: the decode step hands ONE slab (the gate
+  // product of 5000 rows is not split) and a fixed batch of 16 made it issue 64 loads per cell for the 4 it needs.
+  auto add_slabs = [&](auto uc) __attribute__((always_inline)) {
+    constexpr int U = decltype(uc)::value;
+    for (int s0 = 0; s0 < d.nslab; s0 += U) {
+      float t[4][U];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const float* sp = d.slabs + (size_t)min(s0 + u, d.nslab - 1) * d.slab_stride + (size_t)b * H4 + j;
+      for (int u = 0; u < U; ++u) {
+        const float* sp = d.slabs + (size_t)min(s0 + u, d.nslab - 1) * d.slab_stride + (size_t)b * H4 + j;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) t[g][u] = sp[g * H];
+        for (int g = 0; g < 4; ++g) t[g][u] = sp[g * H];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) pre[g] += (s0 + u < d.nslab) ? t[g][u] : 0.f;
     }
-#pragma unroll
-    for (int u = 0; u < 16; ++u)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) pre[g] += (s0 + u < d.nslab) ? t[g][u] : 0.f;
-  }
+  };
+  if (d.nslab <= 1) add_slabs(std::integral_constant<int, 1>{});
+  else if (d.nslab <= 4) add_slabs(std::integral_constant<int, 4>{});
+  else if (d.nslab <= 8) add_slabs(std::integral_constant<int, 8>{});
+  else add_slabs(std::integral_constant<int, 16>{});
 #pragma unroll
   for (int g = 0; g < 4; ++g) {  // absent terms add +0.f, which leaves every value unchanged
     float v = pre[g];
@@ -280,20 +290,21 @@ __global__ void lstm_bwd_kernel(const ssc_lstm_bwd_desc d) {
   const float cn = d.c_new[(size_t)b * d.ld_cnew + j];
   float dh = d.dh ? d.dh[(size_t)b * d.ld_dh + j] : 0.f;
   if (d.dh2) dh += d.dh2[(size_t)b * d.ld_dh2 + j];
-  for (int s0 = 0; s0 < d.nA; s0 += 16) {  // split-K slabs of the producing GEMMs, fixed order, 16 loads in flight
-    float t[16];
+  // split-K slabs of the producing GEMMs, fixed order, up to 16 loads in flight (the batch follows the slab count)
+  auto add_slabs = [&](const float* slabs, int n, size_t stride, auto uc) __attribute__((always_inline)) {
+    constexpr int U = decltype(uc)::value;
+    for (int s0 = 0; s0 < n; s0 += U) {
+      float t[U];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) t[u] = d.slabsA[(size_t)min(s0 + u, d.nA - 1) * d.strideA + (size_t)b * H + j];
+      for (int u = 0; u < U; ++u) t[u] = slabs[(size_t)min(s0 + u, n - 1) * stride + (size_t)b * H + j];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) dh += (s0 + u < d.nA) ? t[u] : 0.f;
-  }
-  for (int s0 = 0; s0 < d.nB; s0 += 16) {
-    float t[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) t[u] = d.slabsB[(size_t)min(s0 + u, d.nB - 1) * d.strideB + (size_t)b * H + j];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) dh += (s0 + u < d.nB) ? t[u] : 0.f;
-  }
+      for (int u = 0; u < U; ++u) dh += (s0 + u < n) ? t[u] : 0.f;
+    }
+  };
+  if (d.nA > 8) add_slabs(d.slabsA, d.nA, d.strideA, std::integral_constant<int, 16>{});
+  else if (d.nA > 0) add_slabs(d.slabsA, d.nA, d.strideA, std::integral_constant<int, 8>{});
+  if (d.nB > 8) add_slabs(d.slabsB, d.nB, d.strideB, std::integral_constant<int, 16>{});
+  else if (d.nB > 0) add_slabs(d.slabsB, d.nB, d.strideB, std::integral_constant<int, 8>{});
   float tc = tanhf(cn);
   float d_o = dh * tc;
   float dc = dcin + dh * og * (1.f - tc * tc);

@@ -50,6 +50,13 @@ __device__ __forceinline__ float ssc_wave_max(float v) {
   return v;
 }
 __device__ __forceinline__ float ssc_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+// tanh x = 1 - 2 / (1 + e^{2x}) on the hardware exp2 / rcp (v_exp_f32, v_rcp_f32: ~1 ulp each): absolute error < 3e-7 everywhere,
+// exact limits (+-1) for large |x|.  Used where a kernel is bound by its tanh count (attention logits: G*R*A per step - 138 M
+// at the decode shape, ~25 instructions each with the library tanhf); forward and backward of the attention use the SAME function.
+__device__ __forceinline__ float ssc_tanh_fast(float x) {
+  const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);   // e^{2x}
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e);
+}
 
 // internal cross-TU entry points (not part of the C ABI)
 int ssc_gemm_slabs(const ssc_gemm_desc* d, int splits, float* slabs, hipStream_t st);  // partial slabs only
