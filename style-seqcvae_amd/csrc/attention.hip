@@ -145,71 +145,52 @@ __device__ __forceinline__ void wave_masked_softmax(const float* __restrict__ l,
 
 constexpr int MAXR_LANE = 4;  // R <= 256
 
-// One 256-thread workgroup per (row, 256-float feature chunk): every wave derives the row's softmax (R is small) and takes a
-// contiguous quarter of the regions - four times the loads in flight of the one-wave form, which kept 2 waves per CU at C2
-// and was bound by latency, not bandwidth (6.4 us for 19 MB); the four partial sums meet in LDS and are added in wave order.
-__global__ __launch_bounds__(256) void attn_apply_kernel(const float* __restrict__ logits, const float* __restrict__ mask,
-                                                         const float* __restrict__ feats, int G, int R, int F,
-                                                         int rows_per_image, float* __restrict__ alpha_out,
-                                                         float* __restrict__ att, int ldatt) {
-  __shared__ float sa[4][64 * MAXR_LANE];
-  __shared__ __attribute__((aligned(16))) float part[4][256];
-  const int g = blockIdx.y, chunk = blockIdx.x;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int img = g / rows_per_image;
+// One wave per (row, 256-float feature chunk).  (A four-wave form - regions split over the waves of a 256-thread workgroup,
+// partial sums through LDS - was measured in round 2: no gain at the train shape, 6.4 us either way, and 93 vs 60 us at the
+// decode shape, where the kernel is bound by L2 bandwidth, not latency.)
+__global__ __launch_bounds__(64) void attn_apply_kernel(const float* __restrict__ logits, const float* __restrict__ mask,
+                                                        const float* __restrict__ feats, int G, int R, int F,
+                                                        int rows_per_image, float* __restrict__ alpha_out,
+                                                        float* __restrict__ att, int ldatt) {
+  __shared__ float sa[64 * MAXR_LANE];
+  int g = blockIdx.y, chunk = blockIdx.x;
+  int lane = threadIdx.x;
+  int img = g / rows_per_image;
   float al[MAXR_LANE];
   wave_masked_softmax<MAXR_LANE>(logits + (size_t)g * R, mask + (size_t)img * R, R, lane, al);
 #pragma unroll
   for (int i = 0; i < MAXR_LANE; ++i) {
     int r = lane + 64 * i;
     if (r < R) {
-      sa[wave][r] = al[i];   // a wave only reads its own copy: no workgroup barrier before the loads
-      if (chunk == 0 && wave == 0) alpha_out[(size_t)g * R + r] = al[i];
+      sa[r] = al[i];
+      if (chunk == 0) alpha_out[(size_t)g * R + r] = al[i];
     }
   }
-  const int per = (R + 3) / 4;
-  const int r_lo = wave * per, r_hi = min(R, r_lo + per);
+  __syncthreads();
   const float* fp = feats + (size_t)img * R * F;
-  const bool vec = ((F & 3) == 0) && ssc_aligned16_dev(fp) && ((ldatt & 3) == 0) && ssc_aligned16_dev(att);
-  if (vec) {
-    const int f = chunk * 256 + lane * 4;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  int f = chunk * 256 + lane * 4;
+  if (((F & 3) == 0) && ssc_aligned16_dev(fp) && ((ldatt & 3) == 0) && ssc_aligned16_dev(att)) {
     if (f < F) {
-      for (int r0 = r_lo; r0 < r_hi; r0 += 12) {  // up to 12 region rows in flight per wave, summed in region order
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int r0 = 0; r0 < R; r0 += 12) {  // 12 region rows in flight (the kernel is latency-bound), summed in region order
         float4 v[12];
 #pragma unroll
         for (int u = 0; u < 12; ++u) v[u] = *reinterpret_cast<const float4*>(fp + (size_t)min(r0 + u, R - 1) * F + f);
 #pragma unroll
         for (int u = 0; u < 12; ++u) {
-          const float a = (r0 + u < r_hi) ? sa[wave][r0 + u] : 0.f;
+          const float a = (r0 + u < R) ? sa[r0 + u] : 0.f;
           acc.x += a * v[u].x; acc.y += a * v[u].y; acc.z += a * v[u].z; acc.w += a * v[u].w;
         }
       }
-    }
-    *reinterpret_cast<float4*>(&part[wave][lane * 4]) = acc;
-    __syncthreads();
-    if (wave == 0 && f < F) {
-      float4 o = *reinterpret_cast<const float4*>(&part[0][lane * 4]);
-#pragma unroll
-      for (int w = 1; w < 4; ++w) {
-        const float4 t = *reinterpret_cast<const float4*>(&part[w][lane * 4]);
-        o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w;
-      }
-      *reinterpret_cast<float4*>(att + (size_t)g * ldatt + f) = o;
+      *reinterpret_cast<float4*>(att + (size_t)g * ldatt + f) = acc;
     }
   } else {
     for (int k = 0; k < 4; ++k) {
-      const int ff = chunk * 256 + k * 64 + lane;
-      float acc = 0.f;
-      if (ff < F)
-        for (int r = r_lo; r < r_hi; ++r) acc += sa[wave][r] * fp[(size_t)r * F + ff];
-      part[wave][k * 64 + lane] = acc;
-    }
-    __syncthreads();
-    if (wave == 0) {
-      for (int k = 0; k < 4; ++k) {
-        const int ff = chunk * 256 + k * 64 + lane;
-        if (ff < F) att[(size_t)g * ldatt + ff] = ((part[0][k * 64 + lane] + part[1][k * 64 + lane]) + part[2][k * 64 + lane]) + part[3][k * 64 + lane];
+      int ff = chunk * 256 + k * 64 + lane;
+      if (ff < F) {
+        float acc = 0.f;
+        for (int r = 0; r < R; ++r) acc += sa[r] * fp[(size_t)r * F + ff];
+        att[(size_t)g * ldatt + ff] = acc;
       }
     }
   }
@@ -363,7 +344,7 @@ extern "C" int ssc_attn_fwd(const float* q, int ldq, const float* pv, const floa
   if (!mask || !feats || !alpha || !att || !logits || F <= 0 || ldatt < F) return SSC_EINVAL;
   if (R > 64 * MAXR_LANE) return SSC_EINVAL;
   SSC_TRY(ssc_attn_logits(q, ldq, pv, wa, G, R, A, rows_per_image, logits, stream));
-  SSC_LAUNCH(attn_apply_kernel, dim3(ssc_cdiv(F, 256), G), dim3(256), 0, (hipStream_t)stream, logits, mask, feats,
+  SSC_LAUNCH(attn_apply_kernel, dim3(ssc_cdiv(F, 256), G), dim3(64), 0, (hipStream_t)stream, logits, mask, feats,
                      G, R, F, rows_per_image, alpha, att, ldatt);
   SSC_CHECK_LAUNCH();
   return SSC_OK;
@@ -387,7 +368,7 @@ int ssc_attn_fwd_qslabs(const float* qslabs, int nslab, size_t slab_stride, floa
   SSC_LAUNCH(attn_logits_kernel, dim3(G * ssc_cdiv(R, ATTN_RG)), dim3(256), 0, st, qslabs, A, nslab, slab_stride, q_out,
                      ldqo, pv, wa, G, R, A, rows_per_image, logits);
   SSC_CHECK_LAUNCH();
-  SSC_LAUNCH(attn_apply_kernel, dim3(ssc_cdiv(F, 256), G), dim3(256), 0, st, logits, mask, feats, G, R, F,
+  SSC_LAUNCH(attn_apply_kernel, dim3(ssc_cdiv(F, 256), G), dim3(64), 0, st, logits, mask, feats, G, R, F,
                      rows_per_image, alpha, att, ldatt);
   SSC_CHECK_LAUNCH();
   return SSC_OK;
