@@ -10,8 +10,8 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python3 $ROOT/bench.py --steps 5 --warmup 2 --timed-only"
-CMD2="python3 $ROOT/bench.py --steps 2 --warmup 1 --timed-only"
+CMD="python3 $ROOT/bench.py --steps 5 --warmup 2 --timed-only --prewarm 0"
+CMD2="python3 $ROOT/bench.py --steps 2 --warmup 1 --timed-only --prewarm 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $CMD > $OUT/stats.log 2>&1
 echo "stats pass done"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $CMD2 > $OUT/fetch.log 2>&1
