@@ -110,7 +110,7 @@ int ssc_embed_scatter_add(float* dtable, int ldt, const int64_t* ids, int n, int
  * LSTM cell epilogue: torch.nn.LSTMCell pointwise part (gate order i,f,g,o), fused with the split-K
  * slab reduction, the hoisted time-invariant gate terms, both biases and the rank-1 sentiment
  * column (updown_cell.py:146-148,192-194,227-229).
- *   pre[b,n] = sum_{s<nslab} slabs[s][b,n] + add0[b,n] + add1[row1(b),n] + b_ih[n] + b_hh[n]
+ *   pre[b,n] = sum_{s<nslab} slabs[s][b,n] + add0[row0(b),n] + add1[row1(b),n] + b_ih[n] + b_hh[n]
  *              + sent[b]*wcol[n*ldwcol]
  *   gates_out (B,4H) = activated (i,f,g,o);  c_out = f*c_prev + i*g;  h_out = o*tanh(c_out)
  * add1 is indexed by b / rows_per_add1 (decode: per-image hoisted term).  Any optional pointer may be 0.
@@ -126,6 +126,8 @@ typedef struct {
   float* gates_out;            /* (B,4H) activated, ld 4H; may be 0 */
   float* c_out; int ld_cout;
   float* h_out; int ld_hout;
+  const int64_t* add0_rows;    /* optional: add0 is indexed by add0_rows[b] instead of b (decode: a per-token table of the
+                                * embedding's gate contribution, row = the beam's last token) */
 } ssc_lstm_fwd_desc;
 int ssc_lstm_fwd(const ssc_lstm_fwd_desc* d, void* stream);
 /* The same with one more addend formed inside the kernel: pre[b,n] += z[b,:Z] . wz[n,:Z]  (z (B,Z) ld ldz; wz (4H,Z) ld ldwz;
@@ -350,6 +352,9 @@ typedef struct {
   float* alpha;              /* (G,R) */
   float* log_probs;          /* (G,V) ld V; NULL: stop after the cell (UpDownCell.forward) */
   int raw_logits;            /* 1: leave the vocabulary logits un-normalised in log_probs (for ssc_beam_*_logits) */
+  int emb_override;          /* 1: p->emb of THIS call is not the embedding ssc_decode_prepare saw (a caller that hands token
+                              * embeddings instead of ids, UpDownCell.forward): the per-token gate table of the image context
+                              * is not used, the embedding goes through the gate product */
 } ssc_decode_step_desc;
 size_t ssc_decode_step_workspace_bytes(const ssc_model_cfg* cfg, int G, int R);
 int ssc_decode_step(const ssc_model_cfg* cfg, const ssc_params* p, const ssc_decode_step_desc* d, void* workspace,

@@ -18,9 +18,15 @@ inline size_t r4(size_t x) { return (x + 3) & ~(size_t)3; }
 inline size_t r64(size_t x) { return (x + 63) & ~(size_t)63; }
 
 struct ImgLayout {
-  size_t mask, avg, pv, ga_avg, wsum_att, wsum_dec, wz, scratch, scratch_floats, total;
+  size_t mask, avg, pv, ga_avg, wsum_att, wsum_dec, wz, emb_gates, scratch, scratch_floats, total;
   int Fp, Hp, Zp;
+  bool token_table;   // emb_gates holds the (V, 4H) table emb . W_ih^att[:, :E]^T
 };
+// The embedding's contribution to the attention LSTM gates depends on the token only: from this many images per call on it is
+// formed once per call for the whole vocabulary ((V, E) x (E, 4H): 96 GFLOP at C4, 0.5 ms) and the cell kernel picks the row
+// of the beam's last token (ssc_lstm_fwd_desc.add0_rows), instead of a K = E segment of the gate product in every step
+// (5000 x 4800 x 1000 per step at C4: 0.25 ms x 20 steps).  Below it (a handful of rows per step) the segment is cheaper.
+constexpr int DEC_TOKEN_TABLE_MIN_IMAGES = 8;
 ImgLayout img_layout(const ssc_model_cfg* c, int nimg, int R) {
   ImgLayout l;
   l.Fp = (int)r4(c->F);
@@ -36,6 +42,8 @@ ImgLayout img_layout(const ssc_model_cfg* c, int nimg, int R) {
   l.wsum_att = o; o += r64((size_t)4 * c->H * l.Hp);
   l.wsum_dec = o; o += r64((size_t)4 * c->H * l.Hp);
   l.wz = o; o += r64((size_t)4 * c->H * l.Zp);
+  l.token_table = nimg >= DEC_TOKEN_TABLE_MIN_IMAGES;
+  l.emb_gates = o; o += r64(l.token_table ? (size_t)c->V * 4 * c->H : 0);
   size_t a = (size_t)nimg * R * c->A, b = (size_t)nimg * 4 * c->H;
   l.scratch_floats = 33 * (a > b ? a : b);
   l.scratch = o; o += r64(l.scratch_floats);
@@ -321,6 +329,9 @@ extern "C" int ssc_decode_prepare(const ssc_model_cfg* cfg, const ssc_params* p,
   SSC_TRY(gemm_nt(st, W + l.scratch, l.scratch_floats, {{feats, F, p->wv, p->ld_wv, F}}, nimg * R, A, W + l.pv, A));
   SSC_TRY(gemm_nt(st, W + l.scratch, l.scratch_floats, {{W + l.avg, F, p->att_w_ih + E, p->ld_att_w_ih, F}}, nimg, H4,
                   W + l.ga_avg, H4));
+  if (l.token_table)
+    SSC_TRY(gemm_nt(st, W + l.scratch, l.scratch_floats, {{p->emb, p->ld_emb, p->att_w_ih, p->ld_att_w_ih, E}}, cfg->V, H4,
+                    W + l.emb_gates, H4));
   {
     const int H = cfg->H, Z = cfg->Z, S = cfg->S;
     dim3 grid(ssc_cdiv(H, 256), H4);
@@ -363,13 +374,19 @@ extern "C" int ssc_decode_step(const ssc_model_cfg* cfg, const ssc_params* p, co
   int ns = 0;
 
   // embedding + attention LSTM (updown_captioner.py:430, updown_cell.py:143-148)
-  SSC_TRY(ssc_embed_gather(p->emb, p->ld_emb, d->tokens, G, E, W + l.emb, l.Ep, st));
   {
     const float* wr = p->att_w_ih + E + F;
-    SSC_TRY(gemm_slabs(st, slabs, l.slab_floats,
-                       {{W + l.emb, l.Ep, p->att_w_ih, p->ld_att_w_ih, E}, {d->h1, H, I + il.wsum_att, il.Hp, H},
-                        {d->hd, H, wr + H, p->ld_att_w_ih, H}}, G, H4, &ns));
     ssc_lstm_fwd_desc f{};
+    if (il.token_table && !d->emb_override) {   // the embedding's gate term comes from the per-token table, row = the beam's last token
+      SSC_TRY(gemm_slabs(st, slabs, l.slab_floats, {{d->h1, H, I + il.wsum_att, il.Hp, H}, {d->hd, H, wr + H, p->ld_att_w_ih, H}}, G, H4,
+                         &ns));
+      f.add0 = I + il.emb_gates; f.ld_add0 = H4; f.add0_rows = d->tokens;
+    } else {
+      SSC_TRY(ssc_embed_gather(p->emb, p->ld_emb, d->tokens, G, E, W + l.emb, l.Ep, st));
+      SSC_TRY(gemm_slabs(st, slabs, l.slab_floats,
+                         {{W + l.emb, l.Ep, p->att_w_ih, p->ld_att_w_ih, E}, {d->h1, H, I + il.wsum_att, il.Hp, H},
+                          {d->hd, H, wr + H, p->ld_att_w_ih, H}}, G, H4, &ns));
+    }
     f.B = G; f.H = H;
     f.slabs = slabs; f.nslab = ns; f.slab_stride = (size_t)G * H4;
     f.add1 = I + il.ga_avg; f.ld_add1 = H4; f.rows_per_add1 = rpi;

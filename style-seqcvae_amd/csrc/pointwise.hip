@@ -95,7 +95,7 @@ __global__ void lstm_fwd_kernel(const ssc_lstm_fwd_desc d) {
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const int n = g * H + j;
-    a0[g] = d.add0 ? d.add0[(size_t)b * d.ld_add0 + n] : 0.f;
+    a0[g] = d.add0 ? d.add0[(size_t)(d.add0_rows ? d.add0_rows[b] : (int64_t)b) * d.ld_add0 + n] : 0.f;
     a1[g] = d.add1 ? d.add1[(size_t)(b / d.rows_per_add1) * d.ld_add1 + n] : 0.f;
     bi[g] = d.b_ih ? d.b_ih[n] : 0.f;
     bh[g] = d.b_hh ? d.b_hh[n] : 0.f;
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(512, 2) void lstm_fwd_z_kernel(const ssc_lstm_fwd_d
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const int n = g * H + jc;
-    a0[g] = d.add0 ? d.add0[(size_t)bc * d.ld_add0 + n] : 0.f;
+    a0[g] = d.add0 ? d.add0[(size_t)(d.add0_rows ? d.add0_rows[bc] : (int64_t)bc) * d.ld_add0 + n] : 0.f;
     a1[g] = d.add1 ? d.add1[(size_t)(bc / d.rows_per_add1) * d.ld_add1 + n] : 0.f;
     bi[g] = d.b_ih ? d.b_ih[n] : 0.f;
     bh[g] = d.b_hh ? d.b_hh[n] : 0.f;

@@ -79,7 +79,8 @@ class DecodeEngine:
                                    st["h1"].data_ptr(), st["c1"].data_ptr(), st["h_decoder"].data_ptr(),
                                    st["c_decoder"].data_ptr(), new["h1"].data_ptr(), new["c1"].data_ptr(),
                                    new["h_decoder"].data_ptr(), new["c_decoder"].data_ptr(), alpha.data_ptr(),
-                                   lp.data_ptr() if lp is not None else None, 1 if raw_logits else 0)
+                                   lp.data_ptr() if lp is not None else None, 1 if raw_logits else 0,
+                                   1 if emb_table is not None else 0)
         p = self._params()
         if emb_table is not None:  # rows of `emb_table` are the token embeddings themselves (UpDownCell.forward API)
             p.emb = emb_table.data_ptr()

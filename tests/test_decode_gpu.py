@@ -298,3 +298,52 @@ def test_standalone_attention_module_forward_matches_float64():
     assert got.shape == (B, R) and maxdiff(got, ref(mask)) < 1e-5
     assert float(got[1, 5:].abs().max()) == 0.0
     assert maxdiff(att(q.cuda(), feats.cuda()), ref(None)) < 1e-5
+
+
+def test_decode_step_token_table_equals_embedding_segment():
+    """From 8 images per call on ssc_decode_prepare forms the embedding's gate contribution for the whole vocabulary once and the
+    attention-LSTM cell picks the row of each beam's last token (ssc_lstm_fwd_desc.add0_rows); below that the embedding is a
+    K = E segment of the gate product (updown_captioner.py:430, updown_cell.py:143-148).  The same 8 images decoded as one call
+    (table) and as two calls of 4 (segment) give the same log-probs / states / attention weights to fp32 level."""
+    from ssc_runtime.vocab import Vocabulary
+    from var_updown.models import UpDownCaptioner
+    V, F, E, H, A, Z, R = 300, 64, 40, 48, 24, 8, 5
+    torch.manual_seed(5)
+    m = UpDownCaptioner(Vocabulary.synthetic(V), image_feature_size=F, embedding_size=E, hidden_size=H,
+                        attention_projection_size=A, max_caption_length=8, beam_size=3, z_space=Z, prior_std=1.0,
+                        simple_vae=False, latent_embedding="glove", sentiment_vae=1, senti_prior_multip=0.5,
+                        device=torch.device("cuda")).to("cuda")
+    m.eval()
+    m._engine()
+    dec = m._dec
+    g = torch.Generator().manual_seed(6)
+    nimg, rpi = 8, 6
+    G = nimg * rpi
+    feats = torch.randn(nimg, R, F, generator=g).cuda()
+    tok, tok2 = torch.randint(0, V, (G,), generator=g).cuda(), torch.randint(0, V, (G,), generator=g).cuda()
+    sent = torch.randint(-1, 2, (G,), generator=g).float().cuda()
+    eps1, eps2 = torch.randn(G, Z, generator=g).cuda(), torch.randn(G, Z, generator=g).cuda()
+
+    def run(lo, hi):
+        ctx = dec.prepare(feats[lo:hi].contiguous())
+        r = slice(lo * rpi, hi * rpi)
+        lp1, st1, a1 = dec.step(ctx, tok[r].contiguous(), None, sent[r].contiguous(), eps1[r].contiguous())
+        lp2, st2, a2 = dec.step(ctx, tok2[r].contiguous(), st1, sent[r].contiguous(), eps2[r].contiguous())
+        return lp2.clone(), {k: v.clone() for k, v in st2.items()}, a2.clone()
+
+    whole = run(0, 8)                       # table
+    halves = [run(0, 4), run(4, 8)]         # segment
+    lp = torch.cat([h[0] for h in halves])
+    al = torch.cat([h[2] for h in halves])
+    assert maxdiff(whole[0], lp) < 2e-5 and maxdiff(whole[2], al) < 1e-6
+    for k in whole[1]:
+        assert maxdiff(whole[1][k], torch.cat([h[1][k] for h in halves])) < 2e-6, k
+    # a caller that hands token EMBEDDINGS (UpDownCell.forward) overrides p->emb for the call: the table of the image context
+    # (built from the model's own embedding) must not be used then
+    ctx = dec.prepare(feats)
+    _, st_ids, a_ids = dec.step(ctx, tok, None, sent, eps1, want_log_probs=False)
+    emb_w = dict(m.named_parameters())["_embedding_layer.weight"].detach()
+    _, st_emb, a_emb = dec._step_from_embedding(ctx, emb_w[tok], None, sent, eps1)
+    assert maxdiff(a_ids, a_emb) < 1e-6
+    for k in ("h1", "c1", "h_decoder", "c_decoder"):
+        assert maxdiff(st_ids[k], st_emb[k]) < 2e-6, k
