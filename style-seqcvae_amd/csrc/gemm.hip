@@ -1613,7 +1613,7 @@ inline bool use_x3(const ssc_gemm_desc* d, bool vec) { return gemm_mode() == 1 &
 // They select between kernel forms that compute the same product; none is part of the product ABI.
 // Large products (M, N >= 512): 0 = 64x64 kernels, 3 = always the 4-wave 128x128 3xBF16 kernel, 2 = always its wave-specialised
 // form, 1 (default since round 2) = by grid size: wave-specialised from 768 workgroups on (three rounds of the chip: decode
-// +13 % tokens/s), 4-wave below (two workgroups per CU even out grids of one or two rounds).  History: round 1 kept the
+// +8 % tokens/s, alternating same-box A/B), 4-wave below (two workgroups per CU even out grids of one or two rounds).  History: round 1 kept the
 // wave-specialised form opt-in after ONE unexplained GPU memory fault in a long decode run.  Since then its loop
 // structure, addressing and register discipline were rebuilt (branch-free staged loads, uniform loops, 12 waves, scalar bases)
 // under an exact ISA gate, the same kernel family has run the grouped weight gradients of every train step, and the 3000-image
