@@ -301,7 +301,7 @@ def main():
         eng.train_step(feats, caps, senti, eps, lr=lr, kld_weight=750.0, momentum=0.9, weight_decay=0.001,
                        max_norm=12.5, decoder_frozen=False)
 
-    if dres is None:   # no decode leg ran before: bring the GPU out of idle first (same count on every rank: the steps all-reduce)
+    if args.timed_only or args.no_decode:   # no decode leg ran before: bring the GPU out of idle first (same count on every rank: the steps all-reduce)
         for i in range(args.prewarm):
             step(i)
         torch.cuda.synchronize()
