@@ -155,6 +155,9 @@ typedef struct {
   const float* slabsB; int nB; size_t strideB;
 } ssc_lstm_bwd_desc;
 int ssc_lstm_bwd(const ssc_lstm_bwd_desc* d, void* stream);
+/* The same with one more addend of dh formed inside the kernel: dh[b,j] += sum_k x[b,k] w[k,j]  (x (B,K) ld ldx; w (K,H) ld ldw;
+ * exact-fp32 MFMA).  BPTT of the encoder LSTM: x = (dmu | dlv), w = [W_mu ; W_lv] (fc_mean / fc_log_var, updown_cell.py:196-197). */
+int ssc_lstm_bwd_x(const ssc_lstm_bwd_desc* d, const float* x, int ldx, const float* w, int ldw, int K, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Bottom-up top-down attention step: BottomUpTopDownAttention.forward after the q projection

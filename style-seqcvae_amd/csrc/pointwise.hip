@@ -321,6 +321,108 @@ __global__ void lstm_bwd_kernel(const ssc_lstm_bwd_desc d) {
   }
 }
 
+// lstm_bwd_kernel plus one more addend of dh formed IN the kernel: dh[b,j] += sum_k x[b,k] w[k,j]  (x (B,K) ld ldx; w (K,H) ld ldw,
+// j-contiguous).  Used for the encoder LSTM in BPTT: its dh is the carried g_he' plus (dmu | dlv) . [W_mu ; W_lv]  (K = 2Z = 256,
+// updown_cell.py:196-197 backward) - as its own split-K product that was a 10 us launch on the step's dependency chain for 1.2 MB
+// of weights.  Same shape as lstm_fwd_z_kernel: one 512-thread workgroup per (32 batch rows x 16 hidden units), one cell per
+// thread, the x rows and the (K x 16) weight slice go through LDS images to the exact-fp32 16x16x4 MFMA (waves 0 and 1).
+__global__ __launch_bounds__(512, 2) void lstm_bwd_x_kernel(const ssc_lstm_bwd_desc d, const float* __restrict__ x, int ldx,
+                                                            const float* __restrict__ w, int ldw, int K) {
+  constexpr int TB = 32, TJ = 16, KT = 256, LD = KT + 4, NT = 512;
+  __shared__ __attribute__((aligned(16))) float sx[TB * LD];   // x[b0 + r, k]
+  __shared__ __attribute__((aligned(16))) float sw[TJ * LD];   // w[k, j0 + jj] stored [jj][k]
+  __shared__ float st[TB * 17];                                // product tile [row b][jj]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int H = d.H, H4 = 4 * d.H;
+  const int j0 = blockIdx.x * TJ, b0 = blockIdx.y * TB;
+  const int bb = tid >> 4, jj = tid & 15;
+  const int b = b0 + bb, j = j0 + jj;
+  const bool live = b < d.B && j < H;
+  const int bc = live ? b : 0, jc = live ? j : 0;   // clamped: every thread runs the same loads
+  float xr[TB * KT / NT], wr[TJ * KT / NT];
+  auto request_tiles = [&](int k0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < TB * KT / NT; ++u) {   // 16 floats per thread, coalesced along k
+      const int idx = tid + NT * u, row = idx / KT, k = k0 + idx % KT, xb = b0 + row;
+      xr[u] = (xb < d.B && k < K) ? x[(size_t)xb * ldx + k] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < TJ * KT / NT; ++u) {   // 8 floats per thread: 16 consecutive threads read 64 contiguous bytes of a k-row
+      const int idx = tid + NT * u, k = k0 + idx / TJ, wj = j0 + idx % TJ;
+      wr[u] = (wj < H && k < K) ? w[(size_t)k * ldw + wj] : 0.f;
+    }
+  };
+  request_tiles(0);
+  // ---- the cell's own operands (as in lstm_bwd_kernel) -------------------------------------------------------------------------
+  const float dcin = d.dc_in ? d.dc_in[(size_t)bc * d.ld_dcin + jc] : 0.f;
+  const float* g = d.gates + (size_t)bc * H4 + jc;
+  const float ig = g[0], fg = g[H], gg = g[2 * H], og = g[3 * H];
+  const float cp = d.c_prev[(size_t)bc * d.ld_cprev + jc];
+  const float cn = d.c_new[(size_t)bc * d.ld_cnew + jc];
+  float dh = d.dh ? d.dh[(size_t)bc * d.ld_dh + jc] : 0.f;
+  if (d.dh2) dh += d.dh2[(size_t)bc * d.ld_dh2 + jc];
+  auto add_slabs = [&](const float* slabs, int n, size_t stride, auto uc) __attribute__((always_inline)) {
+    constexpr int U = decltype(uc)::value;
+    for (int s0 = 0; s0 < n; s0 += U) {
+      float t[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) t[u] = slabs[(size_t)min(s0 + u, n - 1) * stride + (size_t)bc * H + jc];
+#pragma unroll
+      for (int u = 0; u < U; ++u) dh += (s0 + u < n) ? t[u] : 0.f;
+    }
+  };
+  if (d.nA > 8) add_slabs(d.slabsA, d.nA, d.strideA, std::integral_constant<int, 16>{});
+  else if (d.nA > 0) add_slabs(d.slabsA, d.nA, d.strideA, std::integral_constant<int, 8>{});
+  if (d.nB > 8) add_slabs(d.slabsB, d.nB, d.strideB, std::integral_constant<int, 16>{});
+  else if (d.nB > 0) add_slabs(d.slabsB, d.nB, d.strideB, std::integral_constant<int, 8>{});
+  // ---- x . w for the workgroup's 32 rows x 16 units (fragment convention of lstm_fwd_z_kernel) -----------------------------------
+  ssc_f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+  const int r16 = lane & 15, q4 = lane >> 4;
+  for (int k0 = 0; k0 < K; k0 += KT) {
+    if (k0 > 0) {
+      __syncthreads();   // the previous k-tile has been consumed
+      request_tiles(k0);
+    }
+#pragma unroll
+    for (int u = 0; u < TB * KT / NT; ++u) { const int idx = tid + NT * u; sx[(idx / KT) * LD + idx % KT] = xr[u]; }
+#pragma unroll
+    for (int u = 0; u < TJ * KT / NT; ++u) { const int idx = tid + NT * u; sw[(idx % TJ) * LD + idx / TJ] = wr[u]; }
+    __syncthreads();
+    if (wave < 2) {
+      const int kend = min(KT, (K - k0 + 15) / 16 * 16);   // whole 16-wide chunks; the tail is zero-filled
+      for (int c = 0; c < kend; c += 16) {
+        const float4 av = *reinterpret_cast<const float4*>(&sx[(wave * 16 + r16) * LD + c + 4 * q4]);
+        const float4 bv = *reinterpret_cast<const float4*>(&sw[r16 * LD + c + 4 * q4]);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc, 0, 0, 0);
+      }
+    }
+  }
+  if (wave < 2) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) st[(wave * 16 + 4 * q4 + i) * 17 + r16] = acc[i];
+  }
+  __syncthreads();
+  dh += st[bb * 17 + jj];
+  if (!live) return;
+  float tc = tanhf(cn);
+  float d_o = dh * tc;
+  float dc = dcin + dh * og * (1.f - tc * tc);
+  float dgi = dc * gg * ig * (1.f - ig);
+  float dgf = dc * cp * fg * (1.f - fg);
+  float dgg = dc * ig * (1.f - gg * gg);
+  float dgo = d_o * og * (1.f - og);
+  float* o = d.dG + (size_t)b * H4 + j;
+  o[0] = dgi; o[H] = dgf; o[2 * H] = dgg; o[3 * H] = dgo;
+  d.dc_prev[(size_t)b * d.ld_dcprev + j] = dc * fg;
+  if (d.dgsum) {
+    float* sp = d.dgsum + (size_t)b * H4 + j;
+    sp[0] += dgi; sp[H] += dgf; sp[2 * H] += dgg; sp[3 * H] += dgo;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // latent head
 // ---------------------------------------------------------------------------------------------
@@ -699,6 +801,15 @@ extern "C" int ssc_lstm_bwd(const ssc_lstm_bwd_desc* d, void* stream) {
   if (!d || d->B <= 0 || d->H <= 0 || !d->gates || !d->c_prev || !d->c_new || !d->dG || !d->dc_prev) return SSC_EINVAL;
   if ((d->nA > 0 && !d->slabsA) || (d->nB > 0 && !d->slabsB) || d->nA < 0 || d->nB < 0) return SSC_EINVAL;
   SSC_LAUNCH(lstm_bwd_kernel, dim3(ssc_cdiv(d->H, 128), d->B), dim3(128), 0, S(stream), *d);
+  SSC_CHECK_LAUNCH();
+  return SSC_OK;
+}
+
+extern "C" int ssc_lstm_bwd_x(const ssc_lstm_bwd_desc* d, const float* x, int ldx, const float* w, int ldw, int K, void* stream) {
+  if (!d || d->B <= 0 || d->H <= 0 || !d->gates || !d->c_prev || !d->c_new || !d->dG || !d->dc_prev) return SSC_EINVAL;
+  if ((d->nA > 0 && !d->slabsA) || (d->nB > 0 && !d->slabsB) || d->nA < 0 || d->nB < 0) return SSC_EINVAL;
+  if (!x || !w || K <= 0 || ldx < K || ldw < d->H) return SSC_EINVAL;
+  SSC_LAUNCH(lstm_bwd_x_kernel, dim3(ssc_cdiv(d->H, 16), ssc_cdiv(d->B, 32)), dim3(512), 0, S(stream), *d, x, ldx, w, ldw, K);
   SSC_CHECK_LAUNCH();
   return SSC_OK;
 }

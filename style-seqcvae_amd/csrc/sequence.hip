@@ -661,6 +661,7 @@ static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const s
   // wsum_att / wz were prepared by ssc_train_fwd of the same minibatch (parameters are unchanged until the update)
   float* dx = W + l.dx;            // [datt (F) | dh1 (H) | dhd' (H)], ld XW
   int n_gh1 = 0, n_ghd = 0, n_ghd2 = 0, n_ghe = 0;  // slab counts carried from step t+1 (none at t = T-1)
+  const bool fc_adjacent_b = (p->fc_lv_w == p->fc_mean_w + (size_t)Z * p->ld_fc_mean_w) && p->ld_fc_lv_w == p->ld_fc_mean_w;
   const size_t sBH = (size_t)B * H;
   const size_t sBX = (size_t)B * (F + 2 * H);
   // Launch order of one step (every product streams its weight block once; a product is issued as soon as its dG exists and
@@ -718,21 +719,26 @@ static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const s
       d.dmulv = dmulv; d.lddmulv = 2 * Z;
       SSC_TRY(ssc_latent_bwd(&d, st));
     }
-    // 4-5. encoder LSTM: dhe = g_he' slabs + (dmu Wmu + dlv Wlv) slabs
-    SSC_TRY(gemm_to_slabs(c, W + l.sl_dhe, l.small_floats, true, false,
-                          {{dmulv, 2 * Z, p->fc_mean_w, p->ld_fc_mean_w, Z}, {dmulv + Z, 2 * Z, p->fc_lv_w, p->ld_fc_lv_w, Z}}, B, H,
-                          &ns));
+    // 4-5. encoder LSTM: dhe = g_he' slabs + (dmu | dlv) [W_mu ; W_lv].  With the two fc weights adjacent in the flat store the
+    // K = 2Z product is formed inside the cell kernel (ssc_lstm_bwd_x): no launch of its own on the dependency chain
     {
       ssc_lstm_bwd_desc d{};
       d.B = B; d.H = H;
       d.slabsA = W + l.sl_ghe; d.nA = n_ghe; d.strideA = sBH;
-      d.slabsB = W + l.sl_dhe; d.nB = ns; d.strideB = sBH;
       d.dc_in = W + l.g_ce; d.ld_dcin = l.Hp;
       d.gates = W + l.gates_e + (size_t)t * B * H4;
       d.c_prev = W + l.ce + t * sH; d.ld_cprev = l.Hp;
       d.c_new = W + l.ce + (t + 1) * sH; d.ld_cnew = l.Hp;
       d.dG = dge; d.dc_prev = W + l.g_ce; d.ld_dcprev = l.Hp;
-      SSC_TRY(ssc_lstm_bwd(&d, st));
+      if (fc_adjacent_b) {
+        SSC_TRY(ssc_lstm_bwd_x(&d, dmulv, 2 * Z, p->fc_mean_w, p->ld_fc_mean_w, 2 * Z, st));
+      } else {
+        SSC_TRY(gemm_to_slabs(c, W + l.sl_dhe, l.small_floats, true, false,
+                              {{dmulv, 2 * Z, p->fc_mean_w, p->ld_fc_mean_w, Z}, {dmulv + Z, 2 * Z, p->fc_lv_w, p->ld_fc_lv_w, Z}}, B, H,
+                              &ns));
+        d.slabsB = W + l.sl_dhe; d.nB = ns; d.strideB = sBH;
+        SSC_TRY(ssc_lstm_bwd(&d, st));
+      }
     }
     // 6. [datt | dh1 | dhd'] = dGd W_ih^dec[:, :F+2H] (slabs of launch 2) + dGe W_ih^enc[:, :F+2H] (appended here), one sum
     SSC_TRY(gemm_to_slabs(c, c.slabs + (size_t)n_dxd * sBX, c.slab_floats - (size_t)n_dxd * sBX, true, false,

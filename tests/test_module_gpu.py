@@ -242,3 +242,49 @@ def test_lstm_fwd_z_equals_cell_with_precomputed_latent_block(B, H, Z, nslab):
     cw = torch.sigmoid(f) * c_prev.double() + torch.sigmoid(i) * torch.tanh(gg)
     hw = torch.sigmoid(o) * torch.tanh(cw)
     assert (cz.double() - cw).abs().max().item() < 1e-5 and (hz.double() - hw).abs().max().item() < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,K,nA", [(64, 1200, 256, 5), (5, 37, 26, 0), (70, 50, 300, 9)])
+def test_lstm_bwd_x_equals_cell_backward_with_precomputed_addend(B, H, K, nA):
+    """ssc_lstm_bwd_x (LSTM cell backward with the addend dh += x . w formed inside the kernel; BPTT of the encoder LSTM with
+    x = (dmu | dlv), w = [W_mu ; W_lv], updown_cell.py:196-197) against ssc_lstm_bwd fed the same product through dh2."""
+    import ctypes as C
+    from ssc_runtime import lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(B * 1000 + H + K)
+    dev = "cuda"
+    Hp = (H + 3) // 4 * 4
+    x = torch.randn(B, K, generator=g).to(dev)
+    w = torch.full((K, Hp), float("nan"))
+    w[:, :H] = torch.randn(K, H, generator=g) * 0.1
+    w = w.to(dev)
+    gates = torch.rand(B, 4 * H, generator=g).to(dev)
+    c_prev, c_new = torch.randn(B, H, generator=g).to(dev), torch.randn(B, H, generator=g).to(dev)
+    dh_in, dc_in = torch.randn(B, H, generator=g).to(dev), torch.randn(B, H, generator=g).to(dev)
+    slabs = (torch.randn(max(nA, 1), B, H, generator=g) * 0.3).to(dev)
+
+    def run(fused):
+        dG, dcp = torch.empty(B, 4 * H, device=dev), torch.empty(B, H, device=dev)
+        d = L.LstmBwdDesc()
+        d.B, d.H = B, H
+        d.dh, d.ld_dh = dh_in.data_ptr(), H
+        d.dc_in, d.ld_dcin = dc_in.data_ptr(), H
+        d.gates = gates.data_ptr()
+        d.c_prev, d.ld_cprev, d.c_new, d.ld_cnew = c_prev.data_ptr(), H, c_new.data_ptr(), H
+        d.dG, d.dc_prev, d.ld_dcprev = dG.data_ptr(), dcp.data_ptr(), H
+        if nA:
+            d.slabsA, d.nA, d.strideA = slabs.data_ptr(), nA, B * H
+        if fused:
+            lib.ssc_lstm_bwd_x(C.byref(d), x.data_ptr(), K, w.data_ptr(), Hp, K, L.stream_ptr())
+        else:
+            add = (x.double() @ w[:, :H].double()).float().contiguous()
+            d.dh2, d.ld_dh2 = add.data_ptr(), H
+            lib.ssc_lstm_bwd(C.byref(d), L.stream_ptr())
+        torch.cuda.synchronize()
+        return dG, dcp
+
+    a, b = run(True), run(False)
+    for u, v in zip(a, b):
+        assert torch.isfinite(u).all()
+        assert (u - v).abs().max().item() < 2e-5 * max(1.0, float(v.abs().max()))
