@@ -134,6 +134,10 @@ int ssc_lstm_fwd(const ssc_lstm_fwd_desc* d, void* stream);
  * exact-fp32 MFMA).  Used for the latent block of the decoder LSTM input (updown_cell.py:211-229): z exists only after the
  * latent head of the same step, the rest of the gate product does not wait for it. */
 int ssc_lstm_fwd_z(const ssc_lstm_fwd_desc* d, const float* z, int ldz, const float* wz, int ldwz, int Z, void* stream);
+/* ssc_lstm_fwd that also leaves partial products of its output with an nn.Linear weight wp (NP <= 256 rows of H, ld ldwp):
+ *   pout[s][b,n] = sum_{j in [16 s, 16 s + 16)} h_out[b,j] wp[n,j],   s < ceil(H/16), each slab (B,NP) ld NP
+ * (the encoder LSTM's h feeds fc_mean | fc_log_var in the same step, updown_cell.py:196-197: ssc_latent_fwd sums the slabs). */
+int ssc_lstm_fwd_p(const ssc_lstm_fwd_desc* d, const float* wp, int ldwp, int NP, float* pout, void* stream);
 
 /* LSTMCell pointwise backward (SURVEY Appendix A.4 "LSTM^-1"):
  *   dh (B,H) (+ dh2 optional second addend), dc_in (B,H), gates (activated), c_prev, c_new

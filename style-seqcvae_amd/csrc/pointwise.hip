@@ -277,6 +277,108 @@ __global__ __launch_bounds__(512, 2) void lstm_fwd_z_kernel(const ssc_lstm_fwd_d
   d.c_out[(size_t)b * d.ld_cout + j] = c;
   d.h_out[(size_t)b * d.ld_hout + j] = h;
 }
+// lstm_fwd_kernel that also leaves partial products of its OUTPUT: pout[blockIdx.x][b, n] = sum_{j in the workgroup's 16 units}
+// h[b,j] wp[n,j]  (wp (NP,H) ld ldwp: an nn.Linear weight; NP <= 256).  The encoder LSTM's h feeds fc_mean | fc_log_var
+// (updown_cell.py:196-197) in the same step: as a product of its own that was a 10 us launch on the dependency chain for 1.2 MB
+// of weights; here every (32 rows x 16 units) workgroup multiplies the h tile it has just computed with its 16 weight columns
+// (exact-fp32 16x16x4 MFMA, K = 16) and the consumer (latent head) sums the cdiv(H,16) partial slabs in index order.
+__global__ __launch_bounds__(512, 2) void lstm_fwd_p_kernel(const ssc_lstm_fwd_desc d, const float* __restrict__ wp, int ldwp,
+                                                            int NP, float* __restrict__ pout) {
+  constexpr int TB = 32, TJ = 16, LD = TJ + 4, NT = 512, NPMAX = 256;
+  __shared__ __attribute__((aligned(16))) float sh[TB * LD];      // h[b0 + r, j0 + k]
+  __shared__ __attribute__((aligned(16))) float sw[NPMAX * LD];   // wp[n, j0 + k]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int H = d.H, H4 = 4 * d.H;
+  const int j0 = blockIdx.x * TJ, b0 = blockIdx.y * TB;
+  const int bb = tid >> 4, jj = tid & 15;
+  const int b = b0 + bb, j = j0 + jj;
+  const bool live = b < d.B && j < H;
+  const int bc = live ? b : 0, jc = live ? j : 0;   // clamped: every thread runs the same loads
+  // the weight slice is requested first (independent of the cell)
+  float wr[NPMAX * TJ / NT];
+#pragma unroll
+  for (int u = 0; u < NPMAX * TJ / NT; ++u) {   // 8 floats per thread: 16 consecutive threads read 64 contiguous bytes of a row
+    const int idx = tid + NT * u, n = idx / TJ, wj = j0 + idx % TJ;
+    wr[u] = (n < NP && wj < H) ? wp[(size_t)n * ldwp + wj] : 0.f;
+  }
+  float a0[4], a1[4], bi[4], bh[4], sw4[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int n = g * H + jc;
+    a0[g] = d.add0 ? d.add0[(size_t)(d.add0_rows ? d.add0_rows[bc] : (int64_t)bc) * d.ld_add0 + n] : 0.f;
+    a1[g] = d.add1 ? d.add1[(size_t)(bc / d.rows_per_add1) * d.ld_add1 + n] : 0.f;
+    bi[g] = d.b_ih ? d.b_ih[n] : 0.f;
+    bh[g] = d.b_hh ? d.b_hh[n] : 0.f;
+    sw4[g] = d.sent ? d.wcol[(size_t)n * d.ldwcol] : 0.f;
+  }
+  const float sv = d.sent ? d.sent[bc] : 0.f;
+  const float cp = d.c_prev ? d.c_prev[(size_t)bc * d.ld_cprev + jc] : 0.f;
+  float pre[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int s0 = 0; s0 < d.nslab; s0 += 16) {
+    float t[4][16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const float* sp = d.slabs + (size_t)min(s0 + u, d.nslab - 1) * d.slab_stride + (size_t)bc * H4 + jc;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) t[g][u] = sp[g * H];
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) pre[g] += (s0 + u < d.nslab) ? t[g][u] : 0.f;
+  }
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    float v = pre[g];
+    v += a0[g];
+    v += a1[g];
+    v += bi[g];
+    v += bh[g];
+    if (d.sent) v += sv * sw4[g];
+    pre[g] = v;
+  }
+  const float ig = ssc_sigmoid(pre[0]), fg = ssc_sigmoid(pre[1]), gg = tanhf(pre[2]), og = ssc_sigmoid(pre[3]);
+  const float c = fg * cp + ig * gg;
+  const float h = og * tanhf(c);
+  if (live) {
+    if (d.gates_out) {
+      float* go = d.gates_out + (size_t)b * H4 + j;
+      go[0] = ig; go[H] = fg; go[2 * H] = gg; go[3 * H] = og;
+    }
+    d.c_out[(size_t)b * d.ld_cout + j] = c;
+    d.h_out[(size_t)b * d.ld_hout + j] = h;
+  }
+  // ---- partial product of the h tile with the workgroup's 16 weight columns ------------------------------------------------------
+  sh[bb * LD + jj] = live ? h : 0.f;
+#pragma unroll
+  for (int u = 0; u < NPMAX * TJ / NT; ++u) { const int idx = tid + NT * u; sw[(idx / TJ) * LD + idx % TJ] = wr[u]; }
+  __syncthreads();
+  const int r16 = lane & 15, q4 = lane >> 4;
+  float* po = pout + (size_t)blockIdx.x * d.B * NP;
+  // 2 row tiles x NP/16 column tiles; wave w takes column tiles 2w, 2w+1 (K = 16: one chunk, 4 MFMAs per tile)
+#pragma unroll
+  for (int ci = 0; ci < 2; ++ci) {
+    const int ct = 2 * wave + ci;
+    if (ct * 16 >= NP) break;
+    const float4 bv = *reinterpret_cast<const float4*>(&sw[(ct * 16 + r16) * LD + 4 * q4]);
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      const float4 av = *reinterpret_cast<const float4*>(&sh[(rt * 16 + r16) * LD + 4 * q4]);
+      ssc_f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc, 0, 0, 0);
+      const int n = ct * 16 + r16;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ob = b0 + rt * 16 + 4 * q4 + i;
+        if (ob < d.B && n < NP) po[(size_t)ob * NP + n] = acc[i];
+      }
+    }
+  }
+}
+
 __global__ void lstm_bwd_kernel(const ssc_lstm_bwd_desc d) {
   int j = blockIdx.x * blockDim.x + threadIdx.x;
   int b = blockIdx.y;
@@ -476,6 +578,68 @@ __global__ void latent_prior_sample_kernel(const float* __restrict__ eps, int ld
   if (i >= Z) return;
   float pm = sent ? pm_scale * sent[g] : 0.f;
   z[(size_t)g * ldz + i] = eps[(size_t)g * ldeps + i] * sd + pm;
+}
+
+// latent_fwd_kernel for MANY partial slabs (the cdiv(H,16) partial products of lstm_fwd_p_kernel): one 256-thread workgroup per
+// row; the slab list is split into 256 / (64 ceil(Z/64)) contiguous parts that are summed in parallel (each in index order) and
+// combined in part order - fixed summation order, four times the loads in flight of the wave-per-row form.  Z <= 256.
+__global__ __launch_bounds__(256) void latent_fwd_wide_kernel(const ssc_latent_fwd_desc d) {
+  __shared__ float pm_[4][64], pl_[4][64], kl_[4];
+  const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int Z = d.Z;
+  const int ZW = (Z + 63) / 64;            // waves per full z range (1, 2 or 4)
+  const int SP = 4 / ZW;                   // slab parts
+  const int zw = wave % ZW, part = wave / ZW;
+  const int z = zw * 64 + lane;
+  const int per = (d.nslab + SP - 1) / SP;
+  const int s_lo = part * per, s_hi = min(d.nslab, s_lo + per);
+  float m = 0.f, l = 0.f;
+  if (z < Z && ZW * SP == 4) {
+    for (int s0 = s_lo; s0 < s_hi; s0 += 16) {
+      float tm[16], tl[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const float* row = d.mulv + (size_t)min(s0 + u, s_hi - 1) * d.slab_stride + (size_t)b * d.ldmulv;
+        tm[u] = row[z];
+        tl[u] = row[Z + z];
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        m += (s0 + u < s_hi) ? tm[u] : 0.f;
+        l += (s0 + u < s_hi) ? tl[u] : 0.f;
+      }
+    }
+  }
+  pm_[wave][lane] = m;
+  pl_[wave][lane] = l;
+  __syncthreads();
+  float acc = 0.f;
+  if (part == 0 && z < Z) {
+    for (int p = 1; p < SP; ++p) { m += pm_[p * ZW + zw][lane]; l += pl_[p * ZW + zw][lane]; }
+    const float pm = d.sent ? d.pm_scale * d.sent[b] : 0.f;
+    const float pvar = d.prior_var, lpv = logf(pvar);
+    m += d.bmu[z];
+    l += d.blv[z];
+    const float var = expf(l);
+    const float zz = d.eps[(size_t)b * d.ldeps + z] * sqrtf(var) + m;
+    d.mu[(size_t)b * d.ldz + z] = m;
+    d.lv[(size_t)b * d.ldz + z] = l;
+    d.z[(size_t)b * d.ldz + z] = zz;
+    if (d.kld_mode == 0) {
+      acc = 1.f + l - m * m - var;
+    } else {
+      const float dm = m - pm;
+      acc = 1.f + l - lpv - (dm * dm + var) / (pvar + 0.00001f);
+    }
+  }
+  acc = ssc_wave_sum(acc);
+  if (lane == 0) kl_[wave] = acc;
+  __syncthreads();
+  if (tid == 0) {
+    float a = 0.f;
+    for (int w2 = 0; w2 < ZW; ++w2) a += kl_[w2];   // waves of part 0, in z order
+    d.kld_acc[b] += d.w[b] * (-0.5f * a);
+  }
 }
 
 __global__ void latent_bwd_kernel(const ssc_latent_bwd_desc d) {
@@ -805,6 +969,17 @@ extern "C" int ssc_lstm_bwd(const ssc_lstm_bwd_desc* d, void* stream) {
   return SSC_OK;
 }
 
+extern "C" int ssc_lstm_fwd_p(const ssc_lstm_fwd_desc* d, const float* wp, int ldwp, int NP, float* pout, void* stream) {
+  if (!d || d->B <= 0 || d->H <= 0 || !d->c_out || !d->h_out) return SSC_EINVAL;
+  if (d->nslab < 0 || (d->nslab > 0 && !d->slabs)) return SSC_EINVAL;
+  if (d->sent && !d->wcol) return SSC_EINVAL;
+  if (d->add1 && d->rows_per_add1 <= 0) return SSC_EINVAL;
+  if (!wp || !pout || NP <= 0 || NP > 256 || ldwp < d->H) return SSC_EINVAL;
+  SSC_LAUNCH(lstm_fwd_p_kernel, dim3(ssc_cdiv(d->H, 16), ssc_cdiv(d->B, 32)), dim3(512), 0, S(stream), *d, wp, ldwp, NP, pout);
+  SSC_CHECK_LAUNCH();
+  return SSC_OK;
+}
+
 extern "C" int ssc_lstm_bwd_x(const ssc_lstm_bwd_desc* d, const float* x, int ldx, const float* w, int ldw, int K, void* stream) {
   if (!d || d->B <= 0 || d->H <= 0 || !d->gates || !d->c_prev || !d->c_new || !d->dG || !d->dc_prev) return SSC_EINVAL;
   if ((d->nA > 0 && !d->slabsA) || (d->nB > 0 && !d->slabsB) || d->nA < 0 || d->nB < 0) return SSC_EINVAL;
@@ -818,7 +993,11 @@ extern "C" int ssc_latent_fwd(const ssc_latent_fwd_desc* d, void* stream) {
   if (!d || d->B <= 0 || d->Z <= 0 || !d->mulv || d->nslab < 1 || !d->bmu || !d->blv || !d->eps || !d->w || !d->mu ||
       !d->lv || !d->z || !d->kld_acc)
     return SSC_EINVAL;
-  SSC_LAUNCH(latent_fwd_kernel, dim3(ssc_cdiv(d->B, 4)), dim3(256), 0, S(stream), *d);
+  const int zw = (d->Z + 63) / 64;
+  if (d->nslab > 16 && (zw == 1 || zw == 2 || zw == 4))
+    SSC_LAUNCH(latent_fwd_wide_kernel, dim3(d->B), dim3(256), 0, S(stream), *d);
+  else
+    SSC_LAUNCH(latent_fwd_kernel, dim3(ssc_cdiv(d->B, 4)), dim3(256), 0, S(stream), *d);
   SSC_CHECK_LAUNCH();
   return SSC_OK;
 }

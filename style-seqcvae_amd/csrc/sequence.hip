@@ -532,7 +532,10 @@ extern "C" int ssc_train_fwd(const ssc_model_cfg* cfg, const ssc_params* p, cons
       SSC_TRY(ssc_gemm_slabs_group(dp, 2, regions, caps, ns2, st));
       n_ge_a = ns2[0]; n_gd_a = ns2[1];
     }
-    // encoder LSTM cell
+    // encoder LSTM cell.  With fc_mean / fc_log_var adjacent in the flat store (one (2Z, H) operand) the cell kernel also leaves
+    // the partial products h_e . [W_mu ; W_lv]^T of its 16-unit slices (ssc_lstm_fwd_p) and the latent head sums them: no
+    // product launch between the cell and the latent head
+    const bool fused_fc = fc_adjacent && 2 * Z <= 256 && (size_t)ssc_cdiv(H, 16) * B * 2 * Z <= l.small_floats;
     {
       ssc_lstm_fwd_desc d{};
       d.B = B; d.H = H;
@@ -542,14 +545,17 @@ extern "C" int ssc_train_fwd(const ssc_model_cfg* cfg, const ssc_params* p, cons
       d.c_prev = cep; d.ld_cprev = l.Hp;
       d.gates_out = W + l.gates_e + (size_t)t * B * H4;
       d.c_out = cen; d.ld_cout = l.Hp; d.h_out = hen; d.ld_hout = l.Hp;
-      SSC_TRY(ssc_lstm_fwd(&d, st));
+      if (fused_fc) SSC_TRY(ssc_lstm_fwd_p(&d, p->fc_mean_w, p->ld_fc_mean_w, 2 * Z, W + l.sl_mulv, st));
+      else SSC_TRY(ssc_lstm_fwd(&d, st));
     }
     // latent head: mean / log_var / z / KL (updown_cell.py:196-208, updown_captioner.py:295-303)
     {
       float* mulv = W + l.mulv;
       ssc_latent_fwd_desc d{};
       d.B = B; d.Z = Z;
-      if (fc_adjacent) {  // one (2Z x H) operand; the slabs go straight to the latent epilogue
+      if (fused_fc) {
+        d.mulv = W + l.sl_mulv; d.ldmulv = 2 * Z; d.nslab = ssc_cdiv(H, 16); d.slab_stride = (size_t)B * 2 * Z;
+      } else if (fc_adjacent) {  // one (2Z x H) operand; the slabs go straight to the latent epilogue
         SSC_TRY(gemm_to_slabs(c, W + l.sl_mulv, l.small_floats, true, true, {{hen, l.Hp, p->fc_mean_w, p->ld_fc_mean_w, H}}, B,
                               2 * Z, &ns));
         d.mulv = W + l.sl_mulv; d.ldmulv = 2 * Z; d.nslab = ns; d.slab_stride = (size_t)B * 2 * Z;

@@ -114,6 +114,7 @@ SYMBOLS = {
     "ssc_embed_scatter_add": (_i, [vp, _i, vp, _i, _i, vp, _i, _i, vp]),
     "ssc_lstm_fwd": (_i, [C.POINTER(LstmFwdDesc), vp]),
     "ssc_lstm_fwd_z": (_i, [C.POINTER(LstmFwdDesc), vp, _i, vp, _i, _i, vp]),
+    "ssc_lstm_fwd_p": (_i, [C.POINTER(LstmFwdDesc), vp, _i, _i, vp, vp]),
     "ssc_lstm_bwd_x": (_i, [C.POINTER(LstmBwdDesc), vp, _i, vp, _i, _i, vp]),
     "ssc_lstm_bwd": (_i, [C.POINTER(LstmBwdDesc), vp]),
     "ssc_attn_logits": (_i, [vp, _i, vp, vp, _i, _i, _i, _i, vp, vp]),

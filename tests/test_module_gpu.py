@@ -288,3 +288,48 @@ def test_lstm_bwd_x_equals_cell_backward_with_precomputed_addend(B, H, K, nA):
     for u, v in zip(a, b):
         assert torch.isfinite(u).all()
         assert (u - v).abs().max().item() < 2e-5 * max(1.0, float(v.abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,NP,nslab", [(64, 1200, 256, 12), (5, 37, 26, 3), (70, 50, 12, 0)])
+def test_lstm_fwd_p_partial_products_sum_to_the_linear_layer(B, H, NP, nslab):
+    """ssc_lstm_fwd_p = ssc_lstm_fwd + partial products of its h with an nn.Linear weight (NP x H): the ceil(H/16) slabs sum to
+    h @ wp^T (fc_mean | fc_log_var after the encoder LSTM, updown_cell.py:196-197); cell outputs equal ssc_lstm_fwd's bit for bit."""
+    import ctypes as C
+    from ssc_runtime import lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(B * 1000 + H + NP)
+    dev = "cuda"
+    Hp = (H + 3) // 4 * 4
+    slabs = (torch.randn(max(nslab, 1), B, 4 * H, generator=g) * 0.3).to(dev)
+    wp = torch.full((NP, Hp), float("nan"))
+    wp[:, :H] = torch.randn(NP, H, generator=g) * 0.2
+    wp = wp.to(dev)
+    b_ih, b_hh = torch.randn(4 * H, generator=g).to(dev), torch.randn(4 * H, generator=g).to(dev)
+    c_prev = torch.randn(B, H, generator=g).to(dev)
+    ns = (H + 15) // 16
+
+    def run(fused):
+        h, c, gates = (torch.empty(B, H, device=dev), torch.empty(B, H, device=dev), torch.empty(B, 4 * H, device=dev))
+        pout = torch.full((ns, B, NP), float("nan"), device=dev)
+        d = L.LstmFwdDesc()
+        d.B, d.H = B, H
+        if nslab:
+            d.slabs, d.nslab, d.slab_stride = slabs.data_ptr(), nslab, B * 4 * H
+        d.b_ih, d.b_hh = b_ih.data_ptr(), b_hh.data_ptr()
+        d.c_prev, d.ld_cprev = c_prev.data_ptr(), H
+        d.gates_out = gates.data_ptr()
+        d.c_out, d.ld_cout, d.h_out, d.ld_hout = c.data_ptr(), H, h.data_ptr(), H
+        if fused:
+            lib.ssc_lstm_fwd_p(C.byref(d), wp.data_ptr(), Hp, NP, pout.data_ptr(), L.stream_ptr())
+        else:
+            lib.ssc_lstm_fwd(C.byref(d), L.stream_ptr())
+        torch.cuda.synchronize()
+        return h, c, gates, pout
+
+    hp, cp_, gp, pout = run(True)
+    h0, c0, g0, _ = run(False)
+    assert torch.equal(hp, h0) and torch.equal(cp_, c0) and torch.equal(gp, g0)
+    want = hp.double() @ wp[:, :H].double().t()
+    assert torch.isfinite(pout).all()
+    assert (pout.double().sum(0) - want).abs().max().item() < 1e-5
