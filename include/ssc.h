@@ -160,7 +160,9 @@ typedef struct {
 } ssc_lstm_bwd_desc;
 int ssc_lstm_bwd(const ssc_lstm_bwd_desc* d, void* stream);
 /* The same with one more addend of dh formed inside the kernel: dh[b,j] += sum_k x[b,k] w[k,j]  (x (B,K) ld ldx; w (K,H) ld ldw;
- * exact-fp32 MFMA).  BPTT of the encoder LSTM: x = (dmu | dlv), w = [W_mu ; W_lv] (fc_mean / fc_log_var, updown_cell.py:196-197). */
+ * exact-fp32 MFMA; K <= 768: its LDS images take (48 (K+4) + 2176) floats).  BPTT of the
+ * encoder LSTM: x = (dmu | dlv), w = [W_mu ; W_lv] (fc_mean / fc_log_var, updown_cell.py:196-197); of the attention LSTM:
+ * x = dq, w = Wq (the query projection, attention.py:69). */
 int ssc_lstm_bwd_x(const ssc_lstm_bwd_desc* d, const float* x, int ldx, const float* w, int ldw, int K, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

@@ -424,16 +424,22 @@ __global__ void lstm_bwd_kernel(const ssc_lstm_bwd_desc d) {
 }
 
 // lstm_bwd_kernel plus one more addend of dh formed IN the kernel: dh[b,j] += sum_k x[b,k] w[k,j]  (x (B,K) ld ldx; w (K,H) ld ldw,
-// j-contiguous).  Used for the encoder LSTM in BPTT: its dh is the carried g_he' plus (dmu | dlv) . [W_mu ; W_lv]  (K = 2Z = 256,
-// updown_cell.py:196-197 backward) - as its own split-K product that was a 10 us launch on the step's dependency chain for 1.2 MB
-// of weights.  Same shape as lstm_fwd_z_kernel: one 512-thread workgroup per (32 batch rows x 16 hidden units), one cell per
-// thread, the x rows and the (K x 16) weight slice go through LDS images to the exact-fp32 16x16x4 MFMA (waves 0 and 1).
+// j-contiguous; K <= 1024).  Used in BPTT for the encoder LSTM - dh = carried g_he' + (dmu | dlv) . [W_mu ; W_lv], K = 2Z = 256
+// (updown_cell.py:196-197 backward) - and for the attention LSTM - dh += dq . Wq, K = A = 768 (attention.py:69 backward): as
+// split-K products of their own these were 10-18 us launches on the step's dependency chain for 1-4 MB of weights.  Same shape
+// as lstm_fwd_z_kernel: one 512-thread workgroup per (32 batch rows x 16 hidden units), one cell per thread; the x rows and the
+// (K x 16) weight slice go through LDS images to the exact-fp32 16x16x4 MFMA: wave w takes row tile w & 1 and the quarter
+// w >> 1 of the K range, the four partial tiles are added in quarter order.
+template <int KMAX>   // 256 | 768: bounds the staged registers (KMAX / 16 + KMAX / 32 floats per thread)
 __global__ __launch_bounds__(512, 2) void lstm_bwd_x_kernel(const ssc_lstm_bwd_desc d, const float* __restrict__ x, int ldx,
                                                             const float* __restrict__ w, int ldw, int K) {
-  constexpr int TB = 32, TJ = 16, KT = 256, LD = KT + 4, NT = 512;
-  __shared__ __attribute__((aligned(16))) float sx[TB * LD];   // x[b0 + r, k]
-  __shared__ __attribute__((aligned(16))) float sw[TJ * LD];   // w[k, j0 + jj] stored [jj][k]
-  __shared__ float st[TB * 17];                                // product tile [row b][jj]
+  constexpr int TB = 32, TJ = 16, NT = 512;
+  extern __shared__ __attribute__((aligned(16))) float bwdx_lds[];
+  const int KP = (K + 63) & ~63;       // four quarters of whole 16-wide chunks
+  const int LD = KP + 4;
+  float* sx = bwdx_lds;                // x[b0 + r, k]: TB * LD
+  float* sw = sx + TB * LD;            // w[k, j0 + jj] stored [jj][k]: TJ * LD
+  float* st = sw + TJ * LD;            // partial product tiles [quarter][row b][jj]: 4 * TB * 17
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int H = d.H, H4 = 4 * d.H;
   const int j0 = blockIdx.x * TJ, b0 = blockIdx.y * TB;
@@ -441,20 +447,25 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_x_kernel(const ssc_lstm_bwd_d
   const int b = b0 + bb, j = j0 + jj;
   const bool live = b < d.B && j < H;
   const int bc = live ? b : 0, jc = live ? j : 0;   // clamped: every thread runs the same loads
-  float xr[TB * KT / NT], wr[TJ * KT / NT];
-  auto request_tiles = [&](int k0) __attribute__((always_inline)) {
+  // staging without integer division by the run-time K (it cost ~35 instructions per element: 24 us per launch at K = 768):
+  // x: thread (row = tid >> 4, t = tid & 15) takes k = t + 16 u of its row; w: thread (k = (tid >> 4) + 32 u, unit tid & 15).
+  // Either way 16 consecutive threads read 64 contiguous bytes.
+  float xr[KMAX / 16], wr[KMAX / 32];
+  {
+    const int xb = b0 + (tid >> 4);
+    const float* xp = x + (size_t)min(xb, d.B - 1) * ldx;
 #pragma unroll
-    for (int u = 0; u < TB * KT / NT; ++u) {   // 16 floats per thread, coalesced along k
-      const int idx = tid + NT * u, row = idx / KT, k = k0 + idx % KT, xb = b0 + row;
-      xr[u] = (xb < d.B && k < K) ? x[(size_t)xb * ldx + k] : 0.f;
+    for (int u = 0; u < KMAX / 16; ++u) {
+      const int k = (tid & 15) + 16 * u;
+      xr[u] = (k < K && xb < d.B) ? xp[k] : 0.f;
     }
+    const int wj = j0 + (tid & 15);
 #pragma unroll
-    for (int u = 0; u < TJ * KT / NT; ++u) {   // 8 floats per thread: 16 consecutive threads read 64 contiguous bytes of a k-row
-      const int idx = tid + NT * u, k = k0 + idx / TJ, wj = j0 + idx % TJ;
-      wr[u] = (wj < H && k < K) ? w[(size_t)k * ldw + wj] : 0.f;
+    for (int u = 0; u < KMAX / 32; ++u) {
+      const int k = (tid >> 4) + 32 * u;
+      wr[u] = (k < K && wj < H) ? w[(size_t)k * ldw + wj] : 0.f;
     }
-  };
-  request_tiles(0);
+  }
   // ---- the cell's own operands (as in lstm_bwd_kernel) -------------------------------------------------------------------------
   const float dcin = d.dc_in ? d.dc_in[(size_t)bc * d.ld_dcin + jc] : 0.f;
   const float* g = d.gates + (size_t)bc * H4 + jc;
@@ -478,36 +489,35 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_x_kernel(const ssc_lstm_bwd_d
   if (d.nB > 8) add_slabs(d.slabsB, d.nB, d.strideB, std::integral_constant<int, 16>{});
   else if (d.nB > 0) add_slabs(d.slabsB, d.nB, d.strideB, std::integral_constant<int, 8>{});
   // ---- x . w for the workgroup's 32 rows x 16 units (fragment convention of lstm_fwd_z_kernel) -----------------------------------
-  ssc_f32x4v acc = {0.f, 0.f, 0.f, 0.f};
-  const int r16 = lane & 15, q4 = lane >> 4;
-  for (int k0 = 0; k0 < K; k0 += KT) {
-    if (k0 > 0) {
-      __syncthreads();   // the previous k-tile has been consumed
-      request_tiles(k0);
-    }
 #pragma unroll
-    for (int u = 0; u < TB * KT / NT; ++u) { const int idx = tid + NT * u; sx[(idx / KT) * LD + idx % KT] = xr[u]; }
-#pragma unroll
-    for (int u = 0; u < TJ * KT / NT; ++u) { const int idx = tid + NT * u; sw[(idx % TJ) * LD + idx / TJ] = wr[u]; }
-    __syncthreads();
-    if (wave < 2) {
-      const int kend = min(KT, (K - k0 + 15) / 16 * 16);   // whole 16-wide chunks; the tail is zero-filled
-      for (int c = 0; c < kend; c += 16) {
-        const float4 av = *reinterpret_cast<const float4*>(&sx[(wave * 16 + r16) * LD + c + 4 * q4]);
-        const float4 bv = *reinterpret_cast<const float4*>(&sw[r16 * LD + c + 4 * q4]);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc, 0, 0, 0);
-      }
-    }
+  for (int u = 0; u < KMAX / 16; ++u) {
+    const int k = (tid & 15) + 16 * u;
+    if (k < KP) sx[(tid >> 4) * LD + k] = xr[u];
   }
-  if (wave < 2) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) st[(wave * 16 + 4 * q4 + i) * 17 + r16] = acc[i];
+  for (int u = 0; u < KMAX / 32; ++u) {
+    const int k = (tid >> 4) + 32 * u;
+    if (k < KP) sw[(tid & 15) * LD + k] = wr[u];
   }
   __syncthreads();
-  dh += st[bb * 17 + jj];
+  {
+    ssc_f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+    const int r16 = lane & 15, q4 = lane >> 4;
+    const int rt = wave & 1, kq = wave >> 1;
+    const int kspan = KP >> 2;   // a multiple of 16
+    for (int c = kq * kspan; c < (kq + 1) * kspan; c += 16) {
+      const float4 av = *reinterpret_cast<const float4*>(&sx[(rt * 16 + r16) * LD + c + 4 * q4]);
+      const float4 bv = *reinterpret_cast<const float4*>(&sw[r16 * LD + c + 4 * q4]);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) st[(kq * TB + rt * 16 + 4 * q4 + i) * 17 + r16] = acc[i];
+  }
+  __syncthreads();
+  dh += ((st[bb * 17 + jj] + st[(TB + bb) * 17 + jj]) + st[(2 * TB + bb) * 17 + jj]) + st[(3 * TB + bb) * 17 + jj];
   if (!live) return;
   float tc = tanhf(cn);
   float d_o = dh * tc;
@@ -983,8 +993,21 @@ extern "C" int ssc_lstm_fwd_p(const ssc_lstm_fwd_desc* d, const float* wp, int l
 extern "C" int ssc_lstm_bwd_x(const ssc_lstm_bwd_desc* d, const float* x, int ldx, const float* w, int ldw, int K, void* stream) {
   if (!d || d->B <= 0 || d->H <= 0 || !d->gates || !d->c_prev || !d->c_new || !d->dG || !d->dc_prev) return SSC_EINVAL;
   if ((d->nA > 0 && !d->slabsA) || (d->nB > 0 && !d->slabsB) || d->nA < 0 || d->nB < 0) return SSC_EINVAL;
-  if (!x || !w || K <= 0 || ldx < K || ldw < d->H) return SSC_EINVAL;
-  SSC_LAUNCH(lstm_bwd_x_kernel, dim3(ssc_cdiv(d->H, 16), ssc_cdiv(d->B, 32)), dim3(512), 0, S(stream), *d, x, ldx, w, ldw, K);
+  if (!x || !w || K <= 0 || K > 768 || ldx < K || ldw < d->H) return SSC_EINVAL;
+  const int KP = (K + 63) & ~63;
+  const size_t lds = ((size_t)(32 + 16) * (KP + 4) + 4 * 32 * 17) * sizeof(float);
+  const dim3 grid(ssc_cdiv(d->H, 16), ssc_cdiv(d->B, 32));
+  if (K <= 256) {
+    SSC_LAUNCH(lstm_bwd_x_kernel<256>, grid, dim3(512), lds, S(stream), *d, x, ldx, w, ldw, K);
+  } else {
+    static bool raised = false;
+    if (!raised) {   // up to 157 KB of dynamic LDS at K = 768 (one workgroup per CU)
+      if (hipFuncSetAttribute((const void*)lstm_bwd_x_kernel<768>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return SSC_EHIP;
+      raised = true;
+    }
+    if (lds > 160 * 1024) return SSC_EINVAL;
+    SSC_LAUNCH(lstm_bwd_x_kernel<768>, grid, dim3(512), lds, S(stream), *d, x, ldx, w, ldw, K);
+  }
   SSC_CHECK_LAUNCH();
   return SSC_OK;
 }

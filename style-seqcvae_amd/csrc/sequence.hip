@@ -673,7 +673,7 @@ static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const s
   // Launch order of one step (every product streams its weight block once; a product is issued as soon as its dG exists and
   // shares a launch with the latency-bound small product of the dependency chain that sits at the same place):
   //   dec cell -> {dz, dGd W_ih^dec[:, :F+2H], dGd W_hh^dec} -> latent -> dhe -> enc cell -> {dGe W_ih^enc[:, :F+2H]} -> sum
-  //   -> attention -> {dq Wq, dGe W_hh^enc} -> att cell -> {dGa (W_ih^att[h1] + W_hh^att), dGa W_ih^att[hd]}
+  //   (with dGe W_hh^enc) -> attention -> att cell (dq Wq formed inside) -> {dGa (W_ih^att[h1] + W_hh^att), dGa W_ih^att[hd]}
 
   if (g_loop.on) { (void)hipEventRecord(g_loop.e[2], st); }
   for (int t = T - 1; t >= 0; --t) {
@@ -746,39 +746,44 @@ static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const s
         SSC_TRY(ssc_lstm_bwd(&d, st));
       }
     }
-    // 6. [datt | dh1 | dhd'] = dGd W_ih^dec[:, :F+2H] (slabs of launch 2) + dGe W_ih^enc[:, :F+2H] (appended here), one sum
-    SSC_TRY(gemm_to_slabs(c, c.slabs + (size_t)n_dxd * sBX, c.slab_floats - (size_t)n_dxd * sBX, true, false,
-                          {{dge, H4, p->enc_w_ih, p->ld_enc_w_ih, H4}}, B, F + 2 * H, &n_dxe));
+    // 6. everything dGe feeds, in one launch: the encoder half of [datt | dh1 | dhd'] (appended to the decoder half's slabs of
+    //    launch 2, one sum) and dGe W_hh^enc for step t-1
+    {
+      ssc_gemm_desc d2[2];
+      fill_desc(d2[0], true, false, {{dge, H4, p->enc_w_ih, p->ld_enc_w_ih, H4}}, B, F + 2 * H);
+      fill_desc(d2[1], true, false, {{dge, H4, p->enc_w_hh, p->ld_enc_w_hh, H4}}, B, H);
+      const ssc_gemm_desc* dp[2] = {&d2[0], &d2[1]};
+      float* regions[2] = {c.slabs + (size_t)n_dxd * sBX, W + l.sl_ghe};
+      const size_t caps[2] = {c.slab_floats - (size_t)n_dxd * sBX, l.small_floats};
+      int ns2[2] = {0, 0};
+      SSC_TRY(ssc_gemm_slabs_group(dp, t > 0 ? 2 : 1, regions, caps, ns2, st));
+      n_dxe = ns2[0]; n_ghe = ns2[1];
+    }
     SSC_TRY(ssc_reduce_slabs(c.slabs, n_dxd + n_dxe, sBX, B, F + 2 * H, dx, XW, nullptr, 0, st));
     // 7. attention backward
     SSC_TRY(ssc_attn_bwd(dx, XW, W + l.q + (size_t)t * B * l.Ap, l.Ap, W + l.pv, p->wa, W + l.alpha + (size_t)t * B * R,
                          bt->feats, B, R, A, F, dq, l.Ap, W + l.dpv, W + l.dwa, W + l.dalpha, st));
-    // 8. dq Wq (summed inside the attention LSTM backward) together with dGe W_hh^enc for step t-1
-    {
-      ssc_gemm_desc d2[2];
-      fill_desc(d2[0], true, false, {{dq, l.Ap, p->wq, p->ld_wq, A}}, B, H);
-      fill_desc(d2[1], true, false, {{dge, H4, p->enc_w_hh, p->ld_enc_w_hh, H4}}, B, H);
-      const ssc_gemm_desc* dp[2] = {&d2[0], &d2[1]};
-      float* regions[2] = {W + l.sl_dqw, W + l.sl_ghe};
-      const size_t caps[2] = {l.small_floats, l.small_floats};
-      int ns2[2] = {0, 0};
-      SSC_TRY(ssc_gemm_slabs_group(dp, t > 0 ? 2 : 1, regions, caps, ns2, st));
-      ns = ns2[0]; n_ghe = ns2[1];
-    }
-    // 9. attention LSTM: dh1 = dx[h1 block] + g_h1' slabs + (dq Wq) slabs
+    // 8-9. attention LSTM: dh1 = dx[h1 block] + g_h1' slabs + dq Wq; the K = A product is formed inside the cell kernel
+    //      (ssc_lstm_bwd_x) while its LDS images fit, else it is a split-K product of its own
     {
       ssc_lstm_bwd_desc d{};
       d.B = B; d.H = H;
       d.dh = dx + F; d.ld_dh = XW;
       d.slabsA = W + l.sl_gh1; d.nA = n_gh1; d.strideA = sBH;
-      d.slabsB = W + l.sl_dqw; d.nB = ns; d.strideB = sBH;
       d.dc_in = W + l.g_c1; d.ld_dcin = l.Hp;
       d.gates = W + l.gates_a + (size_t)t * B * H4;
       d.c_prev = W + l.c1 + t * sH; d.ld_cprev = l.Hp;
       d.c_new = W + l.c1 + (t + 1) * sH; d.ld_cnew = l.Hp;
       d.dG = dga; d.dc_prev = W + l.g_c1; d.ld_dcprev = l.Hp;
       d.dgsum = W + l.dga_sum;
-      SSC_TRY(ssc_lstm_bwd(&d, st));
+      const bool fused_q = A <= 768;
+      if (fused_q) {
+        SSC_TRY(ssc_lstm_bwd_x(&d, dq, l.Ap, p->wq, p->ld_wq, A, st));
+      } else {
+        SSC_TRY(gemm_to_slabs(c, W + l.sl_dqw, l.small_floats, true, false, {{dq, l.Ap, p->wq, p->ld_wq, A}}, B, H, &ns));
+        d.slabsB = W + l.sl_dqw; d.nB = ns; d.strideB = sBH;
+        SSC_TRY(ssc_lstm_bwd(&d, st));
+      }
     }
     // 10. what dGa carries to step t-1 (left as slabs for their consumers)
     if (t > 0) {

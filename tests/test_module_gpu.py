@@ -245,7 +245,7 @@ def test_lstm_fwd_z_equals_cell_with_precomputed_latent_block(B, H, Z, nslab):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,H,K,nA", [(64, 1200, 256, 5), (5, 37, 26, 0), (70, 50, 300, 9)])
+@pytest.mark.parametrize("B,H,K,nA", [(64, 1200, 256, 5), (5, 37, 26, 0), (70, 50, 300, 9), (64, 1200, 768, 5)])
 def test_lstm_bwd_x_equals_cell_backward_with_precomputed_addend(B, H, K, nA):
     """ssc_lstm_bwd_x (LSTM cell backward with the addend dh += x . w formed inside the kernel; BPTT of the encoder LSTM with
     x = (dmu | dlv), w = [W_mu ; W_lv], updown_cell.py:196-197) against ssc_lstm_bwd fed the same product through dh2."""
