@@ -370,40 +370,40 @@ def main():
             eng.forward(feats, caps, senti, eps)
             torch.cuda.synchronize()
             eng.backward(torch.full((B,), 1.0 / B, device=device), torch.full((B,), 1.0 / (B * 750.0), device=device))
-        buf = torch.zeros(4096 * 6, dtype=torch.float32)
+        buf = torch.zeros(4096 * 8, dtype=torch.float32)
         n = lib.ssc_prof_collect(buf.data_ptr(), 4096)
         lib.ssc_prof_enable(0)
-        rec = buf[: n * 6].view(n, 6)
+        rec = buf[: n * 8].view(n, 8)   # kind, M, N, K, splits, ms, algorithmic bytes, flops (exact also for grouped launches)
         names = {0: "gemm_kernel<NT> (forward: x W^T)", 1: "gemm_kernel<NN> (backward: dG W)", 3: "gemm_kernel<TN> (dW = dG^T X)"}
         agg = {}
-        for kind, M, N, K, splits, msr in rec.tolist():
+        for kind, M, N, K, splits, msr, rbytes, rflops in rec.tolist():
             a = agg.setdefault(int(kind), dict(ms=0.0, flops=0.0, bytes=0.0, n=0))
             a["ms"] += msr
-            a["flops"] += 2.0 * M * N * K
-            a["bytes"] += 4.0 * (K * (M + N) + M * N * splits)
+            a["flops"] += rflops
+            a["bytes"] += rbytes
             a["n"] += 1
         if args.dump_gemm:
             shapes = {}
-            for kind, M, N, K, splits, msr in rec.tolist():
-                e = shapes.setdefault((int(kind), int(M), int(N), int(K), int(splits)), [0, 0.0])
+            for kind, M, N, K, splits, msr, rbytes, rflops in rec.tolist():
+                e = shapes.setdefault((int(kind), int(M), int(N), int(K), int(splits)), [0, 0.0, rbytes, rflops])
                 e[0] += 1
                 e[1] += msr
             with open(args.dump_gemm, "w") as f:
                 f.write("kind,M,N,K,splits,calls_per_step,avg_us,total_ms_per_step,TFLOPs,algGBps\n")
-                for (kind, M, N, K, sp), (cnt, tot) in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
+                for (kind, M, N, K, sp), (cnt, tot, rbytes, rflops) in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
                     us = tot / cnt * 1e3
                     f.write(f"{names[kind][12:14]},{M},{N},{K},{sp},{cnt / nprof:.1f},{us:.1f},{tot / nprof:.3f},"
-                            f"{2.0 * M * N * K / us / 1e6:.1f},{4.0 * (K * (M + N) + M * N * sp) / us / 1e3:.0f}\n")
+                            f"{rflops / us / 1e6:.1f},{rbytes / us / 1e3:.0f}\n")
         # Two regimes (DESIGN.md "GEMM"): the per-timestep MINIBATCH products (M = B rows against a wide weight matrix,
         # forward x W^T and backward dG W) stream every weight once per launch -> HBM-bound; the LARGE products over the
         # (t, b) rows (hoisted gate terms, vocabulary head, weight gradients) are bound by the bf16 matrix pipe, on which
         # the 3xBF16 kernels spend six MFMA passes per fp32 product.
         fam = {"minibatch": dict(ms=0.0, bytes=0.0, flops=0.0, n=0), "large": dict(ms=0.0, bytes=0.0, flops=0.0, n=0)}
-        for kind, M, N, K, splits, msr in rec.tolist():
+        for kind, M, N, K, splits, msr, rbytes, rflops in rec.tolist():
             f = fam["minibatch" if M <= c["B"] else "large"]
             f["ms"] += msr
-            f["bytes"] += 4.0 * (K * N + M * K + M * N)          # algorithmic: every operand and the result once
-            f["flops"] += 2.0 * M * N * K
+            f["bytes"] += rbytes          # algorithmic: every operand and the result once (summed over a group's members)
+            f["flops"] += rflops
             f["n"] += 1
         pm = {}
         try:  # HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/)
@@ -426,7 +426,8 @@ def main():
                    "algorithmic_bytes_per_launch": mb["bytes"] / max(1, mb["n"]), "launches_per_step": mb["n"] / nprof,
                    "avg_launch_us": mb["ms"] / max(1, mb["n"]) * 1e3, "share_of_gemm_time": mb["ms"] / total_gemm_ms}
         tf6 = 6.0 * lg["flops"] / (lg["ms"] * 1e-3) / 1e12
-        roof_lg = {"bound": "mfma", "kernel": "large 3xBF16 GEMMs (gemm_x3b_kernel<128x128>; 6 bf16 MFMA passes per fp32 product; "
+        roof_lg = {"bound": "mfma", "kernel": "large 3xBF16 GEMMs (128x128 tiles: wave-specialised gemm_x3w_kernel from 768 workgroups on "
+                   "and for the grouped weight gradients, 4-wave gemm_x3b_kernel below; 6 bf16 MFMA passes per fp32 product; "
                    "nominal K - padded rows skipped on the device count as done)",
                    "achieved": tf6, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": tf6 / MFMA_BF16_PEAK_TF,
                    "traffic": traffic_of(("gemm_x3b_kernel", "gemm_x3w_kernel<NT,128", "gemm_x3w_kernel<NN,128", "gemm_x3w_kernel<TN,128")),
@@ -435,11 +436,11 @@ def main():
         # the single dominant kernel: the wave-specialised 64x256 minibatch kernel in its two layouts (NT: forward x W^T,
         # NN: backward dG W; N >= 1024) - algorithmic bytes per launch / average launch duration, both from the events
         dom = {}
-        for kind, M, N, K, splits, msr in rec.tolist():
+        for kind, M, N, K, splits, msr, rbytes, rflops in rec.tolist():
             if M <= c["B"] and N >= 1024 and int(kind) in (0, 1):
                 e = dom.setdefault(int(kind), dict(ms=0.0, bytes=0.0, n=0))
                 e["ms"] += msr
-                e["bytes"] += 4.0 * (K * N + M * K + M * N)
+                e["bytes"] += rbytes
                 e["n"] += 1
         roof_dom = None
         if dom:

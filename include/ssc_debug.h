@@ -11,8 +11,10 @@ extern "C" {
 #endif
 
 /* In-situ GEMM profiling: while enabled every GEMM launch is bracketed by a hipEvent pair on its stream.
- * ssc_prof_collect synchronises the device and writes up to max_records x 6 floats
- * {kind (0 NT, 1 NN, 3 TN), M, N, sum K, splits, milliseconds}; returns the record count. */
+ * ssc_prof_collect synchronises the device and writes up to max_records x 8 floats
+ * {kind (0 NT, 1 NN, 3 TN), M, N, sum K, splits, milliseconds, algorithmic bytes, flops}; returns the record count.  A grouped
+ * launch is ONE record: its bytes (every operand and result of every member once) and flops (2 M N K per member) are exact,
+ * its N / K are nominal (widest member, summed K). */
 int ssc_prof_enable(int on);
 int ssc_prof_collect(float* out, int max_records);
 

@@ -1549,7 +1549,14 @@ typedef void (*gemm_fn)(const KArgs);
 struct ProfRec {
   hipEvent_t e0, e1;
   int kind, M, N, K, splits;
+  double bytes, flops;   // algorithmic: every operand and the result once, 2 M N K - summed over the members of a grouped launch
 };
+inline void prof_desc(ProfRec* rec, const ssc_gemm_desc* d) {   // adds one product to a record
+  double K = 0;
+  for (int i = 0; i < d->nseg; ++i) K += d->seg[i].K;
+  rec->bytes += 4.0 * (K * d->N + (double)d->M * K + (double)d->M * d->N);
+  rec->flops += 2.0 * d->M * d->N * K;
+}
 constexpr int PROF_MAX = 4096;
 ProfRec* g_prof = nullptr;
 int g_prof_n = 0;
@@ -1728,9 +1735,11 @@ int launch(const ssc_gemm_desc* d, KArgs& k, int splits, hipStream_t st) {
     ProfRec* rec = nullptr;
     if (g_prof_on && g_prof && g_prof_n < PROF_MAX) {
       rec = &g_prof[g_prof_n++];
+      rec->bytes = rec->flops = 0.0;
       rec->kind = (d->a_kc ? 0 : 2) + (d->b_kc ? 0 : 1);
       rec->M = d->M; rec->N = d->N; rec->splits = splits; rec->K = 0;
       for (int i = 0; i < d->nseg; ++i) rec->K += d->seg[i].K;
+      prof_desc(rec, d);
       (void)hipEventRecord(rec->e0, st);
     }
     SSC_TRY(x3w_prepare());
@@ -1746,9 +1755,11 @@ int launch(const ssc_gemm_desc* d, KArgs& k, int splits, hipStream_t st) {
     ProfRec* rec = nullptr;
     if (g_prof_on && g_prof && g_prof_n < PROF_MAX) {
       rec = &g_prof[g_prof_n++];
+      rec->bytes = rec->flops = 0.0;
       rec->kind = (d->a_kc ? 0 : 2) + (d->b_kc ? 0 : 1);
       rec->M = d->M; rec->N = d->N; rec->splits = splits; rec->K = 0;
       for (int i = 0; i < d->nseg; ++i) rec->K += d->seg[i].K;
+      prof_desc(rec, d);
       (void)hipEventRecord(rec->e0, st);
     }
     const bool kg = k.karows || k.kbrows;
@@ -1778,8 +1789,10 @@ int launch(const ssc_gemm_desc* d, KArgs& k, int splits, hipStream_t st) {
     ProfRec* rec = nullptr;
     if (g_prof_on && g_prof && g_prof_n < PROF_MAX) {
       rec = &g_prof[g_prof_n++];
+      rec->bytes = rec->flops = 0.0;
       rec->kind = 0; rec->M = d->M; rec->N = d->N; rec->splits = splits; rec->K = 0;
       for (int i = 0; i < d->nseg; ++i) rec->K += d->seg[i].K;
+      prof_desc(rec, d);
       (void)hipEventRecord(rec->e0, st);
     }
     if (wide && g_x3_nbuf == 1) SSC_LAUNCH((gemm_x3_kernel<2, 2, 1>), grid, dim3(256), 0, st, k);
@@ -1802,10 +1815,12 @@ int launch(const ssc_gemm_desc* d, KArgs& k, int splits, hipStream_t st) {
   ProfRec* rec = nullptr;
   if (g_prof_on && g_prof && g_prof_n < PROF_MAX) {
     rec = &g_prof[g_prof_n++];
+      rec->bytes = rec->flops = 0.0;
     rec->kind = (d->a_kc ? 0 : 2) + (d->b_kc ? 0 : 1);  // 0 NT, 1 NN, 3 TN
     rec->M = d->M; rec->N = d->N; rec->splits = splits;
     rec->K = 0;
     for (int i = 0; i < d->nseg; ++i) rec->K += d->seg[i].K;
+      prof_desc(rec, d);
     (void)hipEventRecord(rec->e0, st);
   }
   SSC_LAUNCH(fn, grid, dim3(256), 0, st, k);
@@ -1978,10 +1993,12 @@ int ssc_gemm_slabs_group(const ssc_gemm_desc* const* d, int n, float* const* reg
   for (int i = n; i < SSC_GROUP_MAX; ++i) { g.first[i + 1] = g.first[n]; g.gx[i] = 1; g.gy[i] = 1; g.gz[i] = 1; }
   SSC_TRY(x3w_prepare());
   ProfRec* rec = nullptr;
-  if (g_prof_on && g_prof && g_prof_n < PROF_MAX) {  // one record for the group: the weight bytes add up exactly (same N)
+  if (g_prof_on && g_prof && g_prof_n < PROF_MAX) {  // one record for the group
     rec = &g_prof[g_prof_n++];
+      rec->bytes = rec->flops = 0.0;
     rec->kind = d[0]->b_kc ? 0 : 1;
-    rec->M = d[0]->M; rec->N = Nmax; rec->splits = nslab[0]; rec->K = Ksum;
+    rec->M = d[0]->M; rec->N = Nmax; rec->splits = nslab[0]; rec->K = Ksum;   // (N, K: nominal; bytes / flops are exact)
+    for (int i = 0; i < n; ++i) prof_desc(rec, d[i]);
     (void)hipEventRecord(rec->e0, st);
   }
   SSC_LAUNCH(x3w_skinny_fn(d[0]->b_kc), dim3(g.first[n]), dim3(x3w_skinny_threads()), (x3w_lds_bytes<64, 256>()), st, g);
@@ -2031,8 +2048,10 @@ int ssc_gemm_dw_group(const ssc_gemm_desc* const* d, int n, hipStream_t st) {
       ProfRec* rec = nullptr;
       if (g_prof_on && g_prof && g_prof_n < PROF_MAX) {  // one record: 2*K*sum(M_i N_i) flops
         rec = &g_prof[g_prof_n++];
+      rec->bytes = rec->flops = 0.0;
         rec->kind = 3;
         rec->M = (int)(MN / d[i]->N); rec->N = d[i]->N; rec->splits = 1; rec->K = (int)Ksum;
+        for (int q = i; q < j; ++q) prof_desc(rec, d[q]);
         (void)hipEventRecord(rec->e0, st);
       }
       SSC_LAUNCH(x3w_big_fn(false, false, kg0), dim3(g.first[m]), dim3(x3w_big_threads()), (x3w_lds_bytes<128, 128>()), st, g);
@@ -2110,9 +2129,9 @@ extern "C" int ssc_prof_collect(float* out, int max_records) {
   for (int i = 0; i < n; ++i) {
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, g_prof[i].e0, g_prof[i].e1);
-    float* o = out + (size_t)i * 6;
+    float* o = out + (size_t)i * 8;
     o[0] = (float)g_prof[i].kind; o[1] = (float)g_prof[i].M; o[2] = (float)g_prof[i].N; o[3] = (float)g_prof[i].K;
-    o[4] = (float)g_prof[i].splits; o[5] = ms;
+    o[4] = (float)g_prof[i].splits; o[5] = ms; o[6] = (float)g_prof[i].bytes; o[7] = (float)g_prof[i].flops;
   }
   g_prof_n = 0;
   return n;
