@@ -35,8 +35,8 @@ def short(name):
     m = re.search(r"gemm_x3_kernel<(\d), (\d), (\d)>", name)
     if m:
         return f"gemm_x3_kernel<NT,64x{64 * int(m.group(2))},lds{m.group(3)}>"
-    m = re.search(r"(?:\(anonymous namespace\)::)?(\w+)\(", name)
-    return m.group(1) if m else name[:50]
+    m = re.search(r"(?:\(anonymous namespace\)::)?(\w+)(<[\w, ]*>)?\(", name)
+    return (m.group(1) + (m.group(2) or "")) if m else name[:50]
 
 
 def pmc(fetch_csv, write_csv, out):
