@@ -1149,7 +1149,7 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
     // the host (x3w_span_ok).
     unsigned oa[NA], ob[NB];  // offset of the chunk at a k-step inside the segment
     unsigned za[NA], zb[NB];  // offset used when the chunk lies past the end of K (same row / column, first k of the step: in range)
-    int ia[NA], ib[NB];       // KG: gathered k-row numbers of the NEXT step
+    int ia[2][NA], ib[2][NB];   // KG: gathered k-row numbers of the next step, buffer = parity of that step (relative to s_lo)
     Cursor cur;
     int s_ld = s_lo;
     // chunk idx: k-contiguous operand -> (row idx>>3, k 4*(idx&7)); m/n-contiguous -> (k idx/Q, column 4*(idx%Q))
@@ -1192,21 +1192,25 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
         }
       }
     };
-    auto prefetch_rows = [&]() __attribute__((always_inline)) {  // KG: row numbers of the k-step after the cursor's (clamped)
+    // KG: the row numbers of the k-step after the cursor's (clamped) go to buffer `buf` = parity of that step.  Two buffers with
+    // compile-time roles (the loop is unrolled by two): with ONE array that was copied into the offsets a step later, hipcc
+    // resolved the loop-carried copy right behind the list loads - `s_waitcnt vmcnt(0)` in the middle of every k-step, a whole
+    // memory round trip in the producers' issue phase (stamps: 0.55 us against 0.25 us without lists).
+    auto prefetch_rows = [&](int buf) __attribute__((always_inline)) {
       if constexpr (KG) {
 #pragma unroll
         for (int u = 0; u < NA; ++u) {
           const int kr = min(cur.k0 + BK + (tid + NPT * u) / QA, cur.K - 1);
-          ia[u] = a.karows[kr];
+          ia[buf][u] = a.karows[kr];
         }
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
           const int kr = min(cur.k0 + BK + (tid + NPT * u) / QB, cur.K - 1);
-          ib[u] = a.kbrows[kr];
+          ib[buf][u] = a.kbrows[kr];
         }
       }
     };
-    auto step_ptrs = [&](int how) __attribute__((always_inline)) {
+    auto step_ptrs = [&](int how, int buf) __attribute__((always_inline)) {
       if constexpr (KG) {
         // gathered k-rows (single segment by construction: how is 0 or 1): the row numbers follow the lists, the base stays at
         // the segment start.  No base_ptrs() here: a second site that stores list entries into the same arrays makes hipcc
@@ -1214,10 +1218,10 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
         // is a vector-memory operation and its wait drains the staged loads).
         if (how != 0) {
 #pragma unroll
-          for (int u = 0; u < NA; ++u) oa[u] = (unsigned)ia[u];
+          for (int u = 0; u < NA; ++u) oa[u] = (unsigned)ia[buf][u];
 #pragma unroll
-          for (int u = 0; u < NB; ++u) ob[u] = (unsigned)ib[u];
-          prefetch_rows();
+          for (int u = 0; u < NB; ++u) ob[u] = (unsigned)ib[buf][u];
+          prefetch_rows(buf ^ 1);
         }
       } else {
         if (how == 2) base_ptrs();   // offsets only change with the segment; the bases follow the cursor
@@ -1242,7 +1246,7 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
           ma |= (kc_in ? 1u : 0u) << u;
         } else {
           const bool in = cur.k0 + idx / QA < cur.K;
-          if constexpr (KG) ea[u] = oa[u] * ((unsigned)cur.lda * 4u) + za[u];
+          if constexpr (KG) ea[u] = __umul24(oa[u], (unsigned)cur.lda * 4u) + za[u];   // 24-bit multiply-add: the 64-bit form (v_mad_u64_u32) took a register PAIR as addend whose undefined high half hipcc placed on the destination of a list load in flight - a false dependency and a vmcnt wait in front of every staged load
           else ea[u] = in ? oa[u] : za[u];
           ma |= (in ? 1u : 0u) << u;
         }
@@ -1255,7 +1259,7 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
           mb |= (kc_in ? 1u : 0u) << u;
         } else {
           const bool in = cur.k0 + idx / QB < cur.K;
-          if constexpr (KG) eb[u] = ob[u] * ((unsigned)cur.ldb * 4u) + zb[u];
+          if constexpr (KG) eb[u] = __umul24(ob[u], (unsigned)cur.ldb * 4u) + zb[u];
           else eb[u] = in ? ob[u] : zb[u];
           mb |= (in ? 1u : 0u) << u;
         }
@@ -1273,10 +1277,10 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
 #pragma unroll
       for (int u = 0; u < NB; ++u) asm volatile("" : "+v"(xb[u])::"memory");
     };
-    auto advance = [&]() __attribute__((always_inline)) {
+    auto advance = [&](int buf) __attribute__((always_inline)) {   // buf: parity of the step the cursor moves TO (KG row buffers)
       const int how = cur.advance(a, s_ld >= s_last);
       s_ld = min(s_ld + 1, s_last);
-      step_ptrs(how);
+      step_ptrs(how, buf);
     };
     auto put_chunk = [&](unsigned char* p, int plane, f32x4 v, bool ok) __attribute__((always_inline)) {
       if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1309,14 +1313,14 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
       cur.init(a, s_lo);
       if (a.kcount) { cur.K = Kc; cur.left = steps_total - 1 - cur.k0 / BK; }
       base_ptrs();
-      prefetch_rows();
+      prefetch_rows(1);   // rows of step s_lo + 1
       // the first PF tiles are requested back to back (one exposed memory latency, not two); afterwards set (r+1) % PF
       // holds tile s_lo + r + 1 when iteration r starts
       SSC_STAMP(120);   // setup done, nothing requested yet
       issue_loads(ra[0], rb[0], oka[0], okb[0], fullk[0]);
 #pragma unroll
       for (int j = 1; j < PF; ++j) {
-        advance();
+        advance(j & 1);
         issue_loads(ra[j], rb[j], oka[j], okb[j], fullk[j]);
       }
       SSC_STAMP(121);   // first PF tiles requested
@@ -1324,7 +1328,7 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
       pin(ra[0], rb[0]);
       SSC_STAMP(122);   // first tile landed
       put_planes(lds, ra[0], rb[0], oka[0], okb[0], fullk[0]);
-      advance();
+      advance(PF & 1);
       issue_loads(ra[0], rb[0], oka[0], okb[0], fullk[0]);
     }
     __syncthreads();
@@ -1344,7 +1348,7 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
         SSC_STAMP(4 * (s + h - s_lo));
         if (s + h + 1 < s_hi) put_planes(lds + ((h + 1) & 1) * STAGE, ra[j], rb[j], oka[j], okb[j], fullk[j]);   // VALU + LDS only
         SSC_STAMP(4 * (s + h - s_lo) + 1);
-        advance();
+        advance((h + 1 + PF) & 1);   // the cursor moves to step (s + h - s_lo) + 1 + PF
         issue_loads(ra[j], rb[j], oka[j], okb[j], fullk[j]);
         SSC_STAMP(4 * (s + h - s_lo) + 2);
         __syncthreads();
@@ -1705,6 +1709,9 @@ inline bool x3w_skinny(const ssc_gemm_desc* d, bool vec) {   // 2 = only where t
 // the wave-specialised kernels address an operand as (uniform 64-bit base) + (32-bit byte offset per lane)
 inline bool x3w_span_ok(const ssc_gemm_desc* d) {
   const size_t lim = (size_t)1 << 30;   // floats
+  if (d->ka_rows || d->kb_rows)         // gathered k-rows: offset = row * (ld * 4) by a 24-bit multiply
+    for (int i = 0; i < d->nseg; ++i)
+      if (d->seg[i].lda >= (1 << 22) || d->seg[i].ldb >= (1 << 22) || d->seg[i].K >= (1 << 24)) return false;
   for (int i = 0; i < d->nseg; ++i) {
     const size_t K = (size_t)d->seg[i].K;
     if (K == 0) continue;

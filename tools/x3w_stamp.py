@@ -61,11 +61,19 @@ def run(shape, wg):
     ws = torch.empty(max(40 * 64 * 4800, 10 * M * N) + 4096, device="cuda")
     segs = [(a, a.stride(0), b, b.stride(0), K) for a, b, K in zip(As, Bs, Ks)]
     buf = torch.zeros(2048, dtype=torch.int64, device="cuda")
+    compact = None
+    if os.environ.get("SSC_STAMP_GATHER") and kind == "TN":   # weight-gradient form: both operands gathered by k-row lists
+        keep = torch.rand(Ks[0]) < 0.71
+        rows = torch.nonzero(keep).flatten().to(torch.int32)
+        cnt = torch.tensor([rows.numel(), 0, 0, 0], dtype=torch.int32)
+        lst = torch.cat([rows, torch.zeros(Ks[0] - rows.numel(), dtype=torch.int32)]).cuda()
+        compact = {"k_count": cnt.cuda(), "ka_rows": lst, "kb_rows": lst}
+        run.keepalive = compact
     for _ in range(5):
-        gemm(segs, M, N, a_kc, b_kc, out, ws=ws)
+        gemm(segs, M, N, a_kc, b_kc, out, ws=ws, compact=compact)
     torch.cuda.synchronize()
     assert setup(buf.data_ptr(), wg) == 0
-    gemm(segs, M, N, a_kc, b_kc, out, ws=ws)
+    gemm(segs, M, N, a_kc, b_kc, out, ws=ws, compact=compact)
     torch.cuda.synchronize()
     setup(None, -1)
     st = buf.cpu().tolist()
