@@ -333,3 +333,45 @@ def test_lstm_fwd_p_partial_products_sum_to_the_linear_layer(B, H, NP, nslab):
     want = hp.double() @ wp[:, :H].double().t()
     assert torch.isfinite(pout).all()
     assert (pout.double().sum(0) - want).abs().max().item() < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("G,R,A,F,rpi", [(64, 36, 768, 2048, 1), (128, 100, 768, 2048, 1), (3, 5, 32, 64, 1), (7, 70, 1024, 100, 1),
+                                         (10, 36, 260, 4096, 5), (9, 130, 64, 2052, 3)])
+def test_attention_forward_matches_float64(G, R, A, F, rpi):
+    """ssc_attn_fwd (attention.py:69-95 + updown_cell.py:151-158) against float64: logits, allennlp masked softmax (masked logits
+    zeroed, not -inf'd, then renormalised with 1e-13) and the weighted sum, with zero-padded regions, rows sharing an image
+    (rpi > 1) and widths that are no multiple of the kernels' 256-column chunks.  2e-5 on values of order 1: hardware exp2 / rcp
+    in the tanh (ssc_tanh_fast, <= 2 ulp) and the summation order."""
+    from ssc_runtime import lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(G * 131 + R)
+    n_img = (G + rpi - 1) // rpi
+    feats = torch.randn(n_img, R, F, generator=g)
+    mask = torch.ones(n_img, R)
+    if R > 4:
+        mask[0, R - 3:] = 0.0
+        mask[-1, 1] = 0.0
+    feats = feats * mask[:, :, None]
+    pv = torch.randn(n_img, R, A, generator=g) * mask[:, :, None]
+    q, wa = torch.randn(G, A, generator=g), torch.randn(A, generator=g) * 0.3
+    img = torch.arange(G) // rpi
+    lg = (torch.tanh(q.double()[:, None, :] + pv.double()[img]) * wa.double()).sum(-1)
+    m = mask.double()[img]
+    p = torch.softmax(lg * m, dim=1) * m
+    al_w = p / (p.sum(1, keepdim=True) + 1e-13)
+    att_w = (al_w[:, :, None] * feats.double()[img]).sum(1)
+    d = "cuda"
+    q_d, pv_d, wa_d, mask_d, feats_d = q.to(d), pv.to(d), wa.to(d), mask.to(d), feats.to(d)
+    logits, alpha = torch.full((G, R), float("nan"), device=d), torch.full((G, R), float("nan"), device=d)
+    ldatt = F + 4
+    att = torch.full((G, ldatt), float("nan"), device=d)
+    lib.ssc_attn_fwd(L.ptr(q_d), A, L.ptr(pv_d), L.ptr(wa_d), L.ptr(mask_d), L.ptr(feats_d), G, R, A, F, rpi,
+                     L.ptr(logits), L.ptr(alpha), L.ptr(att), ldatt, L.stream_ptr())
+    torch.cuda.synchronize()
+    assert (logits.double().cpu() - lg).abs().max().item() < 2e-5 * max(1.0, lg.abs().max().item())
+    assert (alpha.double().cpu() - al_w).abs().max().item() < 2e-5
+    assert (att[:, :F].double().cpu() - att_w).abs().max().item() < 2e-5 * max(1.0, att_w.abs().max().item())
+    assert torch.isnan(att[:, F:]).all()          # nothing written past the F columns of a row
+    if R > 4:
+        assert float(alpha[0, R - 3:].abs().max()) == 0.0
