@@ -40,6 +40,11 @@ parser.add_argument("--constraints-json", default="",
                          "constraint classes per image (what the reference's EvaluationDatasetWithConstraints derives from detector "
                          "boxes, updown-baseline/updown/data/datasets.py:470-620); needs --wordforms-tsv")
 parser.add_argument("--wordforms-tsv", default="", help="class name <TAB> comma separated word forms (data/constraint_wordforms*.tsv)")
+parser.add_argument("--boxes-json", default="",
+                    help='instead of --constraints-json: raw detections {"<image_id>": {"boxes": [[x1, y1, x2, y2], ...], "class_names": [...], '
+                         '"scores": [...]}}, filtered to constraints by ssc_runtime.constraints.ConstraintFilter '
+                         "(updown-baseline/updown/utils/constraints.py:56-209); needs --hierarchy-json and --wordforms-tsv")
+parser.add_argument("--hierarchy-json", default="", help="Open Images class hierarchy (bbox_labels_600_hierarchy_readable.json)")
 
 
 class _LocalGlove(UpDownCaptioner):
@@ -78,12 +83,20 @@ def main():
     predictions = []
     constraints, builder = {}, None
     per_call = _A.images_per_call
-    if _A.constraints_json:
-        from ssc_runtime.constraints import FiniteStateMachineBuilder
+    if _A.constraints_json or _A.boxes_json:
+        from ssc_runtime.constraints import ConstraintFilter, FiniteStateMachineBuilder
         if not _A.wordforms_tsv:
-            raise SystemExit("--constraints-json needs --wordforms-tsv")
-        constraints = {int(k): v for k, v in json.load(open(_A.constraints_json)).items()}
+            raise SystemExit("--constraints-json / --boxes-json need --wordforms-tsv")
         kmax = max(1, _C.DATA.CBS.MAX_GIVEN_CONSTRAINTS)
+        if _A.boxes_json:
+            if not _A.hierarchy_json:
+                raise SystemExit("--boxes-json needs --hierarchy-json")
+            cfilter = ConstraintFilter(_A.hierarchy_json, _C.DATA.CBS.NMS_THRESHOLD, kmax)
+            constraints = {int(k): sorted(cfilter(np.asarray(v["boxes"], dtype=np.float32).reshape(-1, 4), v["class_names"],
+                                                  np.asarray(v["scores"], dtype=np.float32)))
+                           for k, v in json.load(open(_A.boxes_json)).items()}
+        else:
+            constraints = {int(k): v for k, v in json.load(open(_A.constraints_json)).items()}
         builder = FiniteStateMachineBuilder(vocabulary, _A.wordforms_tsv, None, max_given_constraints=kmax,
                                             max_words_per_constraint=_C.DATA.CBS.MAX_WORDS_PER_CONSTRAINT)
         per_call = min(per_call, 4)   # (B, S, S, V) uint8 per (image, sample): keep the machines of one call within ~1 GB

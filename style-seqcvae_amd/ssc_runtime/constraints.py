@@ -12,11 +12,15 @@ word of a multi-word constraint on each edge it labels ("fire" seen, waiting for
 the edge's origin).  `constraint2states[c]` lists the main states (below 2**len(constraints)) in which c is satisfied:
 what `select_best_beam_with_constraints(cbs_simple=False)` consumes (ssc_runtime/decoding.py).
 
-The `ConstraintFilter` (hierarchy-aware NMS over detector boxes, constraints.py:56-209) is not here: it needs the Open
-Images class hierarchy (anytree) and detector outputs and runs once per image, far from the hot path.
+`ConstraintFilter` (constraints.py:56-209) turns one image's detector output into at most k constraint classes: blacklist,
+hierarchy-aware suppression of overlapping boxes (a "dog" box suppresses a "carnivore" box on the same pixels), top-k by
+confidence.  The reference keeps the Open Images hierarchy in an `anytree` tree; anytree is not importable here, so the tree is
+flattened at load time (pre-order label list + node heights) and the reference cannot be run for fixtures: **parity unpinned**
+beyond the hand-checkable cases of tests/test_constraints_cpu.py.  It runs once per image on the host, far from the hot path.
 """
 import csv
-from typing import Dict, Iterable, List, Optional, Sequence, Tuple
+import json
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple, Union
 
 import numpy as np
 import torch
@@ -39,6 +43,86 @@ def add_constraint_words_to_vocabulary(vocabulary, wordforms_tsvpath: str, names
         for w in forms:
             vocabulary.add_token_to_namespace(w, namespace)
     return vocabulary
+
+
+class ConstraintFilter:
+    """Same constructor and call contract as the reference class (constraints.py:105-153): `filter(boxes (n, 4) x1 y1 x2 y2,
+    class_names, scores)` -> constraint class names (unordered, duplicates dropped)."""
+
+    # classes that never become constraints (too rare, not uttered, or well covered by COCO): constraints.py:84-94
+    BLACKLIST = frozenset((
+        "auto part", "bathroom accessory", "bicycle wheel", "boy", "building", "clothing", "door handle", "fashion accessory",
+        "footwear", "girl", "hiking equipment", "human arm", "human beard", "human body", "human ear", "human eye", "human face",
+        "human foot", "human hair", "human hand", "human head", "human leg", "human mouth", "human nose", "land vehicle",
+        "mammal", "man", "person", "personal care", "plant", "plumbing fixture", "seat belt", "skull", "sports equipment", "tire",
+        "tree", "vehicle registration plate", "wheel", "woman"))
+    # detector class name -> constraint word (constraints.py:96-103)
+    REPLACEMENTS = {"band-aid": "bandaid", "wood-burning stove": "wood burning stove", "kitchen & dining room table": "table",
+                    "salt and pepper shakers": "salt and pepper", "power plugs and sockets": "power plugs",
+                    "luggage and bags": "luggage"}
+
+    def __init__(self, hierarchy_jsonpath: Union[str, dict], nms_threshold: float = 0.85, max_given_constraints: int = 3):
+        root = hierarchy_jsonpath if isinstance(hierarchy_jsonpath, dict) else json.load(open(hierarchy_jsonpath))
+        # pre-order walk of {"LabelName": ..., "Subcategory": [...]}: lower-cased labels and node heights (edges on the longest
+        # path down to a leaf - anytree's `height`), iteratively
+        self._labels: List[str] = []
+        self._heights: List[int] = []
+        stack = [(root, None)]
+        parents: List[Optional[int]] = []
+        while stack:
+            node, parent = stack.pop()
+            idx = len(self._labels)
+            self._labels.append(str(node["LabelName"]).lower())
+            self._heights.append(0)
+            parents.append(parent)
+            for child in reversed(node.get("Subcategory", [])):   # reversed: the stack pops the first child first
+                stack.append((child, idx))
+        for idx in range(len(parents) - 1, -1, -1):               # children come after their parent in pre-order
+            if parents[idx] is not None:
+                self._heights[parents[idx]] = max(self._heights[parents[idx]], self._heights[idx] + 1)
+        self._nms_threshold = nms_threshold
+        self._max_given_constraints = max_given_constraints
+        self._height_cache: Dict[str, int] = {}
+
+    def height(self, class_name: str) -> int:
+        """Height of the FIRST node in pre-order whose label is contained in the class name (constraints.py:163-166: `findall(...,
+        node.LabelName.lower() in c)[0].height`; IndexError when nothing matches, as there)."""
+        if class_name not in self._height_cache:
+            hit = next((i for i, lab in enumerate(self._labels) if lab in class_name), None)
+            if hit is None:
+                raise IndexError(f"no class of the hierarchy is contained in {class_name!r}")
+            self._height_cache[class_name] = self._heights[hit]
+        return self._height_cache[class_name]
+
+    def __call__(self, boxes: np.ndarray, class_names: Sequence[str], scores: np.ndarray) -> List[str]:
+        boxes = np.asarray(boxes, dtype=np.float64).reshape(-1, 4)
+        scores = np.asarray(scores, dtype=np.float64).reshape(-1)
+        # padding boxes (confidence 0) and blacklisted classes never become constraints
+        cand = [i for i, c in enumerate(class_names) if scores[i] > 0 and c not in self.BLACKLIST]
+        if not cand:
+            return []
+        names = [class_names[i] for i in cand]
+        keep = self._suppress(boxes[cand], names)
+        # top-k by confidence (stable: equal scores keep the suppression pass's order), renamed, duplicates dropped
+        ranked = sorted(keep, key=lambda i: -scores[cand[i]])[: self._max_given_constraints]
+        return list({self.REPLACEMENTS.get(names[i], names[i]) for i in ranked})
+
+    def _suppress(self, boxes: np.ndarray, names: Sequence[str]) -> List[int]:
+        """Indices kept, finest class first.  A box is dropped iff a KEPT box of a strictly finer class (smaller height)
+        overlaps it with IoU > threshold; boxes of equal height never suppress each other (constraints.py:155-209, restated
+        over the full IoU matrix instead of the shrinking work list; IoU with the pixel-inclusive +1 of the reference)."""
+        h = np.array([self.height(c) for c in names])
+        x1, y1, x2, y2 = boxes.T
+        area = (x2 - x1 + 1) * (y2 - y1 + 1)
+        iw = np.maximum(0.0, np.minimum(x2[:, None], x2[None, :]) - np.maximum(x1[:, None], x1[None, :]) + 1)
+        ih = np.maximum(0.0, np.minimum(y2[:, None], y2[None, :]) - np.maximum(y1[:, None], y1[None, :]) + 1)
+        inter = iw * ih
+        iou = inter / (area[:, None] + area[None, :] - inter)
+        kept: List[int] = []
+        for i in np.argsort(h, kind="stable"):
+            if not any(h[j] < h[i] and iou[j, i] > self._nms_threshold for j in kept):
+                kept.append(int(i))
+        return kept
 
 
 class FiniteStateMachineBuilder:

@@ -122,3 +122,32 @@ def test_inference_script_with_per_image_constraints(tmp_path):
                 assert "w7" in words or "w8" in words, p
             else:
                 assert any(a == "w20" and b in ("w21", "w22") for a, b in zip(words, words[1:])), p
+
+
+def test_inference_script_with_detector_boxes(tmp_path):
+    """scripts/inference.py --boxes-json: raw detections -> ConstraintFilter (hierarchy-aware suppression, top-k) -> per-image
+    machines -> constrained decode: the finer class of two overlapping boxes is the constraint that shows up in the captions."""
+    cfg = tmp_path / "cfg.yaml"
+    cfg.write_text(YAML)
+    tsv = tmp_path / "wf.tsv"
+    tsv.write_text("w7\tw7,w8\nw20\tw20\nw30\tw30\n")
+    hier = {"LabelName": "Entity", "Subcategory": [{"LabelName": "w30", "Subcategory": [{"LabelName": "w7"}]}, {"LabelName": "w20"}]}
+    hj = tmp_path / "hier.json"
+    hj.write_text(json.dumps(hier))
+    big = [10, 10, 110, 110]
+    boxes = {"0": {"boxes": [big, big], "class_names": ["w30", "w7"], "scores": [0.9, 0.4]},            # w7 suppresses its parent w30
+             "2": {"boxes": [big, [300, 300, 400, 400], [0, 0, 0, 0]], "class_names": ["w30", "w20", "w7"], "scores": [0.9, 0.8, 0.0]}}
+    bj = tmp_path / "boxes.json"
+    bj.write_text(json.dumps(boxes))
+    out = tmp_path / "pred.json"
+    run([os.path.join(ROOT, "scripts", "inference.py"), "--config", str(cfg), "--gpu-ids", "0", "--synthetic", "4",
+         "--vocab-size", "150", "--num-boxes", "5", "--output-path", str(out), "--boxes-json", str(bj), "--hierarchy-json", str(hj),
+         "--wordforms-tsv", str(tsv), "--config-override", "DATA.CBS.MAX_GIVEN_CONSTRAINTS", "2", "MODEL.MIN_CONSTRAINTS_TO_SATISFY", "2"], ROOT)
+    preds = json.load(open(out))
+    assert len(preds) == 4 * 4
+    for p in preds:
+        words = p["caption"].split()
+        if p["image_id"] == 0:
+            assert "w7" in words or "w8" in words, p
+        if p["image_id"] == 2:
+            assert "w30" in words and "w20" in words, p
