@@ -175,6 +175,7 @@ class TrainEngine:
         self.fwd_version = 0
         self.dp_buckets = 1
         self.dp_overlap = True
+        self.dp_force = False         # take the phased / overlapped path in a one-rank group too (tests: the real RCCL backend on one GPU)
         self.dp_autograd = False      # the autograd path (UpDownCaptioner.forward + loss.backward()) all-reduces the flat
                                       # gradient buffer inside backward (scripts/train.py without --fused-optimizer)
         self.dp_profile = False       # record the exposed all-reduce time of every overlapped backward (bench.py --gpus N)
@@ -410,7 +411,7 @@ class TrainEngine:
         import torch.distributed as dist
 
         skip = self.decoder_names if decoder_frozen else ()
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1 and self.dp_overlap:
+        if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or self.dp_force) and self.dp_overlap:
             world = self.backward_overlapped(gl, gk, skip=skip, group=group)
         else:
             self.backward(gl, gk, skip=skip)

@@ -76,3 +76,54 @@ def test_two_rank_train_step_equals_single_process():
     want = eng.state_dict()
     for k, v in want.items():
         assert maxdiff(got[k], v) < 2e-6, k
+
+
+def _rccl_worker(port, ret):
+    """One rank on the REAL RCCL backend ("nccl" on ROCm; the gloo tests above never touch it): process-group init bound to the
+    device, the phased backward with its four asynchronous all-reduces of flat gradient ranges, work.wait() on the compute
+    stream, the exposure timing, a barrier and the float64 MAX reduction bench.py uses for its clock."""
+    import torch.distributed as dist
+    from gpuutil import engine_from
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    device = torch.device("cuda", 0)
+    torch.cuda.set_device(device)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+    cfg = oracle.OracleConfig(**CFG)
+    eng = engine_from(cfg, oracle.init_params(cfg, seed=4))
+    eng.dp_force = True
+    eng.dp_profile = True
+    feats, caps, senti, eps = _inputs()
+    for frozen in (True, False):
+        _step(eng, feats, caps, senti, eps, frozen)
+    exposure = eng.dp_exposure_ms()
+    dist.barrier()
+    t = torch.tensor([1.25], device=device, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    torch.cuda.synchronize()
+    ret.put(({k: v.cpu() for k, v in eng.state_dict().items()}, float(t.item()), exposure))
+    dist.destroy_process_group()
+
+
+def test_overlapped_backward_on_the_rccl_backend_one_rank():
+    from gpuutil import engine_from, maxdiff
+    ctx = mp.get_context("spawn")
+    ret = ctx.SimpleQueue()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    p = ctx.Process(target=_rccl_worker, args=(port, ret))
+    p.start()
+    got, tmax, exposure = ret.get()
+    p.join(120)
+    assert p.exitcode == 0
+    assert tmax == 1.25
+    assert len(exposure) == 2 and all(x >= 0.0 for x in exposure)
+    cfg = oracle.OracleConfig(**CFG)
+    eng = engine_from(cfg, oracle.init_params(cfg, seed=4))
+    feats, caps, senti, eps = _inputs()
+    for frozen in (True, False):
+        _step(eng, feats, caps, senti, eps, frozen)
+    for k, v in eng.state_dict().items():
+        assert maxdiff(got[k], v) < 2e-6, k
