@@ -331,7 +331,7 @@ def main():
         t = torch.tensor([sum(ex) / max(1, len(ex)), max(ex) if ex else 0.0], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dp_exposure = {"allreduce_exposed_ms_per_step_mean": float(t[0]), "allreduce_exposed_ms_per_step_max": float(t[1]),
-                       "bytes_per_step": int(eng.grads.flat.numel() * 4), "scheme": "4 phase-ordered ranges, async behind the "
+                       "bytes_per_step": int(eng.grads.flat.numel() * 4), "scheme": "4 ranges (output head behind the BPTT loop, then the three weight-gradient groups), async behind the "
                        "backward phases (engine.backward_overlapped)"}
         if rank == 0:
             print("data-parallel exchange:", json.dumps(dp_exposure), file=sys.stderr, flush=True)

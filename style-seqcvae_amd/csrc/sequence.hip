@@ -611,10 +611,11 @@ __global__ void repeat_kernel(const float* __restrict__ src, int n, int reps, fl
 }
 }  // namespace
 
-// phases (bit mask): 1 = vocabulary head + BPTT time loop (output-head gradients are final after it), 2 = embedding,
-// attention-LSTM and attention-projection gradients, 4 = encoder-LSTM and latent-head gradients, 8 = decoder-LSTM
-// gradients.  Phases must run in this order on one stream; splitting them lets the caller start the all-reduce of a
-// finished gradient range while the next phase computes (ssc_runtime/engine.py).
+// phases (bit mask): 1 = vocabulary head + BPTT time loop, or its halves 16 = vocabulary head (output-head gradients are final
+// after it) and 32 = BPTT time loop; 2 = embedding, attention-LSTM and attention-projection gradients, 4 = encoder-LSTM and
+// latent-head gradients, 8 = decoder-LSTM gradients.  Phases must run in the order 16, 32, 2, 4, 8 on one stream; splitting
+// them lets the caller start the all-reduce of a finished gradient range while the next phase computes
+// (ssc_runtime/engine.py): the output head's 48 MB travel under the whole time loop.
 static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const ssc_batch* bt, void* workspace,
                           size_t workspace_bytes, const float* gl, const float* gk, const ssc_params* g, void* stream,
                           unsigned phases) {
@@ -633,7 +634,7 @@ static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const s
   c.act_count = (const int*)(W + l.act); c.act_rows = c.act_count + 4;  // built by ssc_train_fwd of this minibatch
   c.live_count = (const int*)(W + l.live); c.live_rows = c.live_count + 4;
 
-  if (phases & 1u) {
+  if (phases & (1u | 16u)) {
   // ---- vocabulary head ------------------------------------------------------------------------------
   SSC_TRY(ssc_ce_bwd(W + l.logits, l.Vp, tok + B, W + l.w, W + l.nvalid, W + l.lse, gl, T, B, V, st));
   const float* dlog = W + l.logits;
@@ -663,7 +664,9 @@ static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const s
     if (g->out_w) SSC_TRY(gemm_dw(c, dlog, l.Vp, hd_all, l.Hp, TB, V, H, g->out_w, g->ld_out_w));
     if (g->out_b) SSC_TRY(ssc_colsum2(dlog, l.Vp, TB, V, nullptr, g->out_b, 1, nullptr, 0, c.slabs, st));
   }
+  }  // phase 16 (first half of phase 1)
 
+  if (phases & (1u | 32u)) {
   // wsum_att / wz were prepared by ssc_train_fwd of the same minibatch (parameters are unchanged until the update)
   float* dx = W + l.dx;            // [datt (F) | dh1 (H) | dhd' (H)], ld XW
   int n_gh1 = 0, n_ghd = 0, n_ghd2 = 0, n_ghe = 0;  // slab counts carried from step t+1 (none at t = T-1)
@@ -806,7 +809,7 @@ static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const s
     SSC_LAUNCH(repeat_kernel, dim3(ssc_cdiv(TB, 256)), dim3(256), 0, st, bt->sentiment, B, T, W + l.sent_all);
     SSC_CHECK_LAUNCH();
   }
-  }  // phase 1
+  }  // phase 32 (second half of phase 1)
 
   const int zcol = F + 2 * H + S;
   // ---- weight gradients: one K = T*B GEMM per block ----------------------------------------------------
@@ -936,6 +939,6 @@ extern "C" int ssc_train_bwd(const ssc_model_cfg* cfg, const ssc_params* p, cons
 extern "C" int ssc_train_bwd_phases(const ssc_model_cfg* cfg, const ssc_params* p, const ssc_batch* bt, void* workspace,
                                     size_t workspace_bytes, const float* gl, const float* gk, const ssc_params* g,
                                     unsigned phases, void* stream) {
-  if (phases == 0 || phases > 15u) return SSC_EINVAL;
+  if (phases == 0 || phases > 63u) return SSC_EINVAL;
   return train_bwd_impl(cfg, p, bt, workspace, workspace_bytes, gl, gk, g, stream, phases);
 }

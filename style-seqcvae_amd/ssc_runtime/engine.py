@@ -252,7 +252,8 @@ class TrainEngine:
         dec = self.decoder_names
         first = [n for n in names if n.startswith("_embedding") or n.startswith(P_ATT) or n.startswith(P_BUTD)]
         mid = [n for n in names if n.startswith(P_ENC) or n.startswith(P_CELL + "fc_")]
-        return [(1, self.grads.range_of(head)), (2, self.grads.range_of(first)), (4, self.grads.range_of(mid)),
+        # (mask, range final after it): the head's gradients travel under the whole BPTT loop, which finishes no range itself
+        return [(16, self.grads.range_of(head)), (32, None), (2, self.grads.range_of(first)), (4, self.grads.range_of(mid)),
                 (8, self.grads.range_of(dec))]
 
     def backward_overlapped(self, gl, gk, skip: Sequence[str] = (), group=None):
@@ -270,10 +271,11 @@ class TrainEngine:
         gk = gk.to(torch.float32).contiguous()
         world = dist.get_world_size(group)
         works = []
-        for mask, (lo, hi) in self.phase_ranges():
+        for mask, rng in self.phase_ranges():
             self.lib.ssc_train_bwd_phases(C.byref(self._cfg), C.byref(p), C.byref(bt), _lib.ptr(ws), ws.numel() * 4,
                                           _lib.ptr(gl), _lib.ptr(gk), C.byref(g), mask, _lib.stream_ptr())
-            works.append(dist.all_reduce(self.grads.flat[lo:hi], op=dist.ReduceOp.SUM, group=group, async_op=True))
+            if rng is not None and rng[1] > rng[0]:
+                works.append(dist.all_reduce(self.grads.flat[rng[0]:rng[1]], op=dist.ReduceOp.SUM, group=group, async_op=True))
         if self.dp_profile:   # exposure = time the compute stream sits between its last backward kernel and the reduced gradients
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
