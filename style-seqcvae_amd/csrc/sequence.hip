@@ -613,7 +613,7 @@ __global__ void repeat_kernel(const float* __restrict__ src, int n, int reps, fl
 
 // phases (bit mask): 1 = vocabulary head + BPTT time loop, or its halves 16 = vocabulary head (output-head gradients are final
 // after it) and 32 = BPTT time loop; 2 = embedding, attention-LSTM and attention-projection gradients, 4 = encoder-LSTM and
-// latent-head gradients, 8 = decoder-LSTM gradients.  Phases must run in the order 16, 32, 2, 4, 8 on one stream; splitting
+// latent-head gradients, 8 = decoder-LSTM gradients.  16 and 32 come first, in this order; 2, 4 and 8 are independent of each other (any order); one stream.  Splitting
 // them lets the caller start the all-reduce of a finished gradient range while the next phase computes
 // (ssc_runtime/engine.py): the output head's 48 MB travel under the whole time loop.
 static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const ssc_batch* bt, void* workspace,

@@ -379,3 +379,41 @@ def test_edge_cases_match_oracle():
         for k, v in p.items():
             assert maxdiff(got[k], v.grad) < TOL, k
         assert torch.isfinite(loss).all() and all(torch.isfinite(x).all() for x in got.values())
+
+
+@pytest.mark.parametrize("masks", [(16, 32, 8, 4, 2), (16, 32, 2, 4, 8), (1, 4, 2, 8), (16, 32, 4 | 8, 2), (15,)])
+def test_phased_backward_equals_the_one_call_backward(masks):
+    """ssc_train_bwd_phases (include/ssc.h): the vocabulary head (16) and the BPTT loop (32) first, then the three weight-gradient
+    phases in ANY order - what lets the data-parallel engine reduce a finished gradient range under the phases that follow
+    (engine.phase_ranges) - give the gradients of ssc_train_bwd BIT FOR BIT, at widths where every product takes its production
+    kernel (wave-specialised gate products, grouped weight gradients); the embedding gradient (atomic scatter-add) to 1e-7."""
+    from gpuutil import engine_from
+    cfg = oracle.OracleConfig(vocab_size=1200, image_feature_size=512, embedding_size=256, hidden_size=320,
+                              attention_projection_size=192, z_space=64, max_caption_length=9, sentiment_vae=1,
+                              senti_prior_multip=0.5)
+    eng = engine_from(cfg, oracle.init_params(cfg, seed=11))
+    g = torch.Generator().manual_seed(5)
+    B, R, L = 64, 12, 9
+    feats = torch.randn(B, R, 512, generator=g).cuda()
+    caps = torch.zeros(B, L, dtype=torch.long)
+    for b in range(B):
+        n = 2 + b % 8
+        caps[b, :n] = torch.randint(2, 1200, (n,), generator=g)
+    senti = torch.randint(-1, 2, (B, 1), generator=g).float().cuda()
+    eps = torch.randn(L + 1, B, 64, generator=g).cuda()
+    gl = torch.full((B,), 1.0 / B, device="cuda")
+    gk = torch.full((B,), 1.0 / (B * 750.0), device="cuda")
+    eng.forward(feats, caps.cuda(), senti, eps)
+    eng.grads.flat.fill_(float("nan"))
+    eng.backward(gl, gk)
+    torch.cuda.synchronize()
+    want = {n: v.clone() for n, v in eng.grads.views.items()}
+    assert all(torch.isfinite(v).all() for v in want.values())
+    eng.forward(feats, caps.cuda(), senti, eps)     # (the backward consumes the forward's workspace: logits become dlogits in place)
+    eng.grads.flat.fill_(float("nan"))
+    eng.backward_phased(gl, gk, masks)
+    torch.cuda.synchronize()
+    # the embedding gradient is a scatter-add with float atomics (the one non-deterministic summation order of the path)
+    bad = {n: (v - want[n]).abs().max().item() for n, v in eng.grads.views.items()
+           if not torch.equal(v, want[n]) and not (n == "_embedding_layer.weight" and (v - want[n]).abs().max().item() < 1e-7)}
+    assert not bad, bad
