@@ -167,7 +167,7 @@ class TrainEngine:
         self._ws_key = None
         self._cfg = dims.cfg()
         self._keep = None
-        self._scratch = torch.zeros(1024 + 8, dtype=torch.float32, device=self.device)
+        self._scratch = torch.zeros(1024 + 16, dtype=torch.float32, device=self.device)
         names = list(shapes)
         self.decoder_names = [n for n in names if n.startswith(P_DEC)]
         self.frozen_names = ["_embedding_layer.weight"] if dims.tied else []
@@ -273,16 +273,27 @@ class TrainEngine:
         gk = gk.to(torch.float32).contiguous()
         world = dist.get_world_size(group)
         works = []
+        # only what the update will read travels: a frozen decoder LSTM / tied embedding keeps its (stale) gradient range at home
+        t_lo, t_hi = self.trainable_range(bool(set(self.decoder_names) & skipset))
         for mask, rng in self.phase_ranges():
             self.lib.ssc_train_bwd_phases(C.byref(self._cfg), C.byref(p), C.byref(bt), _lib.ptr(ws), ws.numel() * 4,
                                           _lib.ptr(gl), _lib.ptr(gk), C.byref(g), mask, _lib.stream_ptr())
-            if rng is not None and rng[1] > rng[0]:
-                works.append(dist.all_reduce(self.grads.flat[rng[0]:rng[1]], op=dist.ReduceOp.SUM, group=group, async_op=True))
+            if rng is not None:
+                lo, hi = max(rng[0], t_lo), min(rng[1], t_hi)
+                if hi > lo:
+                    works.append((dist.all_reduce(self.grads.flat[lo:hi], op=dist.ReduceOp.SUM, group=group, async_op=True), (lo, hi)))
         if self.dp_profile:   # exposure = time the compute stream sits between its last backward kernel and the reduced gradients
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        for w in works:
+        # the squared norm of every range is summed as soon as that range has arrived, under the reductions still in flight:
+        # behind the last one only its own range's norm and the update are left
+        n_parts = 0
+        for w, (lo, hi) in works:
             w.wait()
+            self.lib.ssc_sq_norm(_lib.ptr(self.grads.flat[lo:hi]), hi - lo, _lib.ptr(self._scratch),
+                                 _lib.ptr(self._scratch[1026 + n_parts:1027 + n_parts]), _lib.stream_ptr())
+            n_parts += 1
+        self._sq_parts = self._scratch[1026:1026 + n_parts].sum(dim=0, keepdim=True) if n_parts else None
         if self.dp_profile:
             e1.record()
             self.dp_exposure_events.append((e0, e1))
@@ -355,7 +366,7 @@ class TrainEngine:
             hi = self.params.range_of(self.decoder_names)[0]
         return lo, hi
 
-    def clip_sgd_step(self, lr, momentum=0.9, weight_decay=0.001, max_norm=12.5, decoder_frozen=False, gscale=1.0):
+    def clip_sgd_step(self, lr, momentum=0.9, weight_decay=0.001, max_norm=12.5, decoder_frozen=False, gscale=1.0, sq_norm=None):
         """clip_grad_norm_(max_norm) + SGD(momentum, weight_decay) on the flat buffers, skipping frozen ranges
         (torch>=2 semantics: parameters without a gradient are not touched).  Momentum buffers start at zero,
         which reproduces torch's lazily created buffer (first step: buf = d_p).  Returns the squared grad norm."""
@@ -363,8 +374,11 @@ class TrainEngine:
             self.momentum = torch.zeros_like(self.params.flat)
         lo, hi = self.trainable_range(decoder_frozen)
         st = _lib.stream_ptr()
-        sq = self._scratch[1024:1025]
-        self.lib.ssc_sq_norm(_lib.ptr(self.grads.flat[lo:hi]), hi - lo, _lib.ptr(self._scratch), _lib.ptr(sq), st)
+        if sq_norm is not None:   # already summed range by range (backward_overlapped)
+            sq = sq_norm
+        else:
+            sq = self._scratch[1024:1025]
+            self.lib.ssc_sq_norm(_lib.ptr(self.grads.flat[lo:hi]), hi - lo, _lib.ptr(self._scratch), _lib.ptr(sq), st)
         self.lib.ssc_sgd_step(_lib.ptr(self.params.flat[lo:hi]), _lib.ptr(self.grads.flat[lo:hi]),
                               _lib.ptr(self.momentum[lo:hi]), hi - lo, _lib.ptr(sq), float(gscale), float(max_norm),
                               float(lr), float(momentum), float(weight_decay), 0, st)
@@ -431,8 +445,10 @@ class TrainEngine:
         skip = self.decoder_names if decoder_frozen else ()
         if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or self.dp_force) and self.dp_overlap:
             world = self.backward_overlapped(gl, gk, skip=skip, group=group)
+            sq_parts = self._sq_parts
         else:
             self.backward(gl, gk, skip=skip)
             world = self.allreduce_grads(group)
-        self.clip_sgd_step(lr, momentum, weight_decay, max_norm, decoder_frozen, gscale=1.0 / world)
+            sq_parts = None
+        self.clip_sgd_step(lr, momentum, weight_decay, max_norm, decoder_frozen, gscale=1.0 / world, sq_norm=sq_parts)
         return loss, kld
