@@ -438,8 +438,12 @@ class TrainEngine:
         """fwd + bwd + (all-reduce) + clip + SGD: one iteration of train.py:154-176.  Returns (loss, kld) per row."""
         loss, kld = self.forward(feats, caps, sentiment, eps)
         B = loss.numel()
-        gl = torch.full((B,), 1.0 / B, dtype=torch.float32, device=self.device)
-        gk = torch.full((B,), 1.0 / (B * kld_weight), dtype=torch.float32, device=self.device)
+        key = (B, float(kld_weight))
+        if getattr(self, "_upstream_key", None) != key:   # d(mean loss + mean kld / KLD_WEIGHT) / d(loss_b, kld_b): constant per (B, weight)
+            self._upstream = (torch.full((B,), 1.0 / B, dtype=torch.float32, device=self.device),
+                              torch.full((B,), 1.0 / (B * kld_weight), dtype=torch.float32, device=self.device))
+            self._upstream_key = key
+        gl, gk = self._upstream
         import torch.distributed as dist
 
         skip = self.decoder_names if decoder_frozen else ()
