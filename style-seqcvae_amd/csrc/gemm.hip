@@ -1635,7 +1635,11 @@ int g_x3_nbuf = 1;  // single LDS stage: 31 KB per workgroup -> four resident wo
 int g_x3_wide = 0;
 int g_x3_pf = 2;  // tuning hook: 1 = 64x128 block tile for skinny (M <= 64, N >= 1024) 3xBF16 products
 inline bool x3_wide(int M, int N) { return g_x3_wide && M <= 64 && N >= 1024; }
-inline bool big_tile(int M, int N) { return M >= 512 && N >= 512; }
+// 128x128 tiles from 128 rows on: a minibatch of 128-511 rows (C5: B = 128 per GPU) is MFMA-bound in 3xBF16, not HBM-bound - the
+// 64-wide kernels streamed the weights once per 64 rows (B = 128: 16.2 -> 14.3 ms per train step, B = 256: 27.0 -> 22.9 ms with
+// the wave-specialised 128x128 form, same box).  "big_min_m" (SSC_BIG_MIN_M) restores 512.
+int g_big_min_m = getenv("SSC_BIG_MIN_M") ? atoi(getenv("SSC_BIG_MIN_M")) : 128;
+inline bool big_tile(int M, int N) { return M >= g_big_min_m && N >= 512; }
 // M <= 64 with a wide N: 64x128 block tile (wave tile 32x64).  Every workgroup re-reads the whole A operand
 // (the minibatch activations, from L2) for its K-range, and the CU-side load path (~24 GB/s per CU) is what these
 // products run into first (rocprof r01: loads per CU saturate with A+B at BN=64), so halving the A re-reads per
@@ -1775,7 +1779,8 @@ int launch(const ssc_gemm_desc* d, KArgs& k, int splits, hipStream_t st) {
     // wave-specialised one runs ~13 % fewer cycles per k-step and wins once the grid is several rounds deep (decode:
     // 1520 tiles, +10 % tokens/s).  g_x3b: 1 = choose by grid size, 2 = always wave-specialised, 3 = always 4-wave.
     const long wgs = (long)grid.x * grid.y * grid.z;
-    if ((g_x3b == 2 || (g_x3b == 1 && wgs >= 768)) && x3w_span_ok(d) && (!kg || kg_both)) {  // wave-specialised form: 12 waves, 120 KB of dynamic LDS
+    // (below 512 rows - one to four tile rows, split-K - the wave-specialised form wins at every grid size: 59 vs 71 us at 128 x 4800 x 5648)
+    if ((g_x3b == 2 || (g_x3b == 1 && (wgs >= 768 || (d->M < 512 && big_tile(d->M, d->N))))) && x3w_span_ok(d) && (!kg || kg_both)) {  // wave-specialised form: 12 waves, 120 KB of dynamic LDS
       group_fn fn = x3w_big_fn(d->a_kc, d->b_kc, kg);
       SSC_TRY(x3w_prepare());
       KGroup g1;
@@ -1945,6 +1950,10 @@ int ssc_gemm_slabs_group(const ssc_gemm_desc* const* d, int n, float* const* reg
   KGroup g;
   bool ok = n >= 2 && group_on, any_wide = false;
   long work = 0;
+  // two classes of members: minibatches of up to 64 rows on the 64x256 kernels, and of 128-511 rows (MFMA-bound in 3xBF16: C5's
+  // B = 128 per GPU) on the wave-specialised 128x128 kernels; a group is of one class
+  const bool mid = d[0] && d[0]->M >= 128;
+  const int tw = mid ? 128 : 256;
   for (int i = 0; i < n && ok; ++i) {
     SSC_TRY(build_args(d[i], g.a[i]));
     KArgs& k = g.a[i];
@@ -1953,9 +1962,15 @@ int ssc_gemm_slabs_group(const ssc_gemm_desc* const* d, int n, float* const* reg
     const bool compact = k.mcount || k.arows || k.crows || k.kcount || k.karows || k.kbrows;
     // a member needs the minibatch shape and 16 B/lane operands; a NARROW member (N < the 256-column kernels' minimum width,
     // e.g. the 128-column dz product) may ride along in a group that has at least one wide member
-    ok = !compact && x3w_group_member(d[i], vec) && d[i]->b_kc == d[0]->b_kc && regions[i];
-    any_wide = any_wide || x3w_skinny(d[i], vec);
-    work += (long)ssc_cdiv(d[i]->N, 256) * k.steps_total;
+    if (mid) {
+      ok = !compact && vec && d[i]->a_kc && gemm_mode() == 1 && g_x3b != 0 && g_x3b != 3 && d[i]->M >= g_big_min_m && d[i]->M < 512 &&
+           d[i]->M == d[0]->M && d[i]->N >= 64 && x3w_span_ok(d[i]) && d[i]->b_kc == d[0]->b_kc && regions[i];
+      any_wide = any_wide || big_tile(d[i]->M, d[i]->N);
+    } else {
+      ok = !compact && x3w_group_member(d[i], vec) && d[i]->b_kc == d[0]->b_kc && regions[i];
+      any_wide = any_wide || x3w_skinny(d[i], vec);
+    }
+    work += (long)ssc_cdiv(d[i]->N, tw) * ssc_cdiv(d[i]->M, mid ? 128 : 64) * k.steps_total;
   }
   ok = ok && any_wide;
   if (!ok) {
@@ -1967,7 +1982,7 @@ int ssc_gemm_slabs_group(const ssc_gemm_desc* const* d, int n, float* const* reg
   if (per < 4) per = 4;
   for (;; ++per) {  // the whole group in one round of 256 workgroups (a few stragglers in a second round double the time)
     long wgs = 0;
-    for (int i = 0; i < n; ++i) wgs += (long)ssc_cdiv(d[i]->N, 256) * ssc_cdiv(g.a[i].steps_total, per);
+    for (int i = 0; i < n; ++i) wgs += (long)ssc_cdiv(d[i]->N, tw) * ssc_cdiv(d[i]->M, mid ? 128 : 64) * ssc_cdiv(g.a[i].steps_total, per);
     if (wgs <= 256 || per >= 4096) break;
   }
   g.n = n;
@@ -1989,10 +2004,10 @@ int ssc_gemm_slabs_group(const ssc_gemm_desc* const* d, int n, float* const* reg
     k.bias = nullptr;
     k.accumulate = 0;
     k.crows = nullptr;
-    g.gx[i] = ssc_cdiv(d[i]->N, 256);
-    g.gy[i] = 1;
+    g.gx[i] = ssc_cdiv(d[i]->N, tw);
+    g.gy[i] = mid ? ssc_cdiv(d[i]->M, 128) : 1;
     g.gz[i] = splits;
-    g.first[i + 1] = g.first[i] + g.gx[i] * splits;
+    g.first[i + 1] = g.first[i] + g.gx[i] * g.gy[i] * splits;
     nslab[i] = splits;
     for (int s = 0; s < d[i]->nseg; ++s) Ksum += d[i]->seg[s].K;
     if (d[i]->N > Nmax) Nmax = d[i]->N;
@@ -2007,6 +2022,12 @@ int ssc_gemm_slabs_group(const ssc_gemm_desc* const* d, int n, float* const* reg
     rec->M = d[0]->M; rec->N = Nmax; rec->splits = nslab[0]; rec->K = Ksum;   // (N, K: nominal; bytes / flops are exact)
     for (int i = 0; i < n; ++i) prof_desc(rec, d[i]);
     (void)hipEventRecord(rec->e0, st);
+  }
+  if (mid) {
+    SSC_LAUNCH(x3w_big_fn(true, d[0]->b_kc != 0, false), dim3(g.first[n]), dim3(x3w_big_threads()), (x3w_lds_bytes<128, 128>()), st, g);
+    if (rec) (void)hipEventRecord(rec->e1, st);
+    SSC_CHECK_LAUNCH();
+    return SSC_OK;
   }
   SSC_LAUNCH(x3w_skinny_fn(d[0]->b_kc), dim3(g.first[n]), dim3(x3w_skinny_threads()), (x3w_lds_bytes<64, 256>()), st, g);
   if (rec) (void)hipEventRecord(rec->e1, st);
@@ -2170,6 +2191,7 @@ const DebugKey g_debug_keys[] = {
     {"x3w_pf", &g_x3w_pf},           // 64x256 kernels: k-steps in flight in the producers' registers (2 | 3)   (SSC_X3W_PF)
     {"store_wt", &g_store_wt},       // wave-specialised kernels: write-through (sc1) output stores (0 | 1)   (SSC_STORE_WT)
     {"tile_gm", &g_tile_gm},         // tile rows per group of the tile order (8; 0 = row-major)   (SSC_TILE_GM)
+    {"big_min_m", &g_big_min_m},     // rows from which a product with N >= 512 takes 128x128 tiles (128; 512 = round-2 behaviour before)   (SSC_BIG_MIN_M)
 };
 }  // namespace
 

@@ -77,6 +77,9 @@ def _check_train_golden(name):
 @pytest.mark.parametrize("sv,B,R,dims", [
     (1, 8, 36, dict(V=1000, E=200, H=256, A=128, F=512, Z=64, L=12)),
     (0, 5, 10, dict(V=777, E=100, H=130, A=70, F=260, Z=30, L=9)),
+    # minibatches of 128-511 rows take 128x128 tiles (grouped launches of the wave-specialised form) for every gate product
+    (1, 128, 12, dict(V=900, E=192, H=320, A=160, F=512, Z=64, L=7)),
+    (1, 200, 6, dict(V=600, E=128, H=256, A=128, F=256, Z=32, L=5)),
 ])
 def test_train_matches_oracle_medium(sv, B, R, dims):
     cfg = oracle.OracleConfig(vocab_size=dims["V"], image_feature_size=dims["F"], embedding_size=dims["E"],
