@@ -40,7 +40,7 @@ int ssc_prof_loop_ms(float* fwd_loop_ms, float* bwd_loop_ms);
  *   "x3w_pf"      k-steps in flight in the producers' registers of the 64x256 kernels: 2 (default) | 3   (SSC_X3W_PF)
  *   "store_wt"    write-through (sc1) output stores of the wave-specialised kernels (1)            (SSC_STORE_WT)
  *   "tile_gm"     tile rows per group of the XCD-aware tile order (8; 0 = row-major)               (SSC_TILE_GM)
- *   "big_min_m"   rows from which a product with N >= 512 takes 128x128 tiles (128); below 512 rows always in the
+ *   "big_min_m"   rows from which a product with N >= 512 takes 128x128 tiles (65); below 512 rows always in the
  *                 wave-specialised form                                                            (SSC_BIG_MIN_M)
  * Returns SSC_EINVAL for an unknown key. */
 int ssc_debug_set(const char* key, int value);

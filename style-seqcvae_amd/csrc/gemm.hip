@@ -1635,10 +1635,11 @@ int g_x3_nbuf = 1;  // single LDS stage: 31 KB per workgroup -> four resident wo
 int g_x3_wide = 0;
 int g_x3_pf = 2;  // tuning hook: 1 = 64x128 block tile for skinny (M <= 64, N >= 1024) 3xBF16 products
 inline bool x3_wide(int M, int N) { return g_x3_wide && M <= 64 && N >= 1024; }
-// 128x128 tiles from 128 rows on: a minibatch of 128-511 rows (C5: B = 128 per GPU) is MFMA-bound in 3xBF16, not HBM-bound - the
+// 128x128 tiles from 65 rows on: a minibatch of 65-511 rows (C5: B = 128 per GPU) is MFMA-bound in 3xBF16, not HBM-bound - the
 // 64-wide kernels streamed the weights once per 64 rows (B = 128: 16.2 -> 14.3 ms per train step, B = 256: 27.0 -> 22.9 ms with
-// the wave-specialised 128x128 form, same box).  "big_min_m" (SSC_BIG_MIN_M) restores 512.
-int g_big_min_m = getenv("SSC_BIG_MIN_M") ? atoi(getenv("SSC_BIG_MIN_M")) : 128;
+// the wave-specialised 128x128 form, same box; 65-127 rows: one padded tile row still beats two 64-row passes, B = 96: 14.6 ->
+// 12.5 ms).  "big_min_m" (SSC_BIG_MIN_M) = 512 restores the earlier behaviour.
+int g_big_min_m = getenv("SSC_BIG_MIN_M") ? atoi(getenv("SSC_BIG_MIN_M")) : 65;
 inline bool big_tile(int M, int N) { return M >= g_big_min_m && N >= 512; }
 // M <= 64 with a wide N: 64x128 block tile (wave tile 32x64).  Every workgroup re-reads the whole A operand
 // (the minibatch activations, from L2) for its K-range, and the CU-side load path (~24 GB/s per CU) is what these
@@ -1950,9 +1951,9 @@ int ssc_gemm_slabs_group(const ssc_gemm_desc* const* d, int n, float* const* reg
   KGroup g;
   bool ok = n >= 2 && group_on, any_wide = false;
   long work = 0;
-  // two classes of members: minibatches of up to 64 rows on the 64x256 kernels, and of 128-511 rows (MFMA-bound in 3xBF16: C5's
+  // two classes of members: minibatches of up to 64 rows on the 64x256 kernels, and of 65-511 rows (MFMA-bound in 3xBF16: C5's
   // B = 128 per GPU) on the wave-specialised 128x128 kernels; a group is of one class
-  const bool mid = d[0] && d[0]->M >= 128;
+  const bool mid = d[0] && d[0]->M > 64 && d[0]->M >= g_big_min_m;
   const int tw = mid ? 128 : 256;
   for (int i = 0; i < n && ok; ++i) {
     SSC_TRY(build_args(d[i], g.a[i]));
@@ -2191,7 +2192,7 @@ const DebugKey g_debug_keys[] = {
     {"x3w_pf", &g_x3w_pf},           // 64x256 kernels: k-steps in flight in the producers' registers (2 | 3)   (SSC_X3W_PF)
     {"store_wt", &g_store_wt},       // wave-specialised kernels: write-through (sc1) output stores (0 | 1)   (SSC_STORE_WT)
     {"tile_gm", &g_tile_gm},         // tile rows per group of the tile order (8; 0 = row-major)   (SSC_TILE_GM)
-    {"big_min_m", &g_big_min_m},     // rows from which a product with N >= 512 takes 128x128 tiles (128; 512 = round-2 behaviour before)   (SSC_BIG_MIN_M)
+    {"big_min_m", &g_big_min_m},     // rows from which a product with N >= 512 takes 128x128 tiles (65; 512 = the behaviour until late in round 2)   (SSC_BIG_MIN_M)
 };
 }  // namespace
 
