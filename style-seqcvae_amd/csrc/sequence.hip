@@ -312,7 +312,9 @@ __global__ void weight_views_kernel(const ViewArgs a) {
     a.wsum_att[(size_t)n * a.Hp + k] = a.att_ih[(size_t)n * a.ld_att_ih + k] + a.att_hh[(size_t)n * a.ld_att_hh + k];
     a.wsum_dec[(size_t)n * a.Hp + k] = a.dec_ih[(size_t)n * a.ld_dec_ih + k] + a.dec_hh[(size_t)n * a.ld_dec_hh + k];
   }
-  for (int k = tid; k < a.Z; k += blockDim.x) a.wz[(size_t)n * a.Zp + k] = a.dec_z[(size_t)n * a.ld_dec_ih + k];
+  // (pad columns Z..Zp-1 are zero: the backward multiplies with all Zp columns so that the product keeps 16-byte rows when Z is
+  // no multiple of 4 - the reference's shipped Z_SPACE is 150)
+  for (int k = tid; k < a.Zp; k += blockDim.x) a.wz[(size_t)n * a.Zp + k] = k < a.Z ? a.dec_z[(size_t)n * a.ld_dec_ih + k] : 0.f;
   if (a.S && tid == 0) {
     a.wcol_e[n] = a.enc_s[(size_t)n * a.ld_enc_ih];
     a.wcol_d[n] = a.dec_s[(size_t)n * a.ld_dec_ih];
@@ -706,7 +708,7 @@ static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const s
     //    the decoder half of [datt | dh1 | dhd'] (slabs; the encoder half follows in 6), and dGd W_hh^dec for step t-1
     {
       ssc_gemm_desc d3[3];
-      fill_desc(d3[0], true, false, {{dgd, H4, W + l.wz, l.Zp, H4}}, B, Z);
+      fill_desc(d3[0], true, false, {{dgd, H4, W + l.wz, l.Zp, H4}}, B, l.Zp);   // Zp columns (pad columns of wz are zero): 16-byte rows for any Z
       fill_desc(d3[1], true, false, {{dgd, H4, p->dec_w_ih, p->ld_dec_w_ih, H4}}, B, F + 2 * H);
       fill_desc(d3[2], true, false, {{dgd, H4, p->dec_w_hh, p->ld_dec_w_hh, H4}}, B, H);
       const ssc_gemm_desc* dp[3] = {&d3[0], &d3[1], &d3[2]};
@@ -719,7 +721,7 @@ static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const s
     {
       ssc_latent_bwd_desc d{};
       d.B = B; d.Z = Z;
-      d.dz = W + l.sl_dz; d.lddz = Z; d.nslab = ns; d.slab_stride = (size_t)B * Z;
+      d.dz = W + l.sl_dz; d.lddz = l.Zp; d.nslab = ns; d.slab_stride = (size_t)B * l.Zp;
       d.eps = bt->eps + (size_t)t * B * Z; d.ldeps = Z;
       d.mu = W + l.mu + (size_t)t * B * l.Zp; d.lv = W + l.lv + (size_t)t * B * l.Zp; d.ldz = l.Zp;
       d.kld_mode = cfg->kld_mode; d.sent = cfg->pm_scale != 0.f ? bt->sentiment : nullptr;

@@ -80,6 +80,8 @@ def _check_train_golden(name):
     # minibatches of 128-511 rows take 128x128 tiles (grouped launches of the wave-specialised form) for every gate product
     (1, 128, 12, dict(V=900, E=192, H=320, A=160, F=512, Z=64, L=7)),
     (1, 200, 6, dict(V=600, E=128, H=256, A=128, F=256, Z=32, L=5)),
+    # the shipped config.yaml's shape class: BATCH_SIZE 150, Z_SPACE 150 (no multiple of 4: the z-block products run on padded rows)
+    (1, 150, 8, dict(V=500, E=96, H=192, A=96, F=256, Z=30, L=5)),
 ])
 def test_train_matches_oracle_medium(sv, B, R, dims):
     cfg = oracle.OracleConfig(vocab_size=dims["V"], image_feature_size=dims["F"], embedding_size=dims["E"],

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Train-step time of the same engine at other configurations than the headline C2 (which bench.py measures), one GPU:
+    python tools/step_probe.py c5   [steps]    BASELINE.json's stress config: B=128 per GPU, R=100, L=40 (T=41), V=30000; E/H/A/Z as C2
+    python tools/step_probe.py yaml [steps]    the reference's shipped configs/config.yaml: E=600 (frozen table, tied output layer),
+                                               H=900, A=768, Z=150, BATCH_SIZE=150, R=36, L=20, V=10000 (seeded table instead of GloVe)
+"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "style-seqcvae_amd"))
+sys.path.insert(0, ROOT)
+import torch
+
+import bench
+from ssc_runtime.vocab import Vocabulary
+from var_updown.models import UpDownCaptioner
+
+CONFIGS = {"c5": dict(B=128, R=100, F=2048, L=40, Z=128, V=30000, E=1000, H=1200, A=768),
+           "yaml": dict(B=150, R=36, F=2048, L=20, Z=150, V=10000, E=600, H=900, A=768),
+           "c2": dict(bench.C2)}
+
+
+class _SeededTable(UpDownCaptioner):
+    def _initialize_glove(self):   # E in {300, 600}: frozen table + tied head (updown_captioner.py:75-119); no download here
+        g = torch.Generator().manual_seed(3)
+        return torch.randn(self._vocabulary.get_vocab_size(), self.embedding_size, generator=g) * 0.3
+
+
+def main():
+    name = sys.argv[1] if len(sys.argv) > 1 else "c5"
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+    c = CONFIGS[name]
+    dev = torch.device("cuda")
+    torch.manual_seed(2)
+    tied = c["E"] in (300, 600)
+    model = _SeededTable(Vocabulary.synthetic(c["V"]), image_feature_size=c["F"], embedding_size=c["E"], hidden_size=c["H"],
+                         attention_projection_size=c["A"], max_caption_length=c["L"], beam_size=5, use_cbs=tied, z_space=c["Z"],
+                         prior_std=1.0, simple_vae=False, latent_embedding="glove", sentiment_vae=1, senti_prior_multip=0.5,
+                         device=dev).to(dev)
+    eng = model._engine()
+    batches = [bench.synth_batch(1234 + i, c["B"], c["R"], c["F"], c["L"], c["V"], c["Z"], dev) for i in range(2)]
+
+    def step(i):
+        feats, caps, senti, eps = batches[i % 2]
+        eng.train_step(feats, caps, senti, eps, lr=0.015, kld_weight=750.0, momentum=0.9, weight_decay=0.001, max_norm=12.5)
+    for i in range(5):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    print(f"{name} train step {c}: {ms:.2f} ms -> {c['B'] / ms * 1e3:.0f} captions/s", flush=True)
+
+
+if __name__ == "__main__":
+    main()
