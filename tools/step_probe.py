@@ -3,6 +3,7 @@
     python tools/step_probe.py c5   [steps]    BASELINE.json's stress config: B=128 per GPU, R=100, L=40 (T=41), V=30000; E/H/A/Z as C2
     python tools/step_probe.py yaml [steps]    the reference's shipped configs/config.yaml: E=600 (frozen table, tied output layer),
                                                H=900, A=768, Z=150, BATCH_SIZE=150, R=36, L=20, V=10000 (seeded table instead of GloVe)
+    python tools/step_probe.py <name>-decode   diverse decode (50 images x 20 samples per call) of that model at beam 1 and 5
 """
 import os
 import sys
@@ -28,9 +29,33 @@ class _SeededTable(UpDownCaptioner):
         return torch.randn(self._vocabulary.get_vocab_size(), self.embedding_size, generator=g) * 0.3
 
 
+def decode_probe(model, c, dev, beam):
+    """diverse decode of 50-image chunks x 20 latent samples at beam width `beam` (the shipped yaml has BEAM_SIZE 1; C4 uses 5)"""
+    from ssc_runtime.inference import count_tokens, diverse_decode
+    model.eval()
+    g = torch.Generator().manual_seed(4321)
+    feats = [torch.randn(50, c["R"], c["F"], generator=g).to(dev) for _ in range(2)]
+    senti = torch.ones(50, device=dev)
+    t_w = time.perf_counter()
+    while time.perf_counter() - t_w < 1.5:
+        diverse_decode(model._dec, feats[0], senti, 20, beam, c["L"], 1, early_stop=False)
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tokens = 0
+    for i in range(6):
+        pred, _ = diverse_decode(model._dec, feats[i % 2], senti, 20, beam, c["L"], 1, early_stop=False)
+        tokens += count_tokens(pred, 1)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    print(f"decode beam {beam}: {6 * 50 / el:.0f} images/s, {6 * 50 * 20 * c['L'] / el / 1e3:.0f} k row-tokens/s (20 samples x {c['L']} steps per image), "
+          f"{el / 6 * 1e3:.1f} ms per 50-image call", flush=True)
+
+
 def main():
     name = sys.argv[1] if len(sys.argv) > 1 else "c5"
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+    decode = name.endswith("-decode")
+    name = name.replace("-decode", "")
     c = CONFIGS[name]
     dev = torch.device("cuda")
     torch.manual_seed(2)
@@ -40,6 +65,10 @@ def main():
                          prior_std=1.0, simple_vae=False, latent_embedding="glove", sentiment_vae=1, senti_prior_multip=0.5,
                          device=dev).to(dev)
     eng = model._engine()
+    if decode:
+        for beam in (1, 5):
+            decode_probe(model, c, dev, beam)
+        return
     batches = [bench.synth_batch(1234 + i, c["B"], c["R"], c["F"], c["L"], c["V"], c["Z"], dev) for i in range(2)]
 
     def step(i):
