@@ -3,6 +3,7 @@
     python tools/step_probe.py c5   [steps]    BASELINE.json's stress config: B=128 per GPU, R=100, L=40 (T=41), V=30000; E/H/A/Z as C2
     python tools/step_probe.py yaml [steps]    the reference's shipped configs/config.yaml: E=600 (frozen table, tied output layer),
                                                H=900, A=768, Z=150, BATCH_SIZE=150, R=36, L=20, V=10000 (seeded table instead of GloVe)
+    python tools/step_probe.py <name>-dropin   the reference's training loop on the drop-in module API (autograd + torch optimiser)
     python tools/step_probe.py <name>-decode   diverse decode (50 images x 20 samples per call) of that model at beam 1 and 5
 """
 import os
@@ -55,7 +56,8 @@ def main():
     name = sys.argv[1] if len(sys.argv) > 1 else "c5"
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
     decode = name.endswith("-decode")
-    name = name.replace("-decode", "")
+    dropin = name.endswith("-dropin")
+    name = name.replace("-decode", "").replace("-dropin", "")
     c = CONFIGS[name]
     dev = torch.device("cuda")
     torch.manual_seed(2)
@@ -68,6 +70,29 @@ def main():
     if decode:
         for beam in (1, 5):
             decode_probe(model, c, dev, beam)
+        return
+    if dropin:   # the reference's own loop (var_updown/scripts/train.py:154-176) on the module API: autograd, clip_grad_norm_, torch SGD
+        opt = torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=0.015, momentum=0.9, weight_decay=0.001)
+        feats, caps, senti, _ = bench.synth_batch(1234, c["B"], c["R"], c["F"], c["L"], c["V"], c["Z"], dev)
+        senti = senti.reshape(-1, 1)
+
+        def it():
+            out = model(feats, None, None, caps, senti)
+            loss = out["loss"].mean() + out["kld"].mean() / 750.0
+            opt.zero_grad()
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 12.5)
+            opt.step()
+        model.train()
+        for _ in range(5):
+            it()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            it()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        print(f"{name} drop-in loop (model(...), loss.backward(), clip_grad_norm_, torch.optim.SGD): {ms:.2f} ms -> {c['B'] / ms * 1e3:.0f} captions/s", flush=True)
         return
     batches = [bench.synth_batch(1234 + i, c["B"], c["R"], c["F"], c["L"], c["V"], c["Z"], dev) for i in range(2)]
 
