@@ -875,8 +875,14 @@ static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const s
       SSC_TRY(queue_dw(c, q, dge, H4, hd_prev, l.Hp, TB, H4, H, gw + F + H, ld));
     }
     if (g->enc_w_hh) SSC_TRY(queue_dw(c, q, dge, H4, he_prev, l.Hp, TB, H4, H, g->enc_w_hh, g->ld_enc_w_hh));
-    if (g->fc_mean_w) SSC_TRY(queue_dw(c, q, W + l.dmulv, 2 * Z, he_new, l.Hp, TB, Z, H, g->fc_mean_w, g->ld_fc_mean_w));
-    if (g->fc_lv_w) SSC_TRY(queue_dw(c, q, W + l.dmulv + Z, 2 * Z, he_new, l.Hp, TB, Z, H, g->fc_lv_w, g->ld_fc_lv_w));
+    if (g->fc_mean_w && g->fc_lv_w && g->fc_lv_w == g->fc_mean_w + (size_t)Z * g->ld_fc_mean_w && g->ld_fc_lv_w == g->ld_fc_mean_w) {
+      // [dW_mu ; dW_lv] = (dmu | dlv)^T h_e as ONE (2Z x H) product: the two gradients are adjacent in the flat store, and 2Z keeps
+      // 16-byte rows where Z alone does not (the shipped Z_SPACE = 150 sent the two Z-row products to the scalar kernel)
+      SSC_TRY(queue_dw(c, q, W + l.dmulv, 2 * Z, he_new, l.Hp, TB, 2 * Z, H, g->fc_mean_w, g->ld_fc_mean_w));
+    } else {
+      if (g->fc_mean_w) SSC_TRY(queue_dw(c, q, W + l.dmulv, 2 * Z, he_new, l.Hp, TB, Z, H, g->fc_mean_w, g->ld_fc_mean_w));
+      if (g->fc_lv_w) SSC_TRY(queue_dw(c, q, W + l.dmulv + Z, 2 * Z, he_new, l.Hp, TB, Z, H, g->fc_lv_w, g->ld_fc_lv_w));
+    }
     SSC_TRY(flush_dw(c, q));
   }
   // encoder LSTM
@@ -903,13 +909,24 @@ static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const s
       SSC_TRY(queue_dw(c, q, dgd, H4, att, l.Fp, TB, H4, F, gw, ld));
       SSC_TRY(queue_dw(c, q, dgd, H4, h1_new, l.Hp, TB, H4, H, gw + F, ld));
       SSC_TRY(queue_dw(c, q, dgd, H4, hd_prev, l.Hp, TB, H4, H, gw + F + H, ld));
-      SSC_TRY(queue_dw(c, q, dgd, H4, W + l.z, l.Zp, TB, H4, Z, gw + zcol, ld));
+      if (l.Zp != Z) {
+        // Z no multiple of 4: the z-block product runs on the padded Zp columns of z (zero pads) into the forward's aligned
+        // z-block copy - free since the BPTT loop ended - and its Z real columns are copied into place below
+        SSC_TRY(queue_dw(c, q, dgd, H4, W + l.z, l.Zp, TB, H4, l.Zp, W + l.wz, l.Zp));
+      } else {
+        SSC_TRY(queue_dw(c, q, dgd, H4, W + l.z, l.Zp, TB, H4, Z, gw + zcol, ld));
+      }
     } else if (g->dec_w_hh) {
       SSC_TRY(queue_dw(c, q, dgd, H4, hd_prev, l.Hp, TB, H4, H, g->dec_w_hh, g->ld_dec_w_hh));
     }
     SSC_TRY(flush_dw(c, q));
   }
   // decoder LSTM (skipped while frozen: train.py:156-161)
+  if (g->dec_w_ih && l.Zp != Z) {
+    if (hipMemcpy2DAsync(g->dec_w_ih + zcol, (size_t)g->ld_dec_w_ih * sizeof(float), W + l.wz, (size_t)l.Zp * sizeof(float),
+                         (size_t)Z * sizeof(float), H4, hipMemcpyDeviceToDevice, st) != hipSuccess)
+      return SSC_EHIP;
+  }
   if (g->dec_w_ih) {
     float* gw = g->dec_w_ih; int ld = g->ld_dec_w_ih;
     if (S) SSC_TRY(ssc_colsum2(dgd, H4, TB, H4, W + l.sent_all, gw + F + 2 * H, ld, nullptr, 0, c.slabs, st));
