@@ -607,6 +607,60 @@ extern "C" int ssc_train_fwd(const ssc_model_cfg* cfg, const ssc_params* p, cons
 }
 
 namespace {
+// ---- vocabulary sizes that are no multiple of 4 ------------------------------------------------------------------------------
+// The two backward products of the vocabulary head that run over V as a k- or m-extent (d(hidden) = dlogits . W over k = V;
+// dW = dlogits^T . hidden with V rows) need 16-byte rows for the MFMA kernels; with V % 4 != 0 they fell to the scalar kernel over
+// all rows (V = 10001: +7.5 % step time - and real vocabularies are rarely a multiple of 4).  The products now run on the first
+// V4 = V & ~3 entries and these two kernels add the 1-3 entries left (dlogits is defined - zero - on every row without a target).
+__global__ __launch_bounds__(256) void head_tail_rows_kernel(const float* __restrict__ dlog, int ldl, const float* __restrict__ Wt,
+                                                             int ldw, int v0, int nt, int N, float* __restrict__ out, int ldo) {
+  // out[r, n] += sum_{j < nt} dlog[r, v0 + j] * Wt[v0 + j, n]
+  const int r = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  float acc = 0.f;
+  for (int j = 0; j < nt; ++j) acc += dlog[(size_t)r * ldl + v0 + j] * Wt[(size_t)(v0 + j) * ldw + n];
+  out[(size_t)r * ldo + n] += acc;
+}
+__global__ __launch_bounds__(1024) void head_tail_dw_kernel(const float* __restrict__ dlog, int ldl, const float* __restrict__ X, int ldx,
+                                                            int rows, int v0, int N, float* __restrict__ dW, int ldw) {
+  // dW[v0 + j, n] = sum_r dlog[r, v0 + j] * X[r, n]   (j = blockIdx.y); 64 columns x 16 row lanes per workgroup, four rows in
+  // flight per thread, lanes combined in a fixed order
+  __shared__ float part[16][64];
+  const int j = blockIdx.y, nl = threadIdx.x & 63, rl = threadIdx.x >> 6, n = min(blockIdx.x * 64 + nl, N - 1);
+  float acc = 0.f;
+  for (int r0 = rl; r0 < rows; r0 += 64) {
+    float d4[4], x4[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = min(r0 + 16 * u, rows - 1);
+      d4[u] = dlog[(size_t)r * ldl + v0 + j];
+      x4[u] = X[(size_t)r * ldx + n];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc += (r0 + 16 * u < rows) ? d4[u] * x4[u] : 0.f;
+  }
+  part[rl][nl] = acc;
+  __syncthreads();
+  if (rl == 0 && blockIdx.x * 64 + nl < N) {
+    float t = part[0][nl];
+    for (int i = 1; i < 16; ++i) t += part[i][nl];
+    dW[(size_t)(v0 + j) * ldw + n] = t;
+  }
+}
+int head_tail_rows(const float* dlog, int ldl, const float* Wt, int ldw, int v0, int V, int rows, int N, float* out, int ldo, hipStream_t st) {
+  const int nt = V - v0;
+  if (nt <= 0) return SSC_OK;
+  SSC_LAUNCH(head_tail_rows_kernel, dim3(ssc_cdiv(N, 256), rows), dim3(256), 0, st, dlog, ldl, Wt, ldw, v0, nt, N, out, ldo);
+  SSC_CHECK_LAUNCH();
+  return SSC_OK;
+}
+int head_tail_dw(const float* dlog, int ldl, const float* X, int ldx, int v0, int V, int rows, int N, float* dW, int ldw, hipStream_t st) {
+  const int nt = V - v0;
+  if (nt <= 0) return SSC_OK;
+  SSC_LAUNCH(head_tail_dw_kernel, dim3(ssc_cdiv(N, 64), nt), dim3(1024), 0, st, dlog, ldl, X, ldx, rows, v0, N, dW, ldw);
+  SSC_CHECK_LAUNCH();
+  return SSC_OK;
+}
 __global__ void repeat_kernel(const float* __restrict__ src, int n, int reps, float* __restrict__ dst) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n * reps) dst[i] = src[i % n];
@@ -654,16 +708,22 @@ static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const s
     f.add(W + l.dga_sum, (size_t)B * H4);
     SSC_TRY(fill_many(f, 0.f, st));
   }
+  const int V4 = V >= 8 ? (V & ~3) : V;   // (see head_tail_rows_kernel)
   if (cfg->tied) {
     float* dP = W + l.dproj;
-    SSC_TRY(gemm_rows(c, false, {{dlog, l.Vp, p->emb, p->ld_emb, V}}, TB, E, dP, l.Ep));
+    SSC_TRY(gemm_rows(c, false, {{dlog, l.Vp, p->emb, p->ld_emb, V4}}, TB, E, dP, l.Ep));
+    SSC_TRY(head_tail_rows(dlog, l.Vp, p->emb, p->ld_emb, V4, V, TB, E, dP, l.Ep, st));
     SSC_TRY(ssc_tanh_bwd(dP, l.Ep, W + l.proj, l.Ep, TB, E, st));
     SSC_TRY(gemm_rows(c, false, {{dP, l.Ep, p->proj_w, p->ld_proj_w, E}}, TB, H, W + l.dhdv, l.Hp));
     if (g->proj_w) SSC_TRY(gemm_dw(c, dP, l.Ep, hd_all, l.Hp, TB, E, H, g->proj_w, g->ld_proj_w));
     if (g->proj_b) SSC_TRY(ssc_colsum2(dP, l.Ep, TB, E, nullptr, g->proj_b, 1, nullptr, 0, c.slabs, st));
   } else {
-    SSC_TRY(gemm_rows(c, false, {{dlog, l.Vp, p->out_w, p->ld_out_w, V}}, TB, H, W + l.dhdv, l.Hp));
-    if (g->out_w) SSC_TRY(gemm_dw(c, dlog, l.Vp, hd_all, l.Hp, TB, V, H, g->out_w, g->ld_out_w));
+    SSC_TRY(gemm_rows(c, false, {{dlog, l.Vp, p->out_w, p->ld_out_w, V4}}, TB, H, W + l.dhdv, l.Hp));
+    SSC_TRY(head_tail_rows(dlog, l.Vp, p->out_w, p->ld_out_w, V4, V, TB, H, W + l.dhdv, l.Hp, st));
+    if (g->out_w) {
+      SSC_TRY(gemm_dw(c, dlog, l.Vp, hd_all, l.Hp, TB, V4, H, g->out_w, g->ld_out_w));
+      SSC_TRY(head_tail_dw(dlog, l.Vp, hd_all, l.Hp, V4, V, TB, H, g->out_w, g->ld_out_w, st));
+    }
     if (g->out_b) SSC_TRY(ssc_colsum2(dlog, l.Vp, TB, V, nullptr, g->out_b, 1, nullptr, 0, c.slabs, st));
   }
   }  // phase 16 (first half of phase 1)

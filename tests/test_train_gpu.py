@@ -82,6 +82,10 @@ def _check_train_golden(name):
     (1, 200, 6, dict(V=600, E=128, H=256, A=128, F=256, Z=32, L=5)),
     # the shipped config.yaml's shape class: BATCH_SIZE 150, Z_SPACE 150 (no multiple of 4: the z-block products run on padded rows)
     (1, 150, 8, dict(V=500, E=96, H=192, A=96, F=256, Z=30, L=5)),
+    # vocabulary sizes that are no multiple of 4 (the backward head products run on V & ~3 entries + a tail kernel): untied above
+    # (V = 777), tied head (E = 300: frozen table, Linear + Tanh projection) here, and a large untied one
+    (1, 6, 7, dict(V=451, E=300, H=64, A=48, F=128, Z=16, L=6)),
+    (1, 64, 6, dict(V=2003, E=128, H=256, A=128, F=256, Z=32, L=5)),
 ])
 def test_train_matches_oracle_medium(sv, B, R, dims):
     cfg = oracle.OracleConfig(vocab_size=dims["V"], image_feature_size=dims["F"], embedding_size=dims["E"],

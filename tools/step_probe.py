@@ -21,7 +21,8 @@ from var_updown.models import UpDownCaptioner
 
 CONFIGS = {"c5": dict(B=128, R=100, F=2048, L=40, Z=128, V=30000, E=1000, H=1200, A=768),
            "yaml": dict(B=150, R=36, F=2048, L=20, Z=150, V=10000, E=600, H=900, A=768),
-           "c2": dict(bench.C2)}
+           "c2": dict(bench.C2),
+           "c2v": dict(bench.C2, V=10001)}   # a vocabulary size that is no multiple of 4 (real vocabularies rarely are)
 
 
 class _SeededTable(UpDownCaptioner):
