@@ -3,6 +3,7 @@
     python tools/step_probe.py c5   [steps]    BASELINE.json's stress config: B=128 per GPU, R=100, L=40 (T=41), V=30000; E/H/A/Z as C2
     python tools/step_probe.py yaml [steps]    the reference's shipped configs/config.yaml: E=600 (frozen table, tied output layer),
                                                H=900, A=768, Z=150, BATCH_SIZE=150, R=36, L=20, V=10000 (seeded table instead of GloVe)
+    python tools/step_probe.py yaml 10 B=128   any dimension can be overridden
     python tools/step_probe.py <name>-dropin   the reference's training loop on the drop-in module API (autograd + torch optimiser)
     python tools/step_probe.py <name>-decode   diverse decode (50 images x 20 samples per call) of that model at beam 1 and 5
 """
@@ -59,7 +60,10 @@ def main():
     decode = name.endswith("-decode")
     dropin = name.endswith("-dropin")
     name = name.replace("-decode", "").replace("-dropin", "")
-    c = CONFIGS[name]
+    c = dict(CONFIGS[name])
+    for kv in sys.argv[3:]:            # overrides: B=128 V=9487 ...
+        k, v = kv.split("=")
+        c[k] = int(v)
     dev = torch.device("cuda")
     torch.manual_seed(2)
     tied = c["E"] in (300, 600)
