@@ -32,26 +32,27 @@ class _SeededTable(UpDownCaptioner):
         return torch.randn(self._vocabulary.get_vocab_size(), self.embedding_size, generator=g) * 0.3
 
 
-def decode_probe(model, c, dev, beam):
-    """diverse decode of 50-image chunks x 20 latent samples at beam width `beam` (the shipped yaml has BEAM_SIZE 1; C4 uses 5)"""
+def decode_probe(model, c, dev, beam, images=50, n_z=20):
+    """diverse decode of `images`-image chunks x n_z latent samples at beam width `beam` (the shipped yaml has BEAM_SIZE 1; C4 uses 5)"""
     from ssc_runtime.inference import count_tokens, diverse_decode
     model.eval()
     g = torch.Generator().manual_seed(4321)
-    feats = [torch.randn(50, c["R"], c["F"], generator=g).to(dev) for _ in range(2)]
-    senti = torch.ones(50, device=dev)
+    feats = [torch.randn(images, c["R"], c["F"], generator=g).to(dev) for _ in range(2)]
+    senti = torch.ones(images, device=dev)
     t_w = time.perf_counter()
-    while time.perf_counter() - t_w < 1.5:
-        diverse_decode(model._dec, feats[0], senti, 20, beam, c["L"], 1, early_stop=False)
+    while time.perf_counter() - t_w < 2.0:   # (a GPU coming out of idle needs > 1 s to reach its sustained state)
+        diverse_decode(model._dec, feats[0], senti, n_z, beam, c["L"], 1, early_stop=False)
         torch.cuda.synchronize()
     t0 = time.perf_counter()
     tokens = 0
-    for i in range(6):
-        pred, _ = diverse_decode(model._dec, feats[i % 2], senti, 20, beam, c["L"], 1, early_stop=False)
+    reps = 6
+    for i in range(reps):
+        pred, _ = diverse_decode(model._dec, feats[i % 2], senti, n_z, beam, c["L"], 1, early_stop=False)
         tokens += count_tokens(pred, 1)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    print(f"decode beam {beam}: {6 * 50 / el:.0f} images/s, {6 * 50 * 20 * c['L'] / el / 1e3:.0f} k row-tokens/s (20 samples x {c['L']} steps per image), "
-          f"{el / 6 * 1e3:.1f} ms per 50-image call", flush=True)
+    print(f"decode {images} images x {n_z} samples, beam {beam} ({images * n_z * beam} rows): {reps * images / el:.0f} images/s, "
+          f"{reps * images * n_z * c['L'] / el / 1e3:.0f} k tokens/s, {el / reps * 1e3:.1f} ms per call", flush=True)
 
 
 def main():
@@ -73,8 +74,8 @@ def main():
                          device=dev).to(dev)
     eng = model._engine()
     if decode:
-        for beam in (1, 5):
-            decode_probe(model, c, dev, beam)
+        for beam, images, n_z in ((1, 50, 20), (5, 50, 20), (10, 25, 20), (3, 50, 20), (5, 1, 20), (5, 8, 20), (5, 200, 1), (1, 1, 1)):
+            decode_probe(model, c, dev, beam, images, n_z)
         return
     if dropin:   # the reference's own loop (var_updown/scripts/train.py:154-176) on the module API: autograd, clip_grad_norm_, torch SGD
         opt = torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=0.015, momentum=0.9, weight_decay=0.001)
