@@ -74,7 +74,10 @@ def main():
                          device=dev).to(dev)
     eng = model._engine()
     if decode:
-        for beam, images, n_z in ((1, 50, 20), (5, 50, 20), (10, 25, 20), (3, 50, 20), (5, 1, 20), (5, 8, 20), (5, 200, 1), (1, 1, 1)):
+        shapes = ((1, 50, 20), (5, 50, 20), (10, 25, 20), (3, 50, 20), (5, 1, 20), (5, 8, 20), (5, 200, 1), (1, 1, 1))
+        if os.environ.get("SSC_PROBE_SMALL"):   # the small-call end only (the reference's own inference loop decodes one image at a time)
+            shapes = ((5, 1, 20), (5, 2, 20), (5, 4, 20), (1, 1, 20), (1, 4, 20))
+        for beam, images, n_z in shapes:
             decode_probe(model, c, dev, beam, images, n_z)
         return
     if dropin:   # the reference's own loop (var_updown/scripts/train.py:154-176) on the module API: autograd, clip_grad_norm_, torch SGD
