@@ -1570,8 +1570,8 @@ bool g_prof_on = false;
 // reach memory while the kernel is still running instead of being written back at the kernel boundary (rocprof timeline:
 // 1-3.5 us between such a kernel's end and its consumer's start).  Train step 8.76 -> 8.57-8.65 ms (same-box A/B, twice).  Round
 // 2's first try of this showed no difference: the 8-wave kernels were slower then and their own tail hid the write-back.
-int g_store_wt = getenv("SSC_STORE_WT") ? atoi(getenv("SSC_STORE_WT")) : 1;
-int g_tile_gm = getenv("SSC_TILE_GM") ? atoi(getenv("SSC_TILE_GM")) : 8;   // tile_order(): tile rows per group (0 = row-major)
+int g_store_wt = ssc_env_int("SSC_STORE_WT", 1);
+int g_tile_gm = ssc_env_int("SSC_TILE_GM", 8);   // tile_order(): tile rows per group (0 = row-major)
 int build_args(const ssc_gemm_desc* d, KArgs& k) {
   if (!d || d->nseg < 1 || d->nseg > SSC_MAX_SEG || d->M <= 0 || d->N <= 0) return SSC_EINVAL;
   k.tile_gm = g_tile_gm;
@@ -1614,7 +1614,7 @@ gemm_fn pick_layout(const ssc_gemm_desc* d) {
 int g_gemm_mode = -1;  // -1: take the default from the environment on first use
 inline int gemm_mode() {
   if (g_gemm_mode < 0) {
-    const char* e = getenv("SSC_GEMM_MODE");
+    const char* e = ssc_env_debug() ? getenv("SSC_GEMM_MODE") : nullptr;
     g_gemm_mode = (e && e[0] == 'f') ? 0 : 1;
   }
   return g_gemm_mode;
@@ -1630,7 +1630,7 @@ inline bool use_x3(const ssc_gemm_desc* d, bool vec) { return gemm_mode() == 1 &
 // under an exact ISA gate, the same kernel family has run the grouped weight gradients of every train step, and the 3000-image
 // decode of the fault ran clean with it twice (before and after the rebuild).  `ssc_debug_set("large_form", 3)` / SSC_X3B=3
 // selects the 4-wave kernel everywhere.
-int g_x3b = getenv("SSC_X3B") ? atoi(getenv("SSC_X3B")) : 1;
+int g_x3b = ssc_env_int("SSC_X3B", 1);
 int g_x3_nbuf = 1;  // single LDS stage: 31 KB per workgroup -> four resident workgroups per CU (rocprof r01: 37 vs 43 us)
 int g_x3_wide = 0;
 int g_x3_pf = 2;  // tuning hook: 1 = 64x128 block tile for skinny (M <= 64, N >= 1024) 3xBF16 products
@@ -1639,7 +1639,7 @@ inline bool x3_wide(int M, int N) { return g_x3_wide && M <= 64 && N >= 1024; }
 // 64-wide kernels streamed the weights once per 64 rows (B = 128: 16.2 -> 14.3 ms per train step, B = 256: 27.0 -> 22.9 ms with
 // the wave-specialised 128x128 form, same box; 65-127 rows: one padded tile row still beats two 64-row passes, B = 96: 14.6 ->
 // 12.5 ms).  "big_min_m" (SSC_BIG_MIN_M) = 512 restores the earlier behaviour.
-int g_big_min_m = getenv("SSC_BIG_MIN_M") ? atoi(getenv("SSC_BIG_MIN_M")) : 65;
+int g_big_min_m = ssc_env_int("SSC_BIG_MIN_M", 65);
 inline bool big_tile(int M, int N) { return M >= g_big_min_m && N >= 512; }
 // M <= 64 with a wide N: 64x128 block tile (wave tile 32x64).  Every workgroup re-reads the whole A operand
 // (the minibatch activations, from L2) for its K-range, and the CU-side load path (~24 GB/s per CU) is what these
@@ -1678,16 +1678,16 @@ int x3w_prepare() {
   done = true;
   return SSC_OK;
 }
-int g_x3w_skinny = getenv("SSC_X3W_SKINNY") ? atoi(getenv("SSC_X3W_SKINNY")) : 1;  // 0 off, 1 NT and NN, 2 NN only (hook -11 / -12 / -13)
-int g_x3w_min_n = getenv("SSC_X3W_MIN_N") ? atoi(getenv("SSC_X3W_MIN_N")) : 1024;   // narrower products do not fill the chip with 256-column tiles (rocprof: slower than the 64-wide kernels)
-int g_gemm_group = getenv("SSC_GEMM_GROUP") ? atoi(getenv("SSC_GEMM_GROUP")) : 1;   // grouped launches of independent minibatch products
-int g_dw_group = getenv("SSC_DW_GROUP") ? atoi(getenv("SSC_DW_GROUP")) : 1;       // grouped launches of the weight-gradient products (wave-specialised 128x128 form); 0 = one 4-wave launch per product
+int g_x3w_skinny = ssc_env_int("SSC_X3W_SKINNY", 1);  // 0 off, 1 NT and NN, 2 NN only (hook -11 / -12 / -13)
+int g_x3w_min_n = ssc_env_int("SSC_X3W_MIN_N", 1024);   // narrower products do not fill the chip with 256-column tiles (rocprof: slower than the 64-wide kernels)
+int g_gemm_group = ssc_env_int("SSC_GEMM_GROUP", 1);   // grouped launches of independent minibatch products
+int g_dw_group = ssc_env_int("SSC_DW_GROUP", 1);       // grouped launches of the weight-gradient products (wave-specialised 128x128 form); 0 = one 4-wave launch per product
 // k-steps of operand tiles in flight in the producers' registers of the 64x256 kernels: 2 (default) | 3.  Three (120 staged
 // VGPRs, loop unrolled 6x) measured 2-6 % SLOWER on every gate product (40.5 -> 42.8 us at 64 x 4800 x 5648; train step 9.22 ->
 // 9.45 ms): the k-loop is not short of bytes in flight.
-int g_x3w_pf = getenv("SSC_X3W_PF") ? atoi(getenv("SSC_X3W_PF")) : 2;
-int g_x3w_npw = getenv("SSC_X3W_NPW") ? atoi(getenv("SSC_X3W_NPW")) : 8;   // producer waves of the 64x256 kernels (4 | 8)
-int g_x3w_big_npw = getenv("SSC_X3W_BIG_NPW") ? atoi(getenv("SSC_X3W_BIG_NPW")) : 8;   // producer waves of the wave-specialised 128x128 kernels (4 | 8)
+int g_x3w_pf = ssc_env_int("SSC_X3W_PF", 2);
+int g_x3w_npw = ssc_env_int("SSC_X3W_NPW", 8);   // producer waves of the 64x256 kernels (4 | 8)
+int g_x3w_big_npw = ssc_env_int("SSC_X3W_BIG_NPW", 8);   // producer waves of the wave-specialised 128x128 kernels (4 | 8)
 inline int x3w_big_threads() { return g_x3w_big_npw == 8 ? 768 : 512; }
 inline group_fn x3w_big_fn(bool a_kc, bool b_kc, bool kg) {   // layouts NT, NN, TN (+ k-row gather lists)
   if (g_x3w_big_npw == 8)

@@ -1000,11 +1000,8 @@ extern "C" int ssc_lstm_bwd_x(const ssc_lstm_bwd_desc* d, const float* x, int ld
   if (K <= 256) {
     SSC_LAUNCH(lstm_bwd_x_kernel<256>, grid, dim3(512), lds, S(stream), *d, x, ldx, w, ldw, K);
   } else {
-    static bool raised = false;
-    if (!raised) {   // up to 157 KB of dynamic LDS at K = 768 (one workgroup per CU)
-      if (hipFuncSetAttribute((const void*)lstm_bwd_x_kernel<768>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return SSC_EHIP;
-      raised = true;
-    }
+    // up to 157 KB of dynamic LDS at K = 768 (one workgroup per CU).  The attribute is per device: set on every call (cheap)
+    if (hipFuncSetAttribute((const void*)lstm_bwd_x_kernel<768>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return SSC_EHIP;
     if (lds > 160 * 1024) return SSC_EINVAL;
     SSC_LAUNCH(lstm_bwd_x_kernel<768>, grid, dim3(512), lds, S(stream), *d, x, ldx, w, ldw, K);
   }

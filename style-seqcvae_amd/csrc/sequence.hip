@@ -801,7 +801,7 @@ static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const s
       d.c_prev = W + l.ce + t * sH; d.ld_cprev = l.Hp;
       d.c_new = W + l.ce + (t + 1) * sH; d.ld_cnew = l.Hp;
       d.dG = dge; d.dc_prev = W + l.g_ce; d.ld_dcprev = l.Hp;
-      if (fc_adjacent_b) {
+      if (fc_adjacent_b && 2 * Z <= 768) {   // ssc_lstm_bwd_x holds a K <= 768 operand image in LDS; wider latents take the product below
         SSC_TRY(ssc_lstm_bwd_x(&d, dmulv, 2 * Z, p->fc_mean_w, p->ld_fc_mean_w, 2 * Z, st));
       } else {
         SSC_TRY(gemm_to_slabs(c, W + l.sl_dhe, l.small_floats, true, false,

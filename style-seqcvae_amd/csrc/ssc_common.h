@@ -32,6 +32,17 @@ extern thread_local int ssc_tls_hip_error;
     if (rc__ != SSC_OK) return rc__; \
   } while (0)
 
+// Tuning / diagnostic defaults may be overridden from the environment ONLY in a process that opts in with SSC_DEBUG=1: a stray
+// SSC_* variable must not change which kernels the product path runs.  Tools (tools/*.py) set SSC_DEBUG=1.
+#include <stdlib.h>
+#include <string.h>
+static inline bool ssc_env_debug() { const char* d = getenv("SSC_DEBUG"); return d && d[0] == '1'; }
+static inline int ssc_env_int(const char* name, int dflt) {
+  if (!ssc_env_debug()) return dflt;
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
 static inline bool ssc_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 static inline int ssc_cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline size_t ssc_round_up(size_t a, size_t b) { return (a + b - 1) / b * b; }

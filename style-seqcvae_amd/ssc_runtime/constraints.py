@@ -13,10 +13,13 @@ the edge's origin).  `constraint2states[c]` lists the main states (below 2**len(
 what `select_best_beam_with_constraints(cbs_simple=False)` consumes (ssc_runtime/decoding.py).
 
 `ConstraintFilter` (constraints.py:56-209) turns one image's detector output into at most k constraint classes: blacklist,
-hierarchy-aware suppression of overlapping boxes (a "dog" box suppresses a "carnivore" box on the same pixels), top-k by
-confidence.  The reference keeps the Open Images hierarchy in an `anytree` tree; anytree is not importable here, so the tree is
-flattened at load time (pre-order label list + node heights) and the reference cannot be run for fixtures: **parity unpinned**
-beyond the hand-checkable cases of tests/test_constraints_cpu.py.  It runs once per image on the host, far from the hot path.
+top-k by confidence, renames.  The reference's docstring also promises hierarchy-aware suppression of overlapping boxes (a "dog"
+box suppresses a "carnivore" box on the same pixels), but its `_nms` as EXECUTED never drops a box: the work list is sorted by
+ascending height, so for the current (finest) box `heights[rest] >= heights[current]` is always true and `keep_condition` with it
+(constraints.py:195-203).  The default here reproduces what the reference executes (pinned by tests/golden/g13_filter.npz: the
+reference's own `__call__` / `_nms` with the tree heights injected - anytree is not importable, so the tree is flattened at load
+time into a pre-order label list + node heights); the suppression the docstring describes is available as `hierarchy_nms=True`
+(a divergence from the reference, documented in INTEGRATION.md).  It runs once per image on the host, far from the hot path.
 """
 import csv
 import json
@@ -37,11 +40,12 @@ def read_wordforms(tsv_path: str) -> Dict[str, List[str]]:
 
 
 def add_constraint_words_to_vocabulary(vocabulary, wordforms_tsvpath: str, namespace: str = "tokens"):
-    """Every word form of every constraint class becomes a vocabulary token (constraints.py:19-53): CBS can only force
-    words the output layer can emit."""
+    """Every TOKEN of every word form of every constraint class becomes a vocabulary entry (constraints.py:19-53; a form may be
+    several words - "fire hydrant" adds "fire" and "hydrant", :47-51): CBS can only force words the output layer can emit."""
     for forms in read_wordforms(wordforms_tsvpath).values():
-        for w in forms:
-            vocabulary.add_token_to_namespace(w, namespace)
+        for form in forms:
+            for w in form.split():
+                vocabulary.add_token_to_namespace(w, namespace)
     return vocabulary
 
 
@@ -61,7 +65,9 @@ class ConstraintFilter:
                     "salt and pepper shakers": "salt and pepper", "power plugs and sockets": "power plugs",
                     "luggage and bags": "luggage"}
 
-    def __init__(self, hierarchy_jsonpath: Union[str, dict], nms_threshold: float = 0.85, max_given_constraints: int = 3):
+    def __init__(self, hierarchy_jsonpath: Union[str, dict], nms_threshold: float = 0.85, max_given_constraints: int = 3,
+                 hierarchy_nms: bool = False):
+        self._hierarchy_nms = hierarchy_nms
         root = hierarchy_jsonpath if isinstance(hierarchy_jsonpath, dict) else json.load(open(hierarchy_jsonpath))
         # pre-order walk of {"LabelName": ..., "Subcategory": [...]}: lower-cased labels and node heights (edges on the longest
         # path down to a leaf - anytree's `height`), iteratively
@@ -108,10 +114,13 @@ class ConstraintFilter:
         return list({self.REPLACEMENTS.get(names[i], names[i]) for i in ranked})
 
     def _suppress(self, boxes: np.ndarray, names: Sequence[str]) -> List[int]:
-        """Indices kept, finest class first.  A box is dropped iff a KEPT box of a strictly finer class (smaller height)
-        overlaps it with IoU > threshold; boxes of equal height never suppress each other (constraints.py:155-209, restated
-        over the full IoU matrix instead of the shrinking work list; IoU with the pixel-inclusive +1 of the reference)."""
+        """Indices kept, finest class first (`heights.argsort()`, constraints.py:171).  Default: every box - what the
+        reference's loop executes (module docstring).  `hierarchy_nms=True`: a box is dropped iff a KEPT box of a strictly finer
+        class (smaller height) overlaps it with IoU > threshold; boxes of equal height never suppress each other (the
+        behaviour constraints.py:56-70 describes; IoU with the pixel-inclusive +1 of :176-192)."""
         h = np.array([self.height(c) for c in names])
+        if not self._hierarchy_nms:
+            return [int(i) for i in h.argsort()]
         x1, y1, x2, y2 = boxes.T
         area = (x2 - x1 + 1) * (y2 - y1 + 1)
         iw = np.maximum(0.0, np.minimum(x2[:, None], x2[None, :]) - np.maximum(x1[:, None], x1[None, :]) + 1)

@@ -185,10 +185,13 @@ class PrefetchLoader:
                 flat, nb, off = d.ragged
                 src, nbl, offl = flat.numpy(), nb.tolist(), off.tolist()
                 R = max(nbl[r] for r in idx)
+                # the batch is written as a CONTIGUOUS (B, R, F) block at the head of the pinned buffer, so that the upload
+                # is one dense asynchronous memcpy (a strided [:, :R] view would go through a pageable temporary)
+                hv = hf.reshape(-1)[: len(idx) * R * hf.shape[2]].reshape(len(idx), R, hf.shape[2])
                 for i, r in enumerate(idx):
                     n_i = nbl[r]
-                    np.copyto(hf[i, :n_i], src[offl[r]:offl[r] + n_i])
-                    hf[i, n_i:R] = 0
+                    np.copyto(hv[i, :n_i], src[offl[r]:offl[r] + n_i])
+                    hv[i, n_i:R] = 0
                 h["R"] = R
             ii = np.asarray(idx)
             np.take(d.caps.numpy(), ii, axis=0, out=h["caption_tokens"].numpy())
@@ -214,12 +217,15 @@ class PrefetchLoader:
             # finish before it is overwritten.
             self._stream.wait_stream(torch.cuda.current_stream(self.device))
             for key in ("image_features", "caption_tokens", "sentiment", "image_id"):
-                src = h[key][:, :R] if key == "image_features" else h[key]
-                dst = dv[key][:, :R] if key == "image_features" else dv[key]
+                src, dst = h[key], dv[key]
+                if key == "image_features" and R != dst.size(1):
+                    # ragged batch narrower than the staging buffer: the producer packed it as a dense (B, R, F) block at the
+                    # head of the pinned buffer; the same view of the device buffer receives it in one contiguous async copy
+                    B_, F_ = dst.size(0), dst.size(2)
+                    src = src.view(-1)[: B_ * R * F_].view(B_, R, F_)
+                    dst = dst.view(-1)[: B_ * R * F_].view(B_, R, F_)
                 dst.copy_(src, non_blocking=True)
                 out[key] = dst
-            if R != dv["image_features"].size(1):      # ragged batch narrower than the staging buffer: dense (B,R,F) copy
-                out["image_features"] = out["image_features"].contiguous()
             ev = torch.cuda.Event()
             ev.record(self._stream)
         # the PINNED set j may be refilled once these copies have completed; the previous set's copies are checked now
@@ -240,8 +246,6 @@ class PrefetchLoader:
         out, ev = self._pending
         cur = torch.cuda.current_stream(self.device)
         cur.wait_event(ev)
-        for t in out.values():
-            t.record_stream(cur)    # (a ragged batch's dense copy was allocated on the copy stream)
         self._pending = self._issue_upload()
         self.next_batch += 1
         return out

@@ -15,7 +15,7 @@ from .decode import DecodeEngine, cbs_search
 from .decoding import select_best_beam_with_constraints
 
 
-_RAW = os.environ.get("SSC_RAW_LOGITS", "1") != "0"   # A/B switch (tools): 0 = log_softmax kernel + selection on log-probs
+_RAW = not (os.environ.get("SSC_DEBUG", "") == "1" and os.environ.get("SSC_RAW_LOGITS", "1") == "0")   # A/B switch (tools): 0 = log_softmax kernel + selection on log-probs
 
 
 def diverse_decode(dec: DecodeEngine, feats: torch.Tensor, sentiment: Optional[torch.Tensor], n_samples: int, beam: int,

@@ -3,7 +3,10 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("SSC_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "libssc_hip.so")   # override: A/B of builds (tools)
+# The product always loads the in-tree library.  Tools that A/B two builds opt in with SSC_DEBUG=1 (then SSC_LIB_PATH is honoured);
+# without it a stray SSC_LIB_PATH is ignored.
+DEBUG_ENV = os.environ.get("SSC_DEBUG", "") == "1"
+LIB_PATH = (DEBUG_ENV and os.environ.get("SSC_LIB_PATH")) or os.path.join(os.path.dirname(_HERE), "libssc_hip.so")
 SSC_MAX_SEG = 6
 
 c_float_p = C.POINTER(C.c_float)

@@ -37,6 +37,8 @@ sys.path.insert(0, ROOT)
 sys.dont_write_bytecode = True
 
 import oracle  # noqa: E402
+sys.path.insert(0, os.path.dirname(HERE))
+from goldenlib import cbs_table_step  # noqa: E402  (the step function the g12 search cases are defined on)
 
 
 class ToyVocabulary:
@@ -445,9 +447,252 @@ def fsm_fixture(name="g9_fsm"):
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **data)
 
 
+class Torch11:
+    """Run the reference's UNMODIFIED search driver (updown-baseline/updown/modules/cbs.py) under torch 2.x by restoring the two
+    torch-1.1 tensor semantics it relies on - the same rebinding pattern as EpsInjector, nothing in the reference is edited:
+    * ``Tensor.masked_fill`` with a uint8 mask treats it as a boolean mask (cbs.py:134-136, :204-206);
+    * ``/`` between an integer tensor and a Python int is floor division (cbs.py:231, ``backpointer = idx / per_node``)."""
+
+    def __enter__(self):
+        self._mf, self._td = torch.Tensor.masked_fill, torch.Tensor.__truediv__
+        mf, td = self._mf, self._td
+
+        def masked_fill(t, mask, value):
+            return mf(t, mask.bool() if mask.dtype == torch.uint8 else mask, value)
+
+        def truediv(t, other):
+            if not t.is_floating_point() and isinstance(other, int):
+                return torch.div(t, other, rounding_mode="floor")
+            return td(t, other)
+
+        torch.Tensor.masked_fill, torch.Tensor.__truediv__ = masked_fill, truediv
+        return self
+
+    def __exit__(self, *a):
+        torch.Tensor.masked_fill, torch.Tensor.__truediv__ = self._mf, self._td
+
+
+CBS_CASES = [  # (B, S, V, beam, per_node, max_steps, end_boost)   end_boost large -> every beam ends -> early stop (cbs.py:167)
+    (2, 1, 50, 5, 2, 8, 0.0), (2, 3, 50, 3, 2, 8, 1.5), (3, 4, 97, 3, 2, 9, 1.5), (1, 4, 61, 5, 2, 7, 0.0),
+    (2, 1, 40, 1, 1, 8, 1.5), (2, 3, 40, 1, 1, 6, 0.0), (1, 3, 300, 5, 1, 8, 0.0), (2, 1, 30, 3, 2, 12, 9.0),
+    (1, 3, 30, 3, 2, 12, 9.0), (2, 4, 45, 5, 2, 20, 3.0),
+]
+
+
+def cbs_case_inputs(ci):
+    B, S, V, beam, per_node, steps, boost = CBS_CASES[ci]
+    g = torch.Generator().manual_seed(500 + ci)
+    table = torch.randn(V, V, generator=g) * 2.0
+    table[:, 1] += boost
+    drift = torch.randn(7, V, generator=g) * 0.5
+    if S == 1:
+        fsm = torch.ones(B, 1, 1, V, dtype=torch.uint8)
+    else:
+        fsm = (torch.rand(B, S, S, V, generator=g) < 0.5).to(torch.uint8)
+        fsm[:, :, :, 1] = 1  # @@BOUNDARY@@ is allowed on every transition (as in the reference's machines, constraints.py:300-320)
+    return table, drift, fsm
+
+
+def cbs_fixture(UpDownCaptioner, name="g12_cbs"):
+    """(i) ``ConstrainedBeamSearch.search`` (updown-baseline/updown/modules/cbs.py:59-277), unmodified, under Torch11, driven by
+    the table step above (5-tuple, as var_updown's patched driver expects at :127,:169) for S in {1,3,4}, beam in {1,3,5},
+    per-node in {1,2}, early stop hit and not hit.  (ii) the reference ``UpDownCaptioner.forward`` eval branch
+    (var_updown/var_updown/models/updown_captioner.py:324-366; tied 300-d subclass, use_cbs=True, B=1) end to end with injected
+    ``eps`` and machines from the reference ``FiniteStateMachineBuilder``."""
+    import json
+    import tempfile
+    from updown.modules.cbs import ConstrainedBeamSearch
+    data = {"ncases": np.array(len(CBS_CASES))}
+    for ci, (B, S, V, beam, per_node, steps, boost) in enumerate(CBS_CASES):
+        table, drift, fsm = cbs_case_inputs(ci)
+        inner = cbs_table_step(table, drift)
+        calls = {"n": 0}
+
+        def step5(tokens, state):
+            calls["n"] += 1
+            lp, st = inner(tokens, state)
+            return lp, st, None, None, None
+        search = ConstrainedBeamSearch(1, max_steps=steps, beam_size=beam, per_node_beam_size=per_node)
+        with Torch11(), torch.no_grad():
+            preds, lps = search.search(torch.full((B,), 1, dtype=torch.long), None, step5, fsm)
+        key = f"search/case{ci}"
+        data[key + "/dims"] = np.array([B, S, V, beam, per_node, steps])
+        data[key + "/boost"] = np.array(boost)
+        data[key + "/table"] = table.numpy()
+        data[key + "/drift"] = drift.numpy()
+        data[key + "/fsm_bits"] = np.packbits(fsm.numpy())
+        data[key + "/predictions"] = preds.numpy()
+        data[key + "/log_probs"] = lps.numpy()
+        data[key + "/step_calls"] = np.array(calls["n"])
+        print(name, key, (B, S, V, beam, per_node, steps), "step calls", calls["n"], "steps out", preds.shape[-1])
+
+    # (ii) the captioner's eval branch
+    def mod(n, **attrs):
+        m = types.ModuleType(n)
+        m.__dict__.update(attrs)
+        sys.modules[n] = m
+    if "anytree" not in sys.modules:
+        mod("anytree")
+        mod("anytree.search", findall=lambda *a, **k: [])
+    from updown.utils.constraints import FiniteStateMachineBuilder
+    words = ["a", "the", "dog", "dogs", "cat", "cats", "fire", "hydrant", "hydrants", "red", "reddish", "on", "street", "sits"]
+    vocab = ToyVocabulary(2)
+    vocab._tokens += words + [f"w{i}" for i in range(40)]
+    vocab._index = {t: i for i, t in enumerate(vocab._tokens)}
+    V = len(vocab._tokens)
+    wordforms = "dog\tdog,dogs\ncat\tcat,cats\nfire\tfire\nhydrant\thydrant,hydrants\nred\tred,reddish\n"
+    F, E, H, A, Z, L, R, beam = 48, 300, 32, 16, 8, 9, 5, 3
+    data["eval/vocab_tokens"] = np.array(json.dumps(vocab._tokens))
+    data["eval/wordforms_tsv"] = np.array(wordforms)
+    data["eval/dims"] = np.array([V, E, H, A, F, Z, L, R, beam])
+
+    class Tied(UpDownCaptioner):
+        def _initialize_glove(self):
+            t = torch.randn(self._vocabulary.get_vocab_size(), self.embedding_size, generator=torch.Generator().manual_seed(78)) * 0.3
+            t[0] = 0
+            return t
+    eval_cases = [(["dog"], [["dog", []]], 1, 1), ([], [], 2, 1), (["dog", "cat"], [["dog", []], ["cat", []]], 2, 1),
+                  (["fire hydrant", "dog"], [["fire hydrant", []], ["dog", []]], 2, -1),
+                  (["dog", "cat", "red"], [["dog", ["red"]], ["cat", []]], 2, 0),
+                  (["dog", "cat", "fire hydrant"], [["dog", []], ["cat", []], ["fire hydrant", []]], 3, 1)]
+    data["eval/ncases"] = np.array(len(eval_cases))
+    with tempfile.TemporaryDirectory() as td:
+        tsv = os.path.join(td, "wordforms.tsv")
+        open(tsv, "w").write(wordforms)
+        builder = FiniteStateMachineBuilder(vocab, tsv, None, max_given_constraints=3)
+        for ci, (cons, cands, min_sat, senti_v) in enumerate(eval_cases):
+            torch.manual_seed(20 + ci)
+            model = Tied(vocab, image_feature_size=F, embedding_size=E, hidden_size=H, attention_projection_size=A,
+                         max_caption_length=L, beam_size=beam, use_cbs=True, min_constraints_to_satisfy=min_sat, z_space=Z,
+                         prior_std=1.0, simple_vae=False, latent_embedding="glove", sentiment_vae=1, senti_prior_multip=0.5,
+                         cbs_simple=True, device=torch.device("cpu"))
+            model.eval()
+            fsm_full, nstates, c2s = builder.build(list(cons))
+            fsm = fsm_full[:nstates, :nstates, :].unsqueeze(0).contiguous()
+            S = nstates
+            g = torch.Generator().manual_seed(900 + ci)
+            feats = torch.randn(1, R, F, generator=g)
+            if ci == 2:
+                feats[0, R - 1:] = 0
+            senti = torch.tensor([[float(senti_v)]])
+            eps = [torch.randn(1, Z, generator=g)] + [torch.randn(S * beam, Z, generator=g) for _ in range(L - 1)]
+            seen = {}
+            orig_search = model._beam_search.search
+
+            def spy(*a, **k):
+                out = orig_search(*a, **k)
+                seen["beams"], seen["lps"] = out[0].clone(), out[1].clone()
+                return out
+            model._beam_search.search = spy
+            with Torch11(), torch.no_grad(), EpsInjector(eps) as inj:
+                out = model(feats.clone(), None, None, fsm=fsm, num_constraints=torch.tensor([len(cons)]),
+                            constraints=[cands], constraint2states=[c2s], sentiment=senti)
+            key = f"eval/case{ci}"
+            for k2, v in state_dict_np(model).items():
+                data[f"{key}/{k2}"] = v
+            data[key + "/constraints"] = np.array(json.dumps(cons))
+            data[key + "/candidates"] = np.array(json.dumps(cands))
+            data[key + "/constraint2states"] = np.array(json.dumps(c2s))
+            data[key + "/min"] = np.array(min_sat)
+            data[key + "/nstates"] = np.array(S)
+            data[key + "/fsm_bits"] = np.packbits(fsm.numpy())
+            data[key + "/feats"] = feats.numpy()
+            data[key + "/sentiment"] = senti.numpy()
+            data[key + "/eps0"] = eps[0].numpy()
+            data[key + "/eps_rest"] = torch.stack(eps[1:]).numpy()
+            data[key + "/eps_used"] = np.array(inj.k)
+            data[key + "/predictions"] = out["predictions"].numpy()
+            data[key + "/beams"] = seen["beams"].numpy()
+            data[key + "/log_probs"] = seen["lps"].numpy()
+            print(name, key, cons, "S", S, "eps used", inj.k, "pred", [vocab._tokens[int(t)] for t in out["predictions"][0]])
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **data)
+
+
+FILTER_HIERARCHY = {"LabelName": "Entity", "Subcategory": [
+    {"LabelName": "Animal", "Subcategory": [
+        {"LabelName": "Carnivore", "Subcategory": [{"LabelName": "Dog"}, {"LabelName": "Cat"}, {"LabelName": "Bear"}]},
+        {"LabelName": "Bird", "Subcategory": [{"LabelName": "Owl"}, {"LabelName": "Duck"}]},
+        {"LabelName": "Mammal"}]},
+    {"LabelName": "Vehicle", "Subcategory": [{"LabelName": "Land vehicle", "Subcategory": [{"LabelName": "Car"}, {"LabelName": "Truck"}]},
+                                             {"LabelName": "Boat"}]},
+    {"LabelName": "Furniture", "Subcategory": [{"LabelName": "Kitchen & dining room table"}, {"LabelName": "Chair"}]},
+    {"LabelName": "Band-aid"}, {"LabelName": "Person"}, {"LabelName": "Luggage and bags"}]}
+FILTER_CASES = [  # (boxes x1 y1 x2 y2, class names, scores)
+    # identical boxes on a dog / carnivore / animal: as EXECUTED the reference keeps all three (the work list is sorted by ascending
+    # height, so `heights[rest] >= heights[current]` holds for every pair and nothing is ever suppressed, constraints.py:195-203)
+    ([[10, 10, 100, 100], [10, 10, 100, 100], [10, 10, 100, 100]], ["dog", "carnivore", "animal"], [0.9, 0.8, 0.7]),
+    ([[10, 10, 100, 100], [12, 11, 101, 99], [200, 200, 300, 300], [0, 0, 50, 50]], ["carnivore", "dog", "car", "cat"], [0.95, 0.6, 0.8, 0.7]),
+    # blacklist, padding boxes (score 0), replacements, duplicates, more boxes than k
+    ([[0, 0, 10, 10], [20, 20, 40, 40], [50, 50, 90, 90], [0, 0, 0, 0], [5, 5, 15, 15]],
+     ["person", "kitchen & dining room table", "band-aid", "dog", "mammal"], [0.99, 0.5, 0.6, 0.0, 0.9]),
+    ([[0, 0, 10, 10], [20, 20, 40, 40], [50, 50, 90, 90], [60, 60, 95, 95], [1, 1, 9, 9]],
+     ["dog", "dog", "owl", "bird", "luggage and bags"], [0.3, 0.9, 0.8, 0.85, 0.2]),
+    ([[0, 0, 10, 10], [0, 0, 10, 10], [0, 0, 10, 10], [0, 0, 10, 10], [0, 0, 10, 10]],
+     ["animal", "vehicle", "car", "duck", "chair"], [0.5, 0.5, 0.5, 0.5, 0.5]),
+    ([], [], []),
+    ([[0, 0, 10, 10]], ["person"], [0.9]),
+    ([[3, 3, 30, 30], [3, 3, 30, 30]], ["truck", "land vehicle"], [0.4, 0.7]),
+]
+
+
+def filter_fixture(name="g13_filter"):
+    """``ConstraintFilter.__call__`` + ``_nms`` (updown-baseline/updown/utils/constraints.py:105-209), unmodified, for k = 3 and 2.
+    anytree is absent: the instance is made without ``__init__`` (which only builds the anytree tree, :105-121) and ``findall`` -
+    the one anytree call of ``_nms`` (:163-166) - is bound to a walk over a flat pre-order node list with INJECTED heights (edges
+    on the longest path to a leaf), so the fixture pins the executed filtering logic given the hierarchy's heights."""
+    import json
+
+    class Node:
+        def __init__(self, label, height):
+            self.LabelName, self.height = label, height
+
+    nodes = []
+
+    def walk(d):
+        me = Node(d["LabelName"], 0)
+        nodes.append(me)
+        for c in d.get("Subcategory", []):
+            me.height = max(me.height, walk(c) + 1)
+        return me.height
+    walk(FILTER_HIERARCHY)
+
+    def mod(n, **attrs):
+        m = types.ModuleType(n)
+        m.__dict__.update(attrs)
+        sys.modules[n] = m
+    mod("anytree")
+    mod("anytree.search", findall=lambda root, filter_: [n for n in nodes if filter_(n)])
+    for m in [k for k in sys.modules if k.startswith("updown.utils.constraints")]:
+        del sys.modules[m]
+    from updown.utils.constraints import ConstraintFilter
+    data = {"hierarchy": np.array(json.dumps(FILTER_HIERARCHY)), "ncases": np.array(len(FILTER_CASES)),
+            "heights": np.array(json.dumps({n.LabelName.lower(): n.height for n in nodes}))}
+    for k in (3, 2):
+        f = object.__new__(ConstraintFilter)
+        f._hierarchy, f._nms_threshold, f._max_given_constraints = None, 0.85, k
+        for ci, (boxes, names, scores) in enumerate(FILTER_CASES):
+            b = np.asarray(boxes, dtype=np.float64).reshape(-1, 4)
+            sc = np.asarray(scores, dtype=np.float64)
+            kept = f(b, list(names), sc)
+            keep_idx = f._nms(b, list(names)) if len(names) else []
+            key = f"k{k}/case{ci}"
+            data[key + "/boxes"], data[key + "/scores"] = b, sc
+            data[key + "/names"] = np.array(json.dumps(list(names)))
+            data[key + "/kept"] = np.array(json.dumps(sorted(kept)))
+            data[key + "/nms_keep"] = np.asarray(keep_idx, dtype=np.int64)
+            print(name, key, names, "->", sorted(kept), "nms keeps", list(map(int, keep_idx)))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **data)
+
+
 def main():
     UpDownCaptioner = import_reference()
+    filter_fixture()
+    if "--only-filter" in sys.argv:
+        return
     fsm_fixture()
+    cbs_fixture(UpDownCaptioner)
+    if "--only-cbs" in sys.argv:
+        return
     cell_fixture()
     if "--full" in sys.argv or not os.path.exists(os.path.join(HERE, "g10_full_c2.npz")):
         full_size_fixture(UpDownCaptioner, "g10_full_c1", B=4, unk=False)      # BASELINE configs[0]: batch 4

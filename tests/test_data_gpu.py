@@ -46,6 +46,9 @@ def test_prefetch_loader_ragged_zero_pads_each_batch(tmp_path):
         R = int(nb[idx].max())
         f = b["image_features"].cpu()
         assert f.shape == (6, R, 12) and b["image_features"].is_contiguous()
+        # no extra dense copy: the batch is a view of the loader's device ring (one contiguous asynchronous upload)
+        ring = {dv["image_features"].untyped_storage().data_ptr() for dv in ld._dev}
+        assert b["image_features"].untyped_storage().data_ptr() in ring
         for i, r in enumerate(idx.tolist()):
             n = int(nb[r])
             assert torch.equal(f[i, :n], flat[off[r]:off[r] + n]) and not f[i, n:].any()

@@ -1,6 +1,7 @@
-"""GPU: constrained beam search bookkeeping (ssc_beam_*) and the whole eval forward against the CPU oracle
-(oracle.cbs_search restates cbs.py with torch-1.1 semantics; the reference's own cbs.py cannot run on torch>=1.2,
-SURVEY §8(c): pinned by step-level goldens + invariants)."""
+"""GPU: constrained beam search bookkeeping (ssc_beam_*) and the whole eval forward against (a) the reference itself -
+tests/golden/g12_cbs.npz holds the results of the UNMODIFIED updown/modules/cbs.py and of the reference captioner's eval
+branch (generated under the torch-1.1 shim of tests/golden/make_golden.py::Torch11) - and (b) the CPU oracle, which
+tests/test_oracle_cbs_cpu.py shows bit-equal to those fixtures."""
 import pytest
 import torch
 
@@ -210,6 +211,64 @@ def test_trivial_fsm_none_equals_all_ones_mask():
     a, alp = cbs_search(start, None, step, ones, 1, steps, beam, 2)
     b, blp = cbs_search(start, None, step, None, 1, steps, beam, 2)
     assert torch.equal(a, b) and torch.equal(alp, blp)
+
+
+# ---- the reference's own results (g12_cbs) ---------------------------------------------------------------------------------
+from goldenlib import cbs_table_step, load_raw, unpack_fsm  # noqa: E402
+from test_oracle_cbs_cpu import g12_eval_case  # noqa: E402
+
+_G12 = load_raw("g12_cbs")
+
+
+@pytest.mark.parametrize("ci", range(int(_G12["ncases"])))
+def test_cbs_search_hip_equals_reference_fixture(ci):
+    """ssc_beam_first/step/backtrace driven by ssc_runtime.decode.cbs_search == ConstrainedBeamSearch.search (cbs.py:59-277,
+    run unmodified): predictions bit-equal wherever the beam is reachable (a beam whose log-prob is -inf / <= -1e19 holds an
+    arbitrary tie among forbidden tokens), log-probs to 1e-4 (the table step's log_softmax runs on the device here)."""
+    key = f"search/case{ci}"
+    B, S, V, beam, per_node, steps = (int(x) for x in _G12[key + "/dims"])
+    table, drift = torch.from_numpy(_G12[key + "/table"]).cuda(), torch.from_numpy(_G12[key + "/drift"]).cuda()
+    fsm = unpack_fsm(_G12[key + "/fsm_bits"], B, S, V)
+    inner, calls = cbs_table_step(table, drift), {"n": 0}
+
+    def step(tokens, state):
+        calls["n"] += 1
+        return inner(tokens, state)
+    want_p, want_lp = torch.from_numpy(_G12[key + "/predictions"]), torch.from_numpy(_G12[key + "/log_probs"])
+    got_p, got_lp = cbs_search(torch.full((B,), 1, dtype=torch.long, device="cuda"), None, step, fsm.cuda(), 1, steps, beam, per_node)
+    assert got_p.shape == want_p.shape                      # same number of steps: the early stop fired at the same step
+    assert calls["n"] == int(_G12[key + "/step_calls"])
+    finite = torch.isfinite(want_lp) & (want_lp > -1e19)
+    assert maxdiff(got_lp.cpu()[finite], want_lp[finite]) < 1e-4
+    assert torch.equal(got_p.cpu()[finite], want_p[finite])
+
+
+@pytest.mark.parametrize("ci", range(int(_G12["eval/ncases"])))
+def test_eval_forward_hip_equals_reference_fixture(ci):
+    """The drop-in captioner's eval forward (HIP decode steps + device-side CBS + host-side beam selection) == the reference
+    UpDownCaptioner.forward eval branch (updown_captioner.py:324-366) on the same weights, features, injected eps and
+    reference-built machine: identical caption."""
+    from ssc_runtime.vocab import Vocabulary
+    from var_updown.models import UpDownCaptioner
+    c = g12_eval_case(ci)
+    cfg = c["cfg"]
+
+    class Tied(UpDownCaptioner):   # the table comes from the state dict
+        def _initialize_glove(self):
+            return torch.zeros(self._vocabulary.get_vocab_size(), self.embedding_size)
+
+    m = Tied(Vocabulary(c["vocab"]), cfg.image_feature_size, cfg.embedding_size, cfg.hidden_size, cfg.attention_projection_size,
+             max_caption_length=cfg.max_caption_length, beam_size=c["beam"], use_cbs=True, min_constraints_to_satisfy=c["min_sat"],
+             z_space=cfg.z_space, prior_std=1.0, latent_embedding="glove", sentiment_vae=1, senti_prior_multip=0.5,
+             cbs_simple=True, device=torch.device("cuda"))
+    sd = dict(c["params"])
+    sd["_output_layer.weight"] = sd["_embedding_layer.weight"]
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    m._eps_override = [e.clone() for e in c["eps"]]
+    out = m(dev(c["feats"]), None, None, sentiment=dev(c["senti"]), fsm=c["fsm"], num_constraints=torch.tensor([len(c["constraints"])]),
+            constraints=[c["candidates"]], constraint2states=[c["c2s"]])
+    assert torch.equal(out["predictions"].cpu(), c["want"])
 
 
 # ---- constrained beam search with REAL finite state machines (SURVEY 8(f)-1) -------------------------------------------------

@@ -91,3 +91,65 @@ def test_fsm_constraint_is_honoured():
             assert 5 not in p[0, 0, k].tolist()
     best = oracle.select_best_beam_with_constraints(p, lp, torch.tensor([1]), min_constraints_to_satisfy=1)
     assert 5 in best[0].tolist()
+
+
+# ---- pinned to the reference: tests/golden/g12_cbs.npz was produced by the UNMODIFIED updown/modules/cbs.py (under the
+# two-method torch-1.1 shim of tests/golden/make_golden.py::Torch11) and by the reference captioner's eval branch -------------
+import json  # noqa: E402
+
+import pytest  # noqa: E402
+
+from goldenlib import cbs_table_step, load_raw, unpack_fsm  # noqa: E402
+
+_G12 = load_raw("g12_cbs")
+
+
+@pytest.mark.parametrize("ci", range(int(_G12["ncases"])))
+def test_cbs_search_equals_reference_fixture(ci):
+    """oracle.cbs_search == ConstrainedBeamSearch.search (cbs.py:59-277) bit for bit: predictions, log-probs, number of step
+    calls (early stop, cbs.py:167) for S in {1,3,4}, beam in {1,3,5}, per-node in {1,2}."""
+    key = f"search/case{ci}"
+    B, S, V, beam, per_node, steps = (int(x) for x in _G12[key + "/dims"])
+    table, drift = torch.from_numpy(_G12[key + "/table"]), torch.from_numpy(_G12[key + "/drift"])
+    fsm = unpack_fsm(_G12[key + "/fsm_bits"], B, S, V)
+    inner, calls = cbs_table_step(table, drift), {"n": 0}
+
+    def step(tokens, state):
+        calls["n"] += 1
+        return inner(tokens, state)
+    p, lp = oracle.cbs_search(torch.full((B,), 1, dtype=torch.long), None, step, fsm, 1, steps, beam, per_node)
+    assert torch.equal(p, torch.from_numpy(_G12[key + "/predictions"]))
+    assert torch.equal(lp, torch.from_numpy(_G12[key + "/log_probs"]))
+    assert calls["n"] == int(_G12[key + "/step_calls"])
+
+
+def g12_eval_case(ci):
+    key = f"eval/case{ci}"
+    V, E, H, A, F, Z, L, R, beam = (int(x) for x in _G12["eval/dims"])
+    cfg = oracle.OracleConfig(vocab_size=V, image_feature_size=F, embedding_size=E, hidden_size=H, attention_projection_size=A,
+                              z_space=Z, max_caption_length=L, sentiment_vae=1, senti_prior_multip=0.5, tied=True, beam_size=beam)
+    params = {k[len(key) + 7:]: torch.from_numpy(v) for k, v in _G12.items() if k.startswith(key + "/param/")}
+    S = int(_G12[key + "/nstates"])
+    case = dict(cfg=cfg, params=params, S=S, beam=beam, fsm=unpack_fsm(_G12[key + "/fsm_bits"], 1, S, V),
+                feats=torch.from_numpy(_G12[key + "/feats"]), senti=torch.from_numpy(_G12[key + "/sentiment"]),
+                eps=[torch.from_numpy(_G12[key + "/eps0"])] + list(torch.from_numpy(_G12[key + "/eps_rest"])),
+                constraints=json.loads(str(_G12[key + "/constraints"])), min_sat=int(_G12[key + "/min"]),
+                want=torch.from_numpy(_G12[key + "/predictions"]), beams=torch.from_numpy(_G12[key + "/beams"]),
+                lps=torch.from_numpy(_G12[key + "/log_probs"]), vocab=json.loads(str(_G12["eval/vocab_tokens"])),
+                wordforms=str(_G12["eval/wordforms_tsv"]), candidates=json.loads(str(_G12[key + "/candidates"])),
+                c2s=json.loads(str(_G12[key + "/constraint2states"])))
+    return case
+
+
+@pytest.mark.parametrize("ci", range(int(_G12["eval/ncases"])))
+def test_eval_forward_equals_reference_fixture(ci):
+    """oracle.eval_forward == the reference UpDownCaptioner.forward eval branch (updown_captioner.py:324-366, tied 300-d model,
+    use_cbs, cbs_simple, B=1) with injected eps and reference-built machines: all beams, their log-probs (1e-5: the oracle's
+    decode step restates the cell, it is not the reference's code), and the selected caption."""
+    c = g12_eval_case(ci)
+    out = oracle.eval_forward(c["params"], c["cfg"], c["feats"], c["senti"], c["fsm"], torch.tensor([len(c["constraints"])]),
+                              c["eps"], beam_size=c["beam"], min_constraints_to_satisfy=c["min_sat"])
+    finite = c["lps"] > -1e19
+    assert torch.equal(out["beams"][finite], c["beams"][finite])
+    assert (out["log_probs"][finite] - c["lps"][finite]).abs().max() < 1e-5
+    assert torch.equal(out["predictions"], c["want"])

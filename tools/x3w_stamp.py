@@ -42,6 +42,7 @@ def build():
 
 
 def run(shape, wg):
+    os.environ["SSC_DEBUG"] = "1"
     os.environ["SSC_LIB_PATH"] = os.path.join(OUT, "libssc_hip.so")
     import ctypes as C
     import torch
