@@ -18,12 +18,36 @@ def _hipcc():
     raise RuntimeError("hipcc not found")
 
 
+STAMP = os.path.join(HERE, ".build_stamp")
+
+
+def source_hash():
+    """sha256 over the compiler flags and every source / header the library is built from (file names + contents): the
+    library is current iff the stamp written next to it by the build that produced it carries this hash AND the library's own
+    sha256 (mtimes are not evidence: a checkout or a copy to another machine resets them)."""
+    import hashlib
+    h = hashlib.sha256(" ".join(FLAGS).replace(HERE, "").replace(os.path.dirname(HERE), "").encode())
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
+    files += sorted(os.path.join(INCLUDE, f) for f in os.listdir(INCLUDE) if f.endswith(".h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
+def _file_hash(path):
+    import hashlib
+    return hashlib.sha256(open(path, "rb").read()).hexdigest()
+
+
 def needs_build():
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(INCLUDE, "ssc.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    try:
+        src, lib = open(STAMP).read().split()
+    except ValueError:
+        return True
+    return src != source_hash() or lib != _file_hash(LIB)
 
 
 def check_staged_loads(verbose=True):
@@ -68,6 +92,8 @@ def build(force=False, verbose=True):
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    with open(STAMP, "w") as f:
+        f.write(source_hash() + " " + _file_hash(LIB) + "\n")
     return LIB
 
 

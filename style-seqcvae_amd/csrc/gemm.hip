@@ -1550,16 +1550,33 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int nslab, 
 typedef void (*gemm_fn)(const KArgs);
 
 // ---- optional in-situ profiling (bench.py roofline leg): hipEvent pair around every GEMM launch ------
+struct ProfMember { int M, N, K, slot_m, slot_k; };   // slot_*: index of the device-side row / k-row count read back behind the launch, or -1
 struct ProfRec {
   hipEvent_t e0, e1;
   int kind, M, N, K, splits;
   double bytes, flops;   // algorithmic: every operand and the result once, 2 M N K - summed over the members of a grouped launch
+  ProfMember mem[8];     // the members' extents; products with device-side row compaction (m_count / k_count) are priced at
+  int nmem;              // collect time on the rows they really processed (true flops, not the nominal T*B extent)
 };
-inline void prof_desc(ProfRec* rec, const ssc_gemm_desc* d) {   // adds one product to a record
-  double K = 0;
+int* g_prof_counts = nullptr;   // pinned host array: one int per compacted extent of a profiled launch
+int g_prof_slots = 0;
+constexpr int PROF_SLOTS = 8192;
+inline int prof_count_slot(const int* dev_count, hipStream_t st) {
+  if (!dev_count || !g_prof_counts || g_prof_slots >= PROF_SLOTS) return -1;
+  const int slot = g_prof_slots++;
+  g_prof_counts[slot] = -1;
+  if (hipMemcpyAsync(&g_prof_counts[slot], dev_count, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
+  return slot;
+}
+inline void prof_desc(ProfRec* rec, const ssc_gemm_desc* d, hipStream_t st) {   // adds one product to a record
+  int K = 0;
   for (int i = 0; i < d->nseg; ++i) K += d->seg[i].K;
-  rec->bytes += 4.0 * (K * d->N + (double)d->M * K + (double)d->M * d->N);
-  rec->flops += 2.0 * d->M * d->N * K;
+  if (rec->nmem < 8) {
+    ProfMember& m = rec->mem[rec->nmem++];
+    m.M = d->M; m.N = d->N; m.K = K;
+    m.slot_m = prof_count_slot(d->m_count, st);
+    m.slot_k = prof_count_slot(d->k_count, st);
+  }
 }
 constexpr int PROF_MAX = 4096;
 ProfRec* g_prof = nullptr;
@@ -1747,11 +1764,11 @@ int launch(const ssc_gemm_desc* d, KArgs& k, int splits, hipStream_t st) {
     ProfRec* rec = nullptr;
     if (g_prof_on && g_prof && g_prof_n < PROF_MAX) {
       rec = &g_prof[g_prof_n++];
-      rec->bytes = rec->flops = 0.0;
+      rec->bytes = rec->flops = 0.0; rec->nmem = 0;
       rec->kind = (d->a_kc ? 0 : 2) + (d->b_kc ? 0 : 1);
       rec->M = d->M; rec->N = d->N; rec->splits = splits; rec->K = 0;
       for (int i = 0; i < d->nseg; ++i) rec->K += d->seg[i].K;
-      prof_desc(rec, d);
+      prof_desc(rec, d, st);
       (void)hipEventRecord(rec->e0, st);
     }
     SSC_TRY(x3w_prepare());
@@ -1767,11 +1784,11 @@ int launch(const ssc_gemm_desc* d, KArgs& k, int splits, hipStream_t st) {
     ProfRec* rec = nullptr;
     if (g_prof_on && g_prof && g_prof_n < PROF_MAX) {
       rec = &g_prof[g_prof_n++];
-      rec->bytes = rec->flops = 0.0;
+      rec->bytes = rec->flops = 0.0; rec->nmem = 0;
       rec->kind = (d->a_kc ? 0 : 2) + (d->b_kc ? 0 : 1);
       rec->M = d->M; rec->N = d->N; rec->splits = splits; rec->K = 0;
       for (int i = 0; i < d->nseg; ++i) rec->K += d->seg[i].K;
-      prof_desc(rec, d);
+      prof_desc(rec, d, st);
       (void)hipEventRecord(rec->e0, st);
     }
     const bool kg = k.karows || k.kbrows;
@@ -1802,10 +1819,10 @@ int launch(const ssc_gemm_desc* d, KArgs& k, int splits, hipStream_t st) {
     ProfRec* rec = nullptr;
     if (g_prof_on && g_prof && g_prof_n < PROF_MAX) {
       rec = &g_prof[g_prof_n++];
-      rec->bytes = rec->flops = 0.0;
+      rec->bytes = rec->flops = 0.0; rec->nmem = 0;
       rec->kind = 0; rec->M = d->M; rec->N = d->N; rec->splits = splits; rec->K = 0;
       for (int i = 0; i < d->nseg; ++i) rec->K += d->seg[i].K;
-      prof_desc(rec, d);
+      prof_desc(rec, d, st);
       (void)hipEventRecord(rec->e0, st);
     }
     if (wide && g_x3_nbuf == 1) SSC_LAUNCH((gemm_x3_kernel<2, 2, 1>), grid, dim3(256), 0, st, k);
@@ -1828,12 +1845,12 @@ int launch(const ssc_gemm_desc* d, KArgs& k, int splits, hipStream_t st) {
   ProfRec* rec = nullptr;
   if (g_prof_on && g_prof && g_prof_n < PROF_MAX) {
     rec = &g_prof[g_prof_n++];
-      rec->bytes = rec->flops = 0.0;
+      rec->bytes = rec->flops = 0.0; rec->nmem = 0;
     rec->kind = (d->a_kc ? 0 : 2) + (d->b_kc ? 0 : 1);  // 0 NT, 1 NN, 3 TN
     rec->M = d->M; rec->N = d->N; rec->splits = splits;
     rec->K = 0;
     for (int i = 0; i < d->nseg; ++i) rec->K += d->seg[i].K;
-      prof_desc(rec, d);
+      prof_desc(rec, d, st);
     (void)hipEventRecord(rec->e0, st);
   }
   SSC_LAUNCH(fn, grid, dim3(256), 0, st, k);
@@ -2018,10 +2035,10 @@ int ssc_gemm_slabs_group(const ssc_gemm_desc* const* d, int n, float* const* reg
   ProfRec* rec = nullptr;
   if (g_prof_on && g_prof && g_prof_n < PROF_MAX) {  // one record for the group
     rec = &g_prof[g_prof_n++];
-      rec->bytes = rec->flops = 0.0;
+      rec->bytes = rec->flops = 0.0; rec->nmem = 0;
     rec->kind = d[0]->b_kc ? 0 : 1;
     rec->M = d[0]->M; rec->N = Nmax; rec->splits = nslab[0]; rec->K = Ksum;   // (N, K: nominal; bytes / flops are exact)
-    for (int i = 0; i < n; ++i) prof_desc(rec, d[i]);
+    for (int i = 0; i < n; ++i) prof_desc(rec, d[i], st);
     (void)hipEventRecord(rec->e0, st);
   }
   if (mid) {
@@ -2077,10 +2094,10 @@ int ssc_gemm_dw_group(const ssc_gemm_desc* const* d, int n, hipStream_t st) {
       ProfRec* rec = nullptr;
       if (g_prof_on && g_prof && g_prof_n < PROF_MAX) {  // one record: 2*K*sum(M_i N_i) flops
         rec = &g_prof[g_prof_n++];
-      rec->bytes = rec->flops = 0.0;
+      rec->bytes = rec->flops = 0.0; rec->nmem = 0;
         rec->kind = 3;
         rec->M = (int)(MN / d[i]->N); rec->N = d[i]->N; rec->splits = 1; rec->K = (int)Ksum;
-        for (int q = i; q < j; ++q) prof_desc(rec, d[q]);
+        for (int q = i; q < j; ++q) prof_desc(rec, d[q], st);
         (void)hipEventRecord(rec->e0, st);
       }
       SSC_LAUNCH(x3w_big_fn(false, false, kg0), dim3(g.first[m]), dim3(x3w_big_threads()), (x3w_lds_bytes<128, 128>()), st, g);
@@ -2145,8 +2162,9 @@ extern "C" int ssc_prof_enable(int on) {
       if (hipEventCreate(&g_prof[i].e0) != hipSuccess || hipEventCreate(&g_prof[i].e1) != hipSuccess) return SSC_EHIP;
     }
   }
+  if (on && !g_prof_counts && hipHostMalloc((void**)&g_prof_counts, PROF_SLOTS * sizeof(int), hipHostMallocDefault) != hipSuccess) return SSC_EHIP;
   g_prof_on = on != 0;
-  if (on) g_prof_n = 0;
+  if (on) { g_prof_n = 0; g_prof_slots = 0; }
   return SSC_OK;
 }
 
@@ -2159,10 +2177,20 @@ extern "C" int ssc_prof_collect(float* out, int max_records) {
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, g_prof[i].e0, g_prof[i].e1);
     float* o = out + (size_t)i * 8;
+    g_prof[i].bytes = g_prof[i].flops = 0.0;
+    for (int q = 0; q < g_prof[i].nmem; ++q) {   // true extents: rows / k-rows past the device-side count are never touched
+      const ProfMember& m = g_prof[i].mem[q];
+      double M = m.M, K = m.K;
+      if (m.slot_m >= 0 && g_prof_counts[m.slot_m] >= 0 && g_prof_counts[m.slot_m] < m.M) M = g_prof_counts[m.slot_m];
+      if (m.slot_k >= 0 && g_prof_counts[m.slot_k] >= 0 && g_prof_counts[m.slot_k] < m.K) K = g_prof_counts[m.slot_k];
+      g_prof[i].bytes += 4.0 * (K * m.N + M * K + M * m.N);
+      g_prof[i].flops += 2.0 * M * m.N * K;
+    }
     o[0] = (float)g_prof[i].kind; o[1] = (float)g_prof[i].M; o[2] = (float)g_prof[i].N; o[3] = (float)g_prof[i].K;
     o[4] = (float)g_prof[i].splits; o[5] = ms; o[6] = (float)g_prof[i].bytes; o[7] = (float)g_prof[i].flops;
   }
   g_prof_n = 0;
+  g_prof_slots = 0;
   return n;
 }
 
