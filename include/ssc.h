@@ -36,7 +36,7 @@ extern "C" {
 
 #define SSC_MAX_SEG 6
 
-int ssc_version(void);              /* ABI version (this header: 1) */
+int ssc_version(void);              /* ABI version (this header: 2) */
 int ssc_last_hip_error(void);       /* last hipError_t observed by this thread */
 const char* ssc_arch(void);         /* "gfx950" */
 
@@ -182,12 +182,23 @@ int ssc_attn_fwd(const float* q, int ldq, const float* pv, const float* wa, cons
  * the grounded style prior of SENTIMENT_VAE = 2 (updown_cell.py:160-163: per-region attribute means obj_atts, D = 150). */
 int ssc_attn_pool(const float* alpha, const float* x, int G, int R, int D, int rows_per_image, float* out, int ldo,
                   void* stream);
+/* ssc_attn_fwd that also pools a second per-region tensor with the same weights, in the same launch:
+ *   pool[g, :D] = sum_r alpha[g,r] obj[img(g),r,:D]   (obj (nimg,R,D); pool (G, ldpool), columns D..ldpool-1 set to 0) */
+int ssc_attn_fwd_pool(const float* q, int ldq, const float* pv, const float* wa, const float* mask, const float* feats,
+                      int G, int R, int A, int F, int rows_per_image, float* logits, float* alpha, float* att, int ldatt,
+                      const float* obj, int D, float* pool, int ldpool, void* stream);
 
 /* Attention backward: datt (G,F) -> dq (G,A), dpv_acc (G,R,A) += dpre,
  * dwa_acc (G,A) += sum_r dl_r u_r (caller sums over G at the end).  Training only (rows_per_image=1). */
 int ssc_attn_bwd(const float* datt, int lddatt, const float* q, int ldq, const float* pv, const float* wa,
                  const float* alpha, const float* feats, int G, int R, int A, int F, float* dq, int lddq,
                  float* dpv_acc, float* dwa_acc, float* scratch_dalpha, void* stream);
+/* The same when the attention weights also pooled obj (ssc_attn_fwd_pool): dalpha[g,r] += (dpool_a[g,:D] + dpool_b[g,:D]) . obj[g,r,:D]
+ * (two addends of the pooled tensor's gradient, e.g. the LSTM input gradients and the KL term; dpool_b may be 0). */
+int ssc_attn_bwd_pool(const float* datt, int lddatt, const float* q, int ldq, const float* pv, const float* wa,
+                      const float* alpha, const float* feats, int G, int R, int A, int F, float* dq, int lddq,
+                      float* dpv_acc, float* dwa_acc, float* scratch_dalpha, const float* obj, int D, const float* dpool_a,
+                      int lddpa, const float* dpool_b, int lddpb, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Latent head epilogue: fc_mean / fc_log_var bias add, reparameterised sample and closed-form KL
@@ -206,6 +217,8 @@ typedef struct {
   const float* w;               /* (B) step weights w_bt */
   float* mu; float* lv; float* z; int ldz; /* mu, lv, z: (B, ldz) */
   float* kld_acc;               /* (B) */
+  const float* pm; int ldpm;    /* optional per-row, per-dimension prior mean (B, ldpm) instead of pm_scale*sent: SENTIMENT_VAE = 2,
+                                 * the attention-pooled attribute means of the step (updown_cell.py:160-163; kld_mode 1) */
 } ssc_latent_fwd_desc;
 int ssc_latent_fwd(const ssc_latent_fwd_desc* d, void* stream);
 
@@ -223,6 +236,8 @@ typedef struct {
   const float* w; const float* gk; /* (B) step weights, (B) upstream grad of kld_b */
   float* dmulv; int lddmulv;
   int nslab; size_t slab_stride; /* nslab > 1: dz is the first of nslab split-K slabs ((B, lddz) each) to be summed */
+  const float* pm; int ldpm;     /* optional per-element prior mean (see ssc_latent_fwd_desc) ... */
+  float* dpm; int lddpm;         /* ... and its gradient from the KL term, WRITTEN: dpm = -k (mu - pm) / (prior_var + 1e-5) */
 } ssc_latent_bwd_desc;
 int ssc_latent_bwd(const ssc_latent_bwd_desc* d, void* stream);
 
@@ -272,9 +287,11 @@ int ssc_sgd_step(float* p, const float* g, float* buf, size_t n, const float* sq
  * ---------------------------------------------------------------------------------------------- */
 typedef struct {
   int V, E, H, A, F, Z;
-  int S;            /* sentiment columns on the language LSTMs: 0 or 1 (updown_cell.py:47-81) */
+  int S;            /* conditioning columns on the language LSTMs (updown_cell.py:47-81): 0, 1 (the sentiment column) or, with
+                     * kld_mode 2, D = 150 (SENTIMENT_VAE = 2: the attention-pooled attribute means; requires Z == S) */
   int tied;         /* 1: frozen tied embedding + Linear/Tanh projection (updown_captioner.py:112-119) */
-  int kld_mode;     /* 0: SENTIMENT_VAE==0 formula; 1: otherwise (updown_captioner.py:298-303) */
+  int kld_mode;     /* 0: SENTIMENT_VAE==0 formula; 1: otherwise (updown_captioner.py:298-303); 2: the formula of 1 with the
+                     * prior mean of step t = sum_r alpha_tr obj_atts_r (SENTIMENT_VAE = 2, updown_cell.py:160-163) */
   float pm_scale;   /* prior_mean = pm_scale * sentiment (0 for SENTIMENT_VAE 0 / SIMPLE_VAE) */
   float prior_var;  /* PRIOR_STD^2 */
   int pad, boundary;
@@ -311,6 +328,7 @@ typedef struct {
   const int64_t* caps;         /* (B,L) 0-padded, no boundary tokens */
   const float* sentiment;      /* (B) (ignored when cfg.S==0 and pm_scale==0) */
   const float* eps;            /* (T,B,Z) standard normal noise, ld Z */
+  const float* obj_atts;       /* (B,R,S) per-region attribute means; kld_mode 2 only (else ignored, may be 0) */
 } ssc_batch;
 
 size_t ssc_train_workspace_bytes(const ssc_model_cfg* cfg, int B, int R, int L);
@@ -337,6 +355,23 @@ int ssc_train_bwd_phases(const ssc_model_cfg* cfg, const ssc_params* p, const ss
  * (each (T+1,B,H), index 0 = initial zeros), 6: alpha (T,B,R), 7: mu (T,B,Zp), 8: lv (T,B,Zp), 9: logits (T*B,V),
  * 10: tokens (L+2,B) int64, 11: att (T,B,F).  Returns pointer into the workspace (and its ld) or 0. */
 void* ssc_train_workspace_view(const ssc_model_cfg* cfg, int B, int R, int L, void* workspace, int which, int* ld);
+
+/* ------------------------------------------------------------------------------------------------
+ * Data-parallel gradient exchange without RCCL: direct reduce-scatter + all-gather over peer-mapped buffers (hipIpc), all
+ * xGMI links of a GPU busy at once (replaces nn.DataParallel's reduce-add, var_updown/scripts/train.py:123-124).
+ * buf[j] / flags[j]: rank j's flat fp32 buffer and its flag block (3*SSC_XGMI_MAX_RANKS uint32, zero-initialised) as mapped in
+ * THIS process (entry `rank` = the local ones).  ssc_xgmi_allreduce enqueues, on `stream`, the in-place sum over all ranks of
+ * floats [lo, hi) (multiples of 4): every rank calls it with the same (lo, hi, seq), seq strictly increasing from call to call.
+ * Waits are bounded by `timeout` polls (0 = default); a rank that gives up writes a non-zero stage number to *err (device int).
+ * ---------------------------------------------------------------------------------------------- */
+#define SSC_XGMI_MAX_RANKS 8
+typedef struct {
+  int world, rank;
+  float* buf[SSC_XGMI_MAX_RANKS];
+  unsigned* flags[SSC_XGMI_MAX_RANKS];
+} ssc_xgmi_comm;
+int ssc_xgmi_enable_peer(int peer_device);   /* hipDeviceEnablePeerAccess from the current device (idempotent) */
+int ssc_xgmi_allreduce(const ssc_xgmi_comm* c, size_t lo, size_t hi, unsigned seq, unsigned timeout, int* err, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Eval-mode decode step (UpDownCaptioner._decode_step with training=False, updown_captioner.py:371-455;

@@ -86,7 +86,9 @@ class OracleConfig:
             return 0
         if self.sentiment_vae == 1:
             return 1
-        raise NotImplementedError("SENTIMENT_VAE=2 is out of parity scope (SURVEY §8(f)-3)")
+        if self.sentiment_vae == 2:
+            return 150  # the attention-pooled attribute means c (updown_cell.py:62-69: hard-coded 150; z_space must equal it)
+        raise NotImplementedError(f"SENTIMENT_VAE={self.sentiment_vae}")
 
 
 # --------------------------------------------------------------------------- #
@@ -181,11 +183,14 @@ def zero_states(B: int, H: int, like: torch.Tensor) -> Dict[str, torch.Tensor]:
 
 
 def cell_step(params, cfg: OracleConfig, feats, emb, states, training, sentiment, prior_mean, prior_var, eps,
-              cache=None):
+              cache=None, obj_atts=None, return_prior=False):
     """One ``UpDownCell.forward`` (var_updown/var_updown/modules/updown_cell.py:86-231).
 
     ``cache`` (dict) carries the per-sequence terms the reference lru-caches
-    (avg, mask, pv).  Returns (h_dec, states, mean, log_var, alpha).
+    (avg, mask, pv).  Returns (h_dec, states, mean, log_var, alpha)
+    (+ the step's prior mean with ``return_prior``: for SENTIMENT_VAE=2 the
+    attention-pooled ``obj_atts`` (B,R,150), :160-163, which also conditions both
+    language LSTMs, :185-188,219-222).
     """
     B = feats.size(0)
     if cache is None:
@@ -205,10 +210,12 @@ def cell_step(params, cfg: OracleConfig, feats, emb, states, training, sentiment
     alpha, cache["pv"] = butd_attention(params, states["h1"], feats, mask, cache.get("pv"))  # :151
     att = torch.sum(alpha.unsqueeze(-1) * feats, dim=1)  # :156-158
 
+    if cfg.sentiment_vae == 2:
+        prior_mean = torch.sum(alpha.unsqueeze(-1) * obj_atts, dim=1)  # :160-163
     if cfg.simple_vae:
         prior_mean = torch.zeros_like(prior_mean)  # :165-166
     s = cfg.senti_cols
-    extra = [sentiment] if s == 1 else []
+    extra = [sentiment] if s == 1 else ([prior_mean] if s > 1 else [])  # latent_embedding == "glove": c = prior_mean (:169-170)
     if training:  # :176-198
         x_e = torch.cat([att, states["h1"], hd_prev] + extra, dim=1)
         states["h_encoder"], states["c_encoder"] = lstm_cell(
@@ -225,6 +232,8 @@ def cell_step(params, cfg: OracleConfig, feats, emb, states, training, sentiment
     states["h_decoder"], states["c_decoder"] = lstm_cell(
         x_d, states["h_decoder"], states["c_decoder"],
         params[P_DEC + "weight_ih"], params[P_DEC + "weight_hh"], params[P_DEC + "bias_ih"], params[P_DEC + "bias_hh"])
+    if return_prior:
+        return states["h_decoder"], states, mean, log_var, alpha, prior_mean
     return states["h_decoder"], states, mean, log_var, alpha
 
 
@@ -242,6 +251,8 @@ def prior_from_sentiment(cfg: OracleConfig, sentiment, B, like):
         prior_mean = like.new_zeros((B, cfg.z_space))
     elif cfg.sentiment_vae == 1:
         prior_mean = sentiment.repeat(1, cfg.z_space) * cfg.senti_prior_multip
+    elif cfg.sentiment_vae == 2:
+        prior_mean = like.new_zeros((B, cfg.z_space))  # :258-260 (replaced by the attention-pooled obj_atts in every cell step)
     else:
         raise NotImplementedError
     prior_var = (torch.ones_like(prior_mean) * cfg.prior_std).pow(2)
@@ -261,7 +272,7 @@ def embed(params, cfg: OracleConfig, tokens):
 
 
 def decode_step(params, cfg: OracleConfig, feats, tokens, states, training, sentiment, prior_mean, prior_var, eps,
-                cache=None):
+                cache=None, obj_atts=None, return_prior=False):
     """``UpDownCaptioner._decode_step`` (updown_captioner.py:371-455).
 
     In eval mode the caller passes ``feats`` already expanded to one row per
@@ -269,17 +280,22 @@ def decode_step(params, cfg: OracleConfig, feats, tokens, states, training, sent
     Returns (logits | log_probs, states, mean, log_var, alpha).
     """
     emb = embed(params, cfg, tokens)
-    h_dec, states, mean, log_var, alpha = cell_step(
-        params, cfg, feats, emb, states, training, sentiment, prior_mean, prior_var, eps, cache)
+    h_dec, states, mean, log_var, alpha, pm = cell_step(
+        params, cfg, feats, emb, states, training, sentiment, prior_mean, prior_var, eps, cache, obj_atts, True)
     logits = output_logits(params, cfg, h_dec)
     out = logits if training else torch.log_softmax(logits, dim=1)
+    if return_prior:
+        return out, states, mean, log_var, alpha, pm
     return out, states, mean, log_var, alpha
 
 
-def train_forward(params, cfg: OracleConfig, feats, caption_tokens, sentiment, eps, return_steps=False):
+def train_forward(params, cfg: OracleConfig, feats, caption_tokens, sentiment, eps, return_steps=False, obj_atts=None):
     """Training branch of ``UpDownCaptioner.forward`` (updown_captioner.py:228-323).
 
     Returns ``{"loss": (B,), "kld": (B,)}`` (+ per-step intermediates).
+    ``obj_atts`` (B,R,150): per-region attribute means, SENTIMENT_VAE=2 only (what
+    ``translate_obj_atts2obj_means`` :509-532 hands to the cell; the KL term uses the
+    prior mean the cell RETURNS, :287-303).
     """
     B = feats.size(0)
     prior_mean, prior_var = prior_from_sentiment(cfg, sentiment, B, feats)
@@ -290,14 +306,14 @@ def train_forward(params, cfg: OracleConfig, feats, caption_tokens, sentiment, e
     states, cache = None, {}
     step_logits, step_klds, steps = [], [], []
     for t in range(T):
-        logits, states, mean, log_var, alpha = decode_step(
-            params, cfg, feats, tokens[:, t], states, True, sentiment, prior_mean, prior_var, eps[t], cache)
-        pm = torch.zeros_like(prior_mean) if cfg.simple_vae else prior_mean
+        logits, states, mean, log_var, alpha, prior_mean = decode_step(
+            params, cfg, feats, tokens[:, t], states, True, sentiment, prior_mean, prior_var, eps[t], cache, obj_atts, True)
+        pm = prior_mean
         step_klds.append(kld_step(cfg, mean, log_var, pm, prior_var).unsqueeze(1))
         step_logits.append(logits.unsqueeze(1))
         if return_steps:
             steps.append({**{k: v for k, v in states.items()}, "alpha": alpha, "mean": mean, "log_var": log_var,
-                          "logits": logits})
+                          "logits": logits, "prior_mean": pm})
     logits = torch.cat(step_logits, 1)
     klds = torch.cat(step_klds, 1) * tokens_mask[:, 1:].float()
     tmask = tokens_mask[:, 1:].contiguous()

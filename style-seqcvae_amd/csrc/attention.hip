@@ -148,14 +148,19 @@ constexpr int MAXR_LANE = 4;  // R <= 256
 // One wave per (row, 256-float feature chunk).  (A four-wave form - regions split over the waves of a 256-thread workgroup,
 // partial sums through LDS - was measured in round 2: no gain at the train shape, 6.4 us either way, and 93 vs 60 us at the
 // decode shape, where the kernel is bound by L2 bandwidth, not latency.)
+// Chunks past the F/256 feature chunks (present only when `obj` is given) pool a second per-region tensor obj (nimg,R,D) with the
+// same weights: pool[g,:D] = sum_r alpha_r obj_r, the grounded style prior / LSTM conditioning of SENTIMENT_VAE = 2
+// (updown_cell.py:160-163); its pad columns D..ldpool-1 are written as zeros (they are K columns of a gate product).
 __global__ __launch_bounds__(64) void attn_apply_kernel(const float* __restrict__ logits, const float* __restrict__ mask,
                                                         const float* __restrict__ feats, int G, int R, int F,
                                                         int rows_per_image, float* __restrict__ alpha_out,
-                                                        float* __restrict__ att, int ldatt) {
+                                                        float* __restrict__ att, int ldatt, const float* __restrict__ obj, int D,
+                                                        float* __restrict__ pool, int ldpool) {
   __shared__ float sa[64 * MAXR_LANE];
   int g = blockIdx.y, chunk = blockIdx.x;
   int lane = threadIdx.x;
   int img = g / rows_per_image;
+  const int fchunks = (F + 255) / 256;
   float al[MAXR_LANE];
   wave_masked_softmax<MAXR_LANE>(logits + (size_t)g * R, mask + (size_t)img * R, R, lane, al);
 #pragma unroll
@@ -167,6 +172,19 @@ __global__ __launch_bounds__(64) void attn_apply_kernel(const float* __restrict_
     }
   }
   __syncthreads();
+  if (chunk >= fchunks) {   // pooled obj columns (rows of D floats: no 16-byte alignment to rely on)
+    const float* op = obj + (size_t)img * R * D;
+    for (int k = 0; k < 4; ++k) {
+      const int dd = (chunk - fchunks) * 256 + k * 64 + lane;
+      if (dd < ldpool) {
+        float acc = 0.f;
+        if (dd < D)
+          for (int r = 0; r < R; ++r) acc += sa[r] * op[(size_t)r * D + dd];
+        pool[(size_t)g * ldpool + dd] = acc;
+      }
+    }
+    return;
+  }
   const float* fp = feats + (size_t)img * R * F;
   int f = chunk * 256 + lane * 4;
   if (((F & 3) == 0) && ssc_aligned16_dev(fp) && ((ldatt & 3) == 0) && ssc_aligned16_dev(att)) {
@@ -210,9 +228,12 @@ __global__ void attn_pool_kernel(const float* __restrict__ alpha, const float* _
 
 // ---- backward ---------------------------------------------------------------------------------
 // dalpha[g,r] = datt[g,:] . feats[g,r,:]
+// (+ with obj: dalpha[g,r] += (dpa[g,:D] + dpb[g,:D]) . obj[g,r,:D] - the weights also pooled obj, see attn_apply_kernel)
 __global__ __launch_bounds__(256) void attn_dalpha_kernel(const float* __restrict__ datt, int lddatt,
                                                           const float* __restrict__ feats, int G, int R, int F,
-                                                          float* __restrict__ dalpha) {
+                                                          float* __restrict__ dalpha, const float* __restrict__ obj, int D,
+                                                          const float* __restrict__ dpa, int lddpa,
+                                                          const float* __restrict__ dpb, int lddpb) {
   int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
   int lane = threadIdx.x & 63;
   if (wid >= G * R) return;
@@ -228,6 +249,10 @@ __global__ __launch_bounds__(256) void attn_dalpha_kernel(const float* __restric
     }
   } else {
     for (int f = lane; f < F; f += 64) s += dp[f] * fp[f];
+  }
+  if (obj) {
+    const float* op = obj + (size_t)wid * D;
+    for (int k = lane; k < D; k += 64) s += (dpa[(size_t)g * lddpa + k] + (dpb ? dpb[(size_t)g * lddpb + k] : 0.f)) * op[k];
   }
   s = ssc_wave_sum(s);
   if (lane == 0) dalpha[wid] = s;
@@ -345,7 +370,20 @@ extern "C" int ssc_attn_fwd(const float* q, int ldq, const float* pv, const floa
   if (R > 64 * MAXR_LANE) return SSC_EINVAL;
   SSC_TRY(ssc_attn_logits(q, ldq, pv, wa, G, R, A, rows_per_image, logits, stream));
   SSC_LAUNCH(attn_apply_kernel, dim3(ssc_cdiv(F, 256), G), dim3(64), 0, (hipStream_t)stream, logits, mask, feats,
-                     G, R, F, rows_per_image, alpha, att, ldatt);
+                     G, R, F, rows_per_image, alpha, att, ldatt, (const float*)nullptr, 0, (float*)nullptr, 0);
+  SSC_CHECK_LAUNCH();
+  return SSC_OK;
+}
+
+extern "C" int ssc_attn_fwd_pool(const float* q, int ldq, const float* pv, const float* wa, const float* mask,
+                                 const float* feats, int G, int R, int A, int F, int rows_per_image, float* logits,
+                                 float* alpha, float* att, int ldatt, const float* obj, int D, float* pool, int ldpool,
+                                 void* stream) {
+  if (!mask || !feats || !alpha || !att || !logits || F <= 0 || ldatt < F) return SSC_EINVAL;
+  if (!obj || !pool || D <= 0 || ldpool < D || R > 64 * MAXR_LANE) return SSC_EINVAL;
+  SSC_TRY(ssc_attn_logits(q, ldq, pv, wa, G, R, A, rows_per_image, logits, stream));
+  SSC_LAUNCH(attn_apply_kernel, dim3(ssc_cdiv(F, 256) + ssc_cdiv(ldpool, 256), G), dim3(64), 0, (hipStream_t)stream, logits, mask,
+             feats, G, R, F, rows_per_image, alpha, att, ldatt, obj, D, pool, ldpool);
   SSC_CHECK_LAUNCH();
   return SSC_OK;
 }
@@ -362,14 +400,16 @@ extern "C" int ssc_attn_pool(const float* alpha, const float* x, int G, int R, i
 // internal: attention forward with q given as split-K slabs ((G,A) each, ld A); writes the reduced q to q_out (ld ldqo)
 int ssc_attn_fwd_qslabs(const float* qslabs, int nslab, size_t slab_stride, float* q_out, int ldqo, const float* pv,
                         const float* wa, const float* mask, const float* feats, int G, int R, int A, int F,
-                        int rows_per_image, float* logits, float* alpha, float* att, int ldatt, hipStream_t st) {
+                        int rows_per_image, float* logits, float* alpha, float* att, int ldatt, hipStream_t st,
+                        const float* obj, int D, float* pool, int ldpool) {
   if (!qslabs || nslab < 1 || !q_out || !pv || !wa || !mask || !feats || !alpha || !att || !logits) return SSC_EINVAL;
+  if (obj && (!pool || D <= 0 || ldpool < D)) return SSC_EINVAL;
   if (G <= 0 || R <= 0 || A <= 0 || A > ATTN_MAXA || F <= 0 || ldatt < F || ldqo < A || R > 64 * MAXR_LANE) return SSC_EINVAL;
   SSC_LAUNCH(attn_logits_kernel, dim3(G * ssc_cdiv(R, ATTN_RG)), dim3(256), 0, st, qslabs, A, nslab, slab_stride, q_out,
                      ldqo, pv, wa, G, R, A, rows_per_image, logits);
   SSC_CHECK_LAUNCH();
-  SSC_LAUNCH(attn_apply_kernel, dim3(ssc_cdiv(F, 256), G), dim3(64), 0, st, logits, mask, feats, G, R, F,
-                     rows_per_image, alpha, att, ldatt);
+  SSC_LAUNCH(attn_apply_kernel, dim3(ssc_cdiv(F, 256) + (obj ? ssc_cdiv(ldpool, 256) : 0), G), dim3(64), 0, st, logits, mask, feats,
+             G, R, F, rows_per_image, alpha, att, ldatt, obj, D, pool, ldpool);
   SSC_CHECK_LAUNCH();
   return SSC_OK;
 }
@@ -377,10 +417,19 @@ int ssc_attn_fwd_qslabs(const float* qslabs, int nslab, size_t slab_stride, floa
 extern "C" int ssc_attn_bwd(const float* datt, int lddatt, const float* q, int ldq, const float* pv, const float* wa,
                             const float* alpha, const float* feats, int G, int R, int A, int F, float* dq, int lddq,
                             float* dpv_acc, float* dwa_acc, float* scratch_dalpha, void* stream) {
+  return ssc_attn_bwd_pool(datt, lddatt, q, ldq, pv, wa, alpha, feats, G, R, A, F, dq, lddq, dpv_acc, dwa_acc, scratch_dalpha,
+                           nullptr, 0, nullptr, 0, nullptr, 0, stream);
+}
+
+extern "C" int ssc_attn_bwd_pool(const float* datt, int lddatt, const float* q, int ldq, const float* pv, const float* wa,
+                                 const float* alpha, const float* feats, int G, int R, int A, int F, float* dq, int lddq,
+                                 float* dpv_acc, float* dwa_acc, float* scratch_dalpha, const float* obj, int D,
+                                 const float* dpool_a, int lddpa, const float* dpool_b, int lddpb, void* stream) {
   if (!datt || !q || !pv || !wa || !alpha || !feats || !dq || !dpv_acc || !dwa_acc || !scratch_dalpha) return SSC_EINVAL;
   if (G <= 0 || R <= 0 || A <= 0 || F <= 0 || R > 64 * MAXR_LANE || lddatt < F || ldq < A || lddq < A) return SSC_EINVAL;
+  if (obj && (!dpool_a || D <= 0 || lddpa < D || (dpool_b && lddpb < D))) return SSC_EINVAL;
   SSC_LAUNCH(attn_dalpha_kernel, dim3(ssc_cdiv(G * R, 4)), dim3(256), 0, (hipStream_t)stream, datt, lddatt, feats,
-                     G, R, F, scratch_dalpha);
+                     G, R, F, scratch_dalpha, obj, D, dpool_a, lddpa, dpool_b, lddpb);
   SSC_CHECK_LAUNCH();
   SSC_LAUNCH(attn_bwd_apply_kernel, dim3(ssc_cdiv(A, 256), G), dim3(256), 0, (hipStream_t)stream, q, ldq, pv, wa,
                      alpha, scratch_dalpha, G, R, A, dq, lddq, dpv_acc, dwa_acc);

@@ -1,0 +1,214 @@
+// Direct all-reduce of a flat fp32 gradient range over peer-mapped buffers (hipIpc), for the data-parallel train step:
+// one process per GPU, every rank's flat gradient buffer and a small flag block are mapped into every other rank's address
+// space; a rank reads its peers' memory straight over xGMI.
+//
+// Why: the reference's only multi-GPU path is nn.DataParallel's reduce-add to device 0
+// (var_updown/scripts/train.py:123-124).  Here the exchange is one sum over 446 MB of gradients per step.  xGMI is
+// point-to-point (7 links per GPU): a ring moves 2 (N-1)/N S over ONE link per direction (~5 ms at C2), a direct
+// reduce-scatter + all-gather uses all 7 links at once (2 S / N per link: ~0.7 ms).  This file is that direct form; RCCL
+// (torch.distributed "nccl") stays the reference result it is checked against at start-up (ssc_runtime/xgmi.py).
+//
+//   reduce-scatter: rank r sums shard r of every rank's buffer (fixed rank order 0..W-1) in place into its own shard r
+//   all-gather:     rank r copies the reduced shard j from rank j's buffer into its own, for every j != r
+// Shards are disjoint, so both phases work in place: in phase 1 rank r writes only its shard r, which no peer reads in phase 1;
+// in phase 2 it writes the shards j != r, which no peer reads in phase 2.
+//
+// Cross-process ordering uses monotonic sequence numbers in the flag blocks, written by a one-workgroup SIGNAL kernel (system
+// scope release after the stream's earlier kernels have completed) and awaited by a one-workgroup WAIT kernel: no data kernel
+// ever spins, so a waiting rank occupies one wave and can never keep a peer's kernels off the device (two ranks may share one
+// GPU in tests).  Every wait is bounded: after `timeout` polls it raises the error word and returns, so the grid always drains.
+#include "ssc_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct Peers {
+  const float* src[SSC_XGMI_MAX_RANKS];
+  int world, rank;
+};
+
+__global__ void xgmi_signal_kernel(ssc_xgmi_comm c, int stage, unsigned seq) {
+  // everything this stream launched before has completed (kernel boundary); make it visible system-wide, then publish
+  __threadfence_system();
+  const int j = threadIdx.x;
+  if (j < c.world)
+    __hip_atomic_store(c.flags[j] + stage * SSC_XGMI_MAX_RANKS + c.rank, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ void xgmi_wait_kernel(ssc_xgmi_comm c, int stage, unsigned seq, unsigned timeout, int* err) {
+  const int j = threadIdx.x;
+  if (j < c.world) {
+    const unsigned* f = c.flags[c.rank] + stage * SSC_XGMI_MAX_RANKS + j;   // my own flag block: peers write, I poll locally
+    unsigned it = 0;
+    while ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
+      __builtin_amdgcn_s_sleep(32);
+      if (++it >= timeout) {   // a peer never arrived: flag the error and leave (the caller checks it; results are invalid)
+        if (err) atomicExch(err, 1 + stage);
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  __threadfence_system();   // acquire: the data kernels that follow read what the signalling ranks wrote before their release
+}
+
+// 16-byte load that bypasses this device's caches (sc0 sc1 = system scope): a peer's bytes must come from its memory, not from a
+// line an earlier collective left in this L2
+__device__ __forceinline__ void load_sys(f32x4& v, const float* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=&v"(v) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void wait_loads() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// out[i] = sum_j src[j][i], i in [0, n4) float4 units, j in fixed rank order; out may alias src[rank].  W = world size (compile
+// time: W x 2 sixteen-byte loads per thread in flight, no per-rank branches around the hand-issued loads)
+template <int W>
+__global__ __launch_bounds__(256) void xgmi_reduce_kernel(Peers p, float* __restrict__ out, size_t n4) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += 2 * stride) {
+    const size_t i2 = i + stride;
+    const bool two = i2 < n4;
+    const size_t ib = two ? i2 : i;
+    f32x4 a[W], b[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) load_sys(a[j], p.src[j] + 4 * i);
+#pragma unroll
+    for (int j = 0; j < W; ++j) load_sys(b[j], p.src[j] + 4 * ib);
+    wait_loads();
+#pragma unroll
+    for (int j = 0; j < W; ++j) asm volatile("" : "+v"(a[j]), "+v"(b[j])::"memory");
+    f32x4 sa = a[0], sb = b[0];
+#pragma unroll
+    for (int j = 1; j < W; ++j) { sa += a[j]; sb += b[j]; }
+    *reinterpret_cast<f32x4*>(out + 4 * i) = sa;
+    if (two) *reinterpret_cast<f32x4*>(out + 4 * i2) = sb;
+  }
+}
+typedef void (*reduce_fn)(Peers, float*, size_t);
+inline reduce_fn pick_reduce(int W) {
+  switch (W) {
+    case 1: return xgmi_reduce_kernel<1>;
+    case 2: return xgmi_reduce_kernel<2>;
+    case 3: return xgmi_reduce_kernel<3>;
+    case 4: return xgmi_reduce_kernel<4>;
+    case 5: return xgmi_reduce_kernel<5>;
+    case 6: return xgmi_reduce_kernel<6>;
+    case 7: return xgmi_reduce_kernel<7>;
+    default: return xgmi_reduce_kernel<8>;
+  }
+}
+
+struct Gather {
+  const float* src[SSC_XGMI_MAX_RANKS];   // shard j as it lies in rank j's buffer (nullptr for j == rank)
+  float* dst[SSC_XGMI_MAX_RANKS];         // the same shard in the local buffer
+  size_t n4[SSC_XGMI_MAX_RANKS];
+  int world;
+};
+// blockIdx.y = source rank
+__global__ __launch_bounds__(256) void xgmi_gather_kernel(Gather g) {
+  const int j = blockIdx.y;
+  if (j >= g.world || !g.src[j]) return;
+  const float* s = g.src[j];
+  float* d = g.dst[j];
+  const size_t n4 = g.n4[j], stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += 4 * stride) {
+    f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) load_sys(v[u], s + 4 * (i + u * stride < n4 ? i + u * stride : i));
+    wait_loads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(v[u])::"memory");
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (i + u * stride < n4) *reinterpret_cast<f32x4*>(d + 4 * (i + u * stride)) = v[u];
+  }
+}
+
+inline hipStream_t S(void* s) { return (hipStream_t)s; }
+
+int check_comm(const ssc_xgmi_comm* c) {
+  if (!c || c->world < 1 || c->world > SSC_XGMI_MAX_RANKS || c->rank < 0 || c->rank >= c->world) return SSC_EINVAL;
+  for (int j = 0; j < c->world; ++j) {
+    if (!c->buf[j] || !c->flags[j]) return SSC_EINVAL;
+    if (!ssc_aligned16(c->buf[j])) return SSC_EALIGN;
+  }
+  return SSC_OK;
+}
+
+}  // namespace
+
+extern "C" int ssc_xgmi_enable_peer(int peer_device) {
+  hipError_t e = hipDeviceEnablePeerAccess(peer_device, 0);
+  if (e == hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); return SSC_OK; }
+  if (e != hipSuccess) { ssc_tls_hip_error = (int)e; (void)hipGetLastError(); return SSC_EHIP; }
+  return SSC_OK;
+}
+
+// shard j of [lo, hi): floats [lo + j sh, min(hi, lo + (j+1) sh)), sh = ceil((hi - lo) / 4 / world) * 4
+static inline void shard_of(size_t lo, size_t hi, int world, int j, size_t* s_lo, size_t* s_hi) {
+  const size_t n4 = (hi - lo) / 4, sh4 = (n4 + world - 1) / world;
+  size_t a = lo + 4 * sh4 * (size_t)j, b = a + 4 * sh4;
+  if (a > hi) a = hi;
+  if (b > hi) b = hi;
+  *s_lo = a; *s_hi = b;
+}
+
+extern "C" int ssc_xgmi_allreduce(const ssc_xgmi_comm* c, size_t lo, size_t hi, unsigned seq, unsigned timeout, int* err,
+                                  void* stream) {
+  SSC_TRY(check_comm(c));
+  if (hi < lo || (lo & 3) || (hi & 3)) return SSC_EALIGN;   // whole 16-byte units (FlatStore aligns every tensor to 16 bytes)
+  if (hi == lo) return SSC_OK;
+  if (timeout == 0) timeout = 1u << 22;   // ~ seconds of s_sleep(32) polls: a bound, never reached when every rank takes part
+  const int W = c->world, r = c->rank;
+  hipStream_t st = S(stream);
+  // stage 0: every rank's gradients of this range are complete
+  SSC_LAUNCH(xgmi_signal_kernel, dim3(1), dim3(64), 0, st, *c, 0, seq);
+  SSC_CHECK_LAUNCH();
+  SSC_LAUNCH(xgmi_wait_kernel, dim3(1), dim3(64), 0, st, *c, 0, seq, timeout, err);
+  SSC_CHECK_LAUNCH();
+  size_t s_lo, s_hi;
+  shard_of(lo, hi, W, r, &s_lo, &s_hi);
+  if (s_hi > s_lo) {
+    Peers p;
+    p.world = W; p.rank = r;
+    for (int j = 0; j < SSC_XGMI_MAX_RANKS; ++j) p.src[j] = j < W ? c->buf[j] + s_lo : nullptr;
+    const size_t n4 = (s_hi - s_lo) / 4;
+    int grid = (int)((n4 + 511) / 512);
+    if (grid > 1024) grid = 1024;
+    if (grid < 1) grid = 1;
+    SSC_LAUNCH(pick_reduce(W), dim3(grid), dim3(256), 0, st, p, c->buf[r] + s_lo, n4);
+    SSC_CHECK_LAUNCH();
+  }
+  // stage 1: every rank's reduced shard is in its buffer
+  SSC_LAUNCH(xgmi_signal_kernel, dim3(1), dim3(64), 0, st, *c, 1, seq);
+  SSC_CHECK_LAUNCH();
+  SSC_LAUNCH(xgmi_wait_kernel, dim3(1), dim3(64), 0, st, *c, 1, seq, timeout, err);
+  SSC_CHECK_LAUNCH();
+  if (W > 1) {
+    Gather g;
+    g.world = W;
+    size_t most = 0;
+    for (int j = 0; j < SSC_XGMI_MAX_RANKS; ++j) {
+      g.src[j] = nullptr; g.dst[j] = nullptr; g.n4[j] = 0;
+      if (j >= W || j == r) continue;
+      size_t a, b;
+      shard_of(lo, hi, W, j, &a, &b);
+      if (b <= a) continue;
+      g.src[j] = c->buf[j] + a; g.dst[j] = c->buf[r] + a; g.n4[j] = (b - a) / 4;
+      if (g.n4[j] > most) most = g.n4[j];
+    }
+    if (most) {
+      int gx = (int)((most + 1023) / 1024);
+      if (gx > 256) gx = 256;
+      if (gx < 1) gx = 1;
+      SSC_LAUNCH(xgmi_gather_kernel, dim3(gx, W), dim3(256), 0, st, g);
+      SSC_CHECK_LAUNCH();
+    }
+  }
+  // stage 2: every rank has finished reading its peers' shards - the buffers may be overwritten (next backward)
+  SSC_LAUNCH(xgmi_signal_kernel, dim3(1), dim3(64), 0, st, *c, 2, seq);
+  SSC_CHECK_LAUNCH();
+  SSC_LAUNCH(xgmi_wait_kernel, dim3(1), dim3(64), 0, st, *c, 2, seq, timeout, err);
+  SSC_CHECK_LAUNCH();
+  return SSC_OK;
+}

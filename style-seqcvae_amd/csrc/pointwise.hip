@@ -7,7 +7,7 @@
 
 thread_local int ssc_tls_hip_error = 0;
 
-extern "C" int ssc_version(void) { return 1; }
+extern "C" int ssc_version(void) { return 2; }
 extern "C" int ssc_last_hip_error(void) { return ssc_tls_hip_error; }
 extern "C" const char* ssc_arch(void) { return "gfx950"; }
 
@@ -543,7 +543,7 @@ __global__ void latent_fwd_kernel(const ssc_latent_fwd_desc d) {
   int lane = threadIdx.x & 63;
   if (b >= d.B) return;
   const int Z = d.Z;
-  float pm = d.sent ? d.pm_scale * d.sent[b] : 0.f;
+  const float pm_row = d.sent ? d.pm_scale * d.sent[b] : 0.f;
   float pvar = d.prior_var;
   float lpv = logf(pvar);
   float acc = 0.f;
@@ -573,6 +573,7 @@ __global__ void latent_fwd_kernel(const ssc_latent_fwd_desc d) {
     if (d.kld_mode == 0) {
       acc += 1.f + l - m * m - var;
     } else {
+      const float pm = d.pm ? d.pm[(size_t)b * d.ldpm + z] : pm_row;
       float dm = m - pm;
       acc += 1.f + l - lpv - (dm * dm + var) / (pvar + 0.00001f);
     }
@@ -626,7 +627,7 @@ __global__ __launch_bounds__(256) void latent_fwd_wide_kernel(const ssc_latent_f
   float acc = 0.f;
   if (part == 0 && z < Z) {
     for (int p = 1; p < SP; ++p) { m += pm_[p * ZW + zw][lane]; l += pl_[p * ZW + zw][lane]; }
-    const float pm = d.sent ? d.pm_scale * d.sent[b] : 0.f;
+    const float pm = d.pm ? d.pm[(size_t)b * d.ldpm + z] : (d.sent ? d.pm_scale * d.sent[b] : 0.f);
     const float pvar = d.prior_var, lpv = logf(pvar);
     m += d.bmu[z];
     l += d.blv[z];
@@ -676,9 +677,10 @@ __global__ void latent_bwd_kernel(const ssc_latent_bwd_desc d) {
     dmu = dz + k * m;
     dlv = dz * e * 0.5f * sqrtf(var) - 0.5f * k * (1.f - var);
   } else {
-    float pm = d.sent ? d.pm_scale * d.sent[b] : 0.f;
+    float pm = d.pm ? d.pm[(size_t)b * d.ldpm + z] : (d.sent ? d.pm_scale * d.sent[b] : 0.f);
     float den = d.prior_var + 0.00001f;
     dmu = dz + k * (m - pm) / den;
+    if (d.dpm) d.dpm[(size_t)b * d.lddpm + z] = -k * (m - pm) / den;
     dlv = dz * e * 0.5f * sqrtf(var) - 0.5f * k * (1.f - var / den);
   }
   d.dmulv[(size_t)b * d.lddmulv + z] = dmu;

@@ -25,7 +25,9 @@ inline size_t r4(size_t x) { return (x + 3) & ~(size_t)3; }
 struct Layout {
   int B, R, L, T;
   int V, E, H, A, F, Z, S, tied;
-  int Ep, Hp, Ap, Fp, Zp, Vp, H4, XW;  // padded leading dims ; XW = F + 2H
+  int Ep, Hp, Ap, Fp, Zp, Vp, H4, XW;  // padded leading dims ; XW = ld of dx = [datt | dh1 | dhd' | (dc)]
+  int D, Dp, NX;   // D: width of the attention-pooled conditioning c (kld_mode 2: SENTIMENT_VAE = 2, D = S), else 0; NX = columns of dx
+  size_t wc_e, wc_d, pool, dpm;   // D > 0: 16-byte aligned zero-padded copies of the c-blocks of W_ih^enc / W_ih^dec (H4 x Dp), the pooled c of every step (T*B x Dp), the KL term's gradient on the prior mean (B x Dp)
   size_t total = 0;                    // floats
   size_t act;   // int32: [0] = number of (t, b) rows with a real target (w = 1), [4 ...] = their row numbers t*B+b, ascending
   size_t live;  // int32: same layout; rows (t, b) with w = 1 at step t OR ANY LATER step of caption b (see build_active_rows_kernel)
@@ -49,7 +51,13 @@ Layout make_layout(const ssc_model_cfg* c, int B, int R, int L) {
   l.B = B; l.R = R; l.L = L; l.T = L + 1;
   l.V = c->V; l.E = c->E; l.H = c->H; l.A = c->A; l.F = c->F; l.Z = c->Z; l.S = c->S; l.tied = c->tied;
   l.Ep = (int)r4(l.E); l.Hp = (int)r4(l.H); l.Ap = (int)r4(l.A); l.Fp = (int)r4(l.F); l.Zp = (int)r4(l.Z);
-  l.Vp = (int)r4(l.V); l.H4 = 4 * l.H; l.XW = (int)r4(l.F + 2 * l.H);
+  l.Vp = (int)r4(l.V); l.H4 = 4 * l.H;
+  l.D = c->kld_mode == 2 ? c->S : 0; l.Dp = (int)r4(l.D);
+  // with a pooled conditioning block the input-gradient products of the language LSTMs run over the c-block columns too (they
+  // follow the hd' block in W_ih^enc / W_ih^dec), rounded up to 16-byte rows: the row padding of W_ih^enc / columns of the
+  // z-block of W_ih^dec, whose products land in pad columns of dx that nobody reads
+  l.NX = l.D ? (int)r4(l.F + 2 * l.H + l.D) : l.F + 2 * l.H;
+  l.XW = (int)r4(l.NX);
   const size_t T = l.T, TB = T * B, T1B = (T + 1) * (size_t)B;
   l.tok = l.take(2 * (size_t)(L + 2) * B);
   l.w = l.take(TB);
@@ -96,6 +104,8 @@ Layout make_layout(const ssc_model_cfg* c, int B, int R, int L) {
   l.wsum_att = l.take((size_t)l.H4 * l.Hp);   // W_ih^att[:, h1-block] + W_hh^att  (both multiply h1')
   l.wsum_dec = l.take((size_t)l.H4 * l.Hp);   // W_ih^dec[:, hd-block] + W_hh^dec  (both multiply hd')
   l.wz = l.take((size_t)l.H4 * l.Zp);         // 16-B aligned copy of the z-block of W_ih^dec
+  l.wc_e = l.take((size_t)l.H4 * l.Dp); l.wc_d = l.take((size_t)l.H4 * l.Dp);
+  l.pool = l.take(TB * l.Dp); l.dpm = l.take((size_t)B * l.Dp);
   l.logits = l.take(TB * l.Vp);
   l.lse = l.take(2 * TB);
   l.proj = l.take(l.tied ? TB * l.Ep : 0);
@@ -303,8 +313,8 @@ int add2d(const float* a, int lda, const float* b, int ldb, int rows, int cols, 
 struct ViewArgs {
   const float *att_ih, *att_hh, *dec_ih, *dec_hh, *dec_z, *enc_s, *dec_s;   // row-n bases: [n * ld + column offset]
   int ld_att_ih, ld_att_hh, ld_dec_ih, ld_dec_hh, ld_enc_ih;
-  int H, Hp, Z, Zp, S;
-  float *wsum_att, *wsum_dec, *wz, *wcol_e, *wcol_d;
+  int H, Hp, Z, Zp, S, D, Dp;
+  float *wsum_att, *wsum_dec, *wz, *wcol_e, *wcol_d, *wc_e, *wc_d;
 };
 __global__ void weight_views_kernel(const ViewArgs a) {
   const int n = blockIdx.x, tid = threadIdx.x;
@@ -315,9 +325,13 @@ __global__ void weight_views_kernel(const ViewArgs a) {
   // (pad columns Z..Zp-1 are zero: the backward multiplies with all Zp columns so that the product keeps 16-byte rows when Z is
   // no multiple of 4 - the reference's shipped Z_SPACE is 150)
   for (int k = tid; k < a.Zp; k += blockDim.x) a.wz[(size_t)n * a.Zp + k] = k < a.Z ? a.dec_z[(size_t)n * a.ld_dec_ih + k] : 0.f;
-  if (a.S && tid == 0) {
+  if (a.S == 1 && tid == 0) {
     a.wcol_e[n] = a.enc_s[(size_t)n * a.ld_enc_ih];
     a.wcol_d[n] = a.dec_s[(size_t)n * a.ld_dec_ih];
+  }
+  for (int k = tid; k < a.Dp; k += blockDim.x) {   // SENTIMENT_VAE = 2: the 150 conditioning columns, zero-padded to 16-byte rows
+    a.wc_e[(size_t)n * a.Dp + k] = k < a.D ? a.enc_s[(size_t)n * a.ld_enc_ih + k] : 0.f;
+    a.wc_d[(size_t)n * a.Dp + k] = k < a.D ? a.dec_s[(size_t)n * a.ld_dec_ih + k] : 0.f;
   }
 }
 int prepare_weight_views(const Layout& l, const ssc_params* p, float* W, hipStream_t st) {
@@ -327,7 +341,8 @@ int prepare_weight_views(const Layout& l, const ssc_params* p, float* W, hipStre
   a.dec_z = p->dec_w_ih + F + 2 * H + S; a.enc_s = p->enc_w_ih + F + 2 * H; a.dec_s = p->dec_w_ih + F + 2 * H;
   a.ld_att_ih = p->ld_att_w_ih; a.ld_att_hh = p->ld_att_w_hh; a.ld_dec_ih = p->ld_dec_w_ih; a.ld_dec_hh = p->ld_dec_w_hh;
   a.ld_enc_ih = p->ld_enc_w_ih;
-  a.H = H; a.Hp = l.Hp; a.Z = l.Z; a.Zp = l.Zp; a.S = S;
+  a.H = H; a.Hp = l.Hp; a.Z = l.Z; a.Zp = l.Zp; a.S = S; a.D = l.D; a.Dp = l.Dp;
+  a.wc_e = W + l.wc_e; a.wc_d = W + l.wc_d;
   a.wsum_att = W + l.wsum_att; a.wsum_dec = W + l.wsum_dec; a.wz = W + l.wz; a.wcol_e = W + l.wcol_e; a.wcol_d = W + l.wcol_d;
   SSC_LAUNCH(weight_views_kernel, dim3(l.H4), dim3(256), 0, st, a);
   SSC_CHECK_LAUNCH();
@@ -357,10 +372,11 @@ int fill_many(const FillList& f, float v, hipStream_t st) {
 int check_cfg(const ssc_model_cfg* c, const ssc_params* p, const ssc_batch* b) {
   if (!c || !p || !b) return SSC_EINVAL;
   if (c->V <= 1 || c->E <= 0 || c->H <= 0 || c->A <= 0 || c->F <= 0 || c->Z <= 0) return SSC_EINVAL;
-  if (c->S != 0 && c->S != 1) return SSC_EINVAL;
+  if (c->kld_mode < 0 || c->kld_mode > 2) return SSC_EINVAL;
+  if (c->kld_mode == 2 ? (c->S < 2 || c->S != c->Z || !b || !b->obj_atts) : (c->S != 0 && c->S != 1)) return SSC_EINVAL;
   if (b->B <= 0 || b->R <= 0 || b->L <= 0 || b->R > 256) return SSC_EINVAL;
   if (!b->feats || !b->caps || !b->eps) return SSC_EINVAL;
-  if ((c->S || c->pm_scale != 0.f) && !b->sentiment) return SSC_EINVAL;
+  if ((c->S == 1 || c->pm_scale != 0.f) && !b->sentiment) return SSC_EINVAL;
   if (!p->emb || !p->att_w_ih || !p->att_w_hh || !p->att_b_ih || !p->att_b_hh || !p->wq || !p->wv || !p->wa ||
       !p->enc_w_ih || !p->enc_w_hh || !p->enc_b_ih || !p->enc_b_hh || !p->dec_w_ih || !p->dec_w_hh || !p->dec_b_ih ||
       !p->dec_b_hh || !p->fc_mean_w || !p->fc_mean_b || !p->fc_lv_w || !p->fc_lv_b)
@@ -483,6 +499,7 @@ extern "C" int ssc_train_fwd(const ssc_model_cfg* cfg, const ssc_params* p, cons
     float* att = W + l.att + (size_t)t * B * l.Fp;
     float* qt = W + l.q + (size_t)t * B * l.Ap;
     float* zt = W + l.z + (size_t)t * B * l.Zp;
+    float* poolt = l.D ? W + l.pool + (size_t)t * B * l.Dp : nullptr;   // c_t = sum_r alpha_tr obj_atts_r (SENTIMENT_VAE = 2)
     int ns = 0;
     const size_t sG = (size_t)B * H4;   // one gate slab
     int n_ga = 0, n_ge_r = 0, n_gd_r = 0, n_ge_a = 0, n_gd_a = 0;
@@ -520,13 +537,17 @@ extern "C" int ssc_train_fwd(const ssc_model_cfg* cfg, const ssc_params* p, cons
     // inside the logits kernel, which also stores q for the backward pass
     SSC_TRY(gemm_to_slabs(c, W + l.sl_q, l.small_floats, true, true, {{h1n, l.Hp, p->wq, p->ld_wq, H}}, B, A, &ns));
     SSC_TRY(ssc_attn_fwd_qslabs(W + l.sl_q, ns, (size_t)B * A, qt, l.Ap, W + l.pv, p->wa, W + l.mask, bt->feats, B, R, A, F, 1,
-                                W + l.attn_logits, W + l.alpha + (size_t)t * B * R, att, l.Fp, st));
+                                W + l.attn_logits, W + l.alpha + (size_t)t * B * R, att, l.Fp, st,
+                                l.D ? bt->obj_atts : nullptr, l.D, poolt, l.Dp));
     // (iv) the attention-dependent K-segments [att, h1] of the encoder AND decoder products in one launch; their slabs follow
     // the recurrent ones.  x_e = [att, h1, hd', (s)] + he' (updown_cell.py:176-194); x_d = [att, h1, hd', (s), z] (:211-229)
     {
       ssc_gemm_desc d2[2];
-      fill_desc(d2[0], true, true, {{att, l.Fp, p->enc_w_ih, p->ld_enc_w_ih, F}, {h1n, l.Hp, p->enc_w_ih + F, p->ld_enc_w_ih, H}}, B, H4);
-      fill_desc(d2[1], true, true, {{att, l.Fp, p->dec_w_ih, p->ld_dec_w_ih, F}, {h1n, l.Hp, p->dec_w_ih + F, p->ld_dec_w_ih, H}}, B, H4);
+      // (SENTIMENT_VAE = 2: + the attention-pooled conditioning block c, K = Dp against the aligned copies; a segment with K = 0 is dropped)
+      fill_desc(d2[0], true, true, {{att, l.Fp, p->enc_w_ih, p->ld_enc_w_ih, F}, {h1n, l.Hp, p->enc_w_ih + F, p->ld_enc_w_ih, H},
+                                    {poolt, l.Dp, W + l.wc_e, l.Dp, l.Dp}}, B, H4);
+      fill_desc(d2[1], true, true, {{att, l.Fp, p->dec_w_ih, p->ld_dec_w_ih, F}, {h1n, l.Hp, p->dec_w_ih + F, p->ld_dec_w_ih, H},
+                                    {poolt, l.Dp, W + l.wc_d, l.Dp, l.Dp}}, B, H4);
       const ssc_gemm_desc* dp[2] = {&d2[0], &d2[1]};
       float* regions[2] = {W + l.sl_ge + (size_t)n_ge_r * sG, W + l.sl_gd + (size_t)n_gd_r * sG};
       const size_t caps[2] = {l.gate_floats - (size_t)n_ge_r * sG, l.gate_floats - (size_t)n_gd_r * sG};
@@ -543,7 +564,7 @@ extern "C" int ssc_train_fwd(const ssc_model_cfg* cfg, const ssc_params* p, cons
       d.B = B; d.H = H;
       d.slabs = W + l.sl_ge; d.nslab = n_ge_r + n_ge_a; d.slab_stride = sG;
       d.b_ih = p->enc_b_ih; d.b_hh = p->enc_b_hh;
-      if (S) { d.sent = bt->sentiment; d.wcol = W + l.wcol_e; d.ldwcol = 1; }
+      if (S == 1) { d.sent = bt->sentiment; d.wcol = W + l.wcol_e; d.ldwcol = 1; }
       d.c_prev = cep; d.ld_cprev = l.Hp;
       d.gates_out = W + l.gates_e + (size_t)t * B * H4;
       d.c_out = cen; d.ld_cout = l.Hp; d.h_out = hen; d.ld_hout = l.Hp;
@@ -570,6 +591,7 @@ extern "C" int ssc_train_fwd(const ssc_model_cfg* cfg, const ssc_params* p, cons
       d.eps = bt->eps + (size_t)t * B * Z; d.ldeps = Z;
       d.kld_mode = cfg->kld_mode; d.sent = cfg->pm_scale != 0.f ? bt->sentiment : nullptr;
       d.pm_scale = cfg->pm_scale; d.prior_var = cfg->prior_var;
+      if (l.D) { d.pm = poolt; d.ldpm = l.Dp; }   // the prior mean of this step is the pooled c (updown_cell.py:160-163)
       d.w = W + l.w + (size_t)t * B;
       d.mu = W + l.mu + (size_t)t * B * l.Zp; d.lv = W + l.lv + (size_t)t * B * l.Zp; d.z = zt; d.ldz = l.Zp;
       d.kld_acc = kld;
@@ -581,7 +603,7 @@ extern "C" int ssc_train_fwd(const ssc_model_cfg* cfg, const ssc_params* p, cons
       d.B = B; d.H = H;
       d.slabs = W + l.sl_gd; d.nslab = n_gd_r + n_gd_a; d.slab_stride = sG;
       d.b_ih = p->dec_b_ih; d.b_hh = p->dec_b_hh;
-      if (S) { d.sent = bt->sentiment; d.wcol = W + l.wcol_d; d.ldwcol = 1; }
+      if (S == 1) { d.sent = bt->sentiment; d.wcol = W + l.wcol_d; d.ldwcol = 1; }
       d.c_prev = cdp; d.ld_cprev = l.Hp;
       d.gates_out = W + l.gates_d + (size_t)t * B * H4;
       d.c_out = cdn; d.ld_cout = l.Hp; d.h_out = hdn; d.ld_hout = l.Hp;
@@ -734,7 +756,8 @@ static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const s
   int n_gh1 = 0, n_ghd = 0, n_ghd2 = 0, n_ghe = 0;  // slab counts carried from step t+1 (none at t = T-1)
   const bool fc_adjacent_b = (p->fc_lv_w == p->fc_mean_w + (size_t)Z * p->ld_fc_mean_w) && p->ld_fc_lv_w == p->ld_fc_mean_w;
   const size_t sBH = (size_t)B * H;
-  const size_t sBX = (size_t)B * (F + 2 * H);
+  const int NX = l.NX;             // F + 2H (+ the c-block, rounded up to 16-byte rows, with SENTIMENT_VAE = 2)
+  const size_t sBX = (size_t)B * NX;
   // Launch order of one step (every product streams its weight block once; a product is issued as soon as its dG exists and
   // shares a launch with the latency-bound small product of the dependency chain that sits at the same place):
   //   dec cell -> {dz, dGd W_ih^dec[:, :F+2H], dGd W_hh^dec} -> latent -> dhe -> enc cell -> {dGe W_ih^enc[:, :F+2H]} -> sum
@@ -769,7 +792,7 @@ static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const s
     {
       ssc_gemm_desc d3[3];
       fill_desc(d3[0], true, false, {{dgd, H4, W + l.wz, l.Zp, H4}}, B, l.Zp);   // Zp columns (pad columns of wz are zero): 16-byte rows for any Z
-      fill_desc(d3[1], true, false, {{dgd, H4, p->dec_w_ih, p->ld_dec_w_ih, H4}}, B, F + 2 * H);
+      fill_desc(d3[1], true, false, {{dgd, H4, p->dec_w_ih, p->ld_dec_w_ih, H4}}, B, NX);
       fill_desc(d3[2], true, false, {{dgd, H4, p->dec_w_hh, p->ld_dec_w_hh, H4}}, B, H);
       const ssc_gemm_desc* dp[3] = {&d3[0], &d3[1], &d3[2]};
       float* regions[3] = {W + l.sl_dz, c.slabs, W + l.sl_ghd2};
@@ -786,6 +809,7 @@ static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const s
       d.mu = W + l.mu + (size_t)t * B * l.Zp; d.lv = W + l.lv + (size_t)t * B * l.Zp; d.ldz = l.Zp;
       d.kld_mode = cfg->kld_mode; d.sent = cfg->pm_scale != 0.f ? bt->sentiment : nullptr;
       d.pm_scale = cfg->pm_scale; d.prior_var = cfg->prior_var;
+      if (l.D) { d.pm = W + l.pool + (size_t)t * B * l.Dp; d.ldpm = l.Dp; d.dpm = W + l.dpm; d.lddpm = l.Dp; }
       d.w = W + l.w + (size_t)t * B; d.gk = gk;
       d.dmulv = dmulv; d.lddmulv = 2 * Z;
       SSC_TRY(ssc_latent_bwd(&d, st));
@@ -815,7 +839,7 @@ static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const s
     //    launch 2, one sum) and dGe W_hh^enc for step t-1
     {
       ssc_gemm_desc d2[2];
-      fill_desc(d2[0], true, false, {{dge, H4, p->enc_w_ih, p->ld_enc_w_ih, H4}}, B, F + 2 * H);
+      fill_desc(d2[0], true, false, {{dge, H4, p->enc_w_ih, p->ld_enc_w_ih, H4}}, B, NX);
       fill_desc(d2[1], true, false, {{dge, H4, p->enc_w_hh, p->ld_enc_w_hh, H4}}, B, H);
       const ssc_gemm_desc* dp[2] = {&d2[0], &d2[1]};
       float* regions[2] = {c.slabs + (size_t)n_dxd * sBX, W + l.sl_ghe};
@@ -824,10 +848,12 @@ static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const s
       SSC_TRY(ssc_gemm_slabs_group(dp, t > 0 ? 2 : 1, regions, caps, ns2, st));
       n_dxe = ns2[0]; n_ghe = ns2[1];
     }
-    SSC_TRY(ssc_reduce_slabs(c.slabs, n_dxd + n_dxe, sBX, B, F + 2 * H, dx, XW, nullptr, 0, st));
-    // 7. attention backward
-    SSC_TRY(ssc_attn_bwd(dx, XW, W + l.q + (size_t)t * B * l.Ap, l.Ap, W + l.pv, p->wa, W + l.alpha + (size_t)t * B * R,
-                         bt->feats, B, R, A, F, dq, l.Ap, W + l.dpv, W + l.dwa, W + l.dalpha, st));
+    SSC_TRY(ssc_reduce_slabs(c.slabs, n_dxd + n_dxe, sBX, B, NX, dx, XW, nullptr, 0, st));
+    // 7. attention backward (SENTIMENT_VAE = 2: the weights also pooled obj_atts; dc = dx[c block] from both language LSTMs + the
+    //    KL term's gradient on the prior mean)
+    SSC_TRY(ssc_attn_bwd_pool(dx, XW, W + l.q + (size_t)t * B * l.Ap, l.Ap, W + l.pv, p->wa, W + l.alpha + (size_t)t * B * R,
+                              bt->feats, B, R, A, F, dq, l.Ap, W + l.dpv, W + l.dwa, W + l.dalpha, l.D ? bt->obj_atts : nullptr, l.D,
+                              dx + F + 2 * H, XW, W + l.dpm, l.Dp, st));
     // 8-9. attention LSTM: dh1 = dx[h1 block] + g_h1' slabs + dq Wq; the K = A product is formed inside the cell kernel
     //      (ssc_lstm_bwd_x) while its LDS images fit, else it is a split-K product of its own
     {
@@ -867,7 +893,7 @@ static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const s
 
   if (g_loop.on) { (void)hipEventRecord(g_loop.e[3], st); g_loop.bwd = true; }
 
-  if (S) {  // sentiment replicated over time (row = t*B+b) for the rank-1 column gradients
+  if (S == 1) {  // sentiment replicated over time (row = t*B+b) for the rank-1 column gradients
     SSC_LAUNCH(repeat_kernel, dim3(ssc_cdiv(TB, 256)), dim3(256), 0, st, bt->sentiment, B, T, W + l.sent_all);
     SSC_CHECK_LAUNCH();
   }
@@ -935,6 +961,9 @@ static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const s
       SSC_TRY(queue_dw(c, q, dge, H4, hd_prev, l.Hp, TB, H4, H, gw + F + H, ld));
     }
     if (g->enc_w_hh) SSC_TRY(queue_dw(c, q, dge, H4, he_prev, l.Hp, TB, H4, H, g->enc_w_hh, g->ld_enc_w_hh));
+    // c-block (SENTIMENT_VAE = 2): dGe^T C over the padded Dp columns of the pooled history into the forward's aligned copy (free
+    // since the BPTT loop ended); its D real columns are copied into place below
+    if (g->enc_w_ih && l.D) SSC_TRY(queue_dw(c, q, dge, H4, W + l.pool, l.Dp, TB, H4, l.Dp, W + l.wc_e, l.Dp));
     if (g->fc_mean_w && g->fc_lv_w && g->fc_lv_w == g->fc_mean_w + (size_t)Z * g->ld_fc_mean_w && g->ld_fc_lv_w == g->ld_fc_mean_w) {
       // [dW_mu ; dW_lv] = (dmu | dlv)^T h_e as ONE (2Z x H) product: the two gradients are adjacent in the flat store, and 2Z keeps
       // 16-byte rows where Z alone does not (the shipped Z_SPACE = 150 sent the two Z-row products to the scalar kernel)
@@ -948,7 +977,10 @@ static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const s
   // encoder LSTM
   if (g->enc_w_ih) {
     float* gw = g->enc_w_ih; int ld = g->ld_enc_w_ih;
-    if (S) SSC_TRY(ssc_colsum2(dge, H4, TB, H4, W + l.sent_all, gw + F + 2 * H, ld, nullptr, 0, c.slabs, st));
+    if (S == 1) SSC_TRY(ssc_colsum2(dge, H4, TB, H4, W + l.sent_all, gw + F + 2 * H, ld, nullptr, 0, c.slabs, st));
+    if (l.D && hipMemcpy2DAsync(gw + F + 2 * H, (size_t)ld * sizeof(float), W + l.wc_e, (size_t)l.Dp * sizeof(float),
+                                (size_t)l.D * sizeof(float), H4, hipMemcpyDeviceToDevice, st) != hipSuccess)
+      return SSC_EHIP;
   }
   if (g->enc_b_ih && g->enc_b_hh) {
     SSC_TRY(ssc_colsum2(dge, H4, TB, H4, nullptr, g->enc_b_ih, 1, g->enc_b_hh, 0, c.slabs, st));
@@ -976,6 +1008,7 @@ static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const s
       } else {
         SSC_TRY(queue_dw(c, q, dgd, H4, W + l.z, l.Zp, TB, H4, Z, gw + zcol, ld));
       }
+      if (l.D) SSC_TRY(queue_dw(c, q, dgd, H4, W + l.pool, l.Dp, TB, H4, l.Dp, W + l.wc_d, l.Dp));   // c-block, as for the encoder
     } else if (g->dec_w_hh) {
       SSC_TRY(queue_dw(c, q, dgd, H4, hd_prev, l.Hp, TB, H4, H, g->dec_w_hh, g->ld_dec_w_hh));
     }
@@ -989,7 +1022,10 @@ static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const s
   }
   if (g->dec_w_ih) {
     float* gw = g->dec_w_ih; int ld = g->ld_dec_w_ih;
-    if (S) SSC_TRY(ssc_colsum2(dgd, H4, TB, H4, W + l.sent_all, gw + F + 2 * H, ld, nullptr, 0, c.slabs, st));
+    if (S == 1) SSC_TRY(ssc_colsum2(dgd, H4, TB, H4, W + l.sent_all, gw + F + 2 * H, ld, nullptr, 0, c.slabs, st));
+    if (l.D && hipMemcpy2DAsync(gw + F + 2 * H, (size_t)ld * sizeof(float), W + l.wc_d, (size_t)l.Dp * sizeof(float),
+                                (size_t)l.D * sizeof(float), H4, hipMemcpyDeviceToDevice, st) != hipSuccess)
+      return SSC_EHIP;
   }
   if (g->dec_w_hh) {
     // dW_hh^dec = dGd^T HD_prev is the same product as the hd' block of dW_ih^dec

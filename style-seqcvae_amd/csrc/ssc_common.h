@@ -73,7 +73,8 @@ __device__ __forceinline__ float ssc_tanh_fast(float x) {
 int ssc_gemm_slabs(const ssc_gemm_desc* d, int splits, float* slabs, hipStream_t st);  // partial slabs only
 int ssc_attn_fwd_qslabs(const float* qslabs, int nslab, size_t slab_stride, float* q_out, int ldqo, const float* pv,
                         const float* wa, const float* mask, const float* feats, int G, int R, int A, int F,
-                        int rows_per_image, float* logits, float* alpha, float* att, int ldatt, hipStream_t st);
+                        int rows_per_image, float* logits, float* alpha, float* att, int ldatt, hipStream_t st,
+                        const float* obj = nullptr, int D = 0, float* pool = nullptr, int ldpool = 0);
 int ssc_gemm_slabs_auto(const ssc_gemm_desc* d, float* slabs, size_t cap_floats, int* nslab, hipStream_t st);
 // n <= 3 independent minibatch products (M <= 64, same operand layout) in ONE launch, each left as split-K slabs in its
 // own region; falls back to one launch per product when they do not qualify for the 64x256 wave-specialised kernel

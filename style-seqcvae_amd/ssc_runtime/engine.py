@@ -45,9 +45,11 @@ class ModelDims:
     A: int
     F: int
     Z: int
-    S: int = 0            # sentiment columns on the language LSTMs (updown_cell.py:47-81)
+    S: int = 0            # conditioning columns on the language LSTMs (updown_cell.py:47-81): 0, 1 (sentiment) or, with kld_mode 2,
+                          # 150 (SENTIMENT_VAE = 2: attention-pooled attribute means; Z must equal S)
     tied: bool = False    # E in {300,600}: frozen tied embedding (updown_captioner.py:75,112-119)
-    kld_mode: int = 0     # 0: SENTIMENT_VAE == 0 formula, 1 otherwise (updown_captioner.py:298-303)
+    kld_mode: int = 0     # 0: SENTIMENT_VAE == 0 formula, 1 otherwise (updown_captioner.py:298-303), 2: formula 1 with the prior
+                          # mean of each step = the attention-pooled obj_atts (SENTIMENT_VAE = 2, updown_cell.py:160-163)
     pm_scale: float = 0.0  # prior_mean = pm_scale * sentiment
     prior_var: float = 1.0
     pad: int = 0
@@ -218,7 +220,7 @@ class TrainEngine:
             self._ws_key = key
         return self._ws
 
-    def _batch(self, feats, caps, sentiment, eps):
+    def _batch(self, feats, caps, sentiment, eps, obj_atts=None):
         B, R, F = feats.shape
         L = caps.shape[1]
         assert F == self.dims.F and feats.is_contiguous() and caps.is_contiguous() and eps.is_contiguous()
@@ -227,13 +229,18 @@ class TrainEngine:
         sent = None
         if sentiment is not None:
             sent = sentiment.reshape(B).to(torch.float32).contiguous()
+        if self.dims.kld_mode == 2:
+            assert obj_atts is not None and tuple(obj_atts.shape) == (B, R, self.dims.S), "SENTIMENT_VAE = 2 needs obj_atts (B,R,S)"
+            obj_atts = obj_atts.to(torch.float32).contiguous()
+        else:
+            obj_atts = None
         bt = _lib.Batch(B, R, L, feats.data_ptr(), caps.data_ptr(), sent.data_ptr() if sent is not None else None,
-                        eps.data_ptr())
-        return bt, sent
+                        eps.data_ptr(), obj_atts.data_ptr() if obj_atts is not None else None)
+        return bt, (sent, obj_atts)
 
-    def forward(self, feats, caps, sentiment, eps):
-        """-> (loss (B,), kld (B,)); keeps activations for backward()."""
-        bt, sent = self._batch(feats, caps, sentiment, eps)
+    def forward(self, feats, caps, sentiment, eps, obj_atts=None):
+        """-> (loss (B,), kld (B,)); keeps activations for backward().  obj_atts (B,R,S): per-region attribute means, kld_mode 2 only."""
+        bt, sent = self._batch(feats, caps, sentiment, eps, obj_atts)
         ws = self._workspace(bt.B, bt.R, bt.L)
         loss = torch.empty(bt.B, dtype=torch.float32, device=self.device)
         kld = torch.empty(bt.B, dtype=torch.float32, device=self.device)
@@ -434,9 +441,9 @@ class TrainEngine:
         return dp.allreduce_flat(self.grads.flat, group=group, n_buckets=self.dp_buckets)
 
     def train_step(self, feats, caps, sentiment, eps, lr, kld_weight=750.0, momentum=0.9, weight_decay=0.001,
-                   max_norm=12.5, decoder_frozen=False, group=None):
+                   max_norm=12.5, decoder_frozen=False, group=None, obj_atts=None):
         """fwd + bwd + (all-reduce) + clip + SGD: one iteration of train.py:154-176.  Returns (loss, kld) per row."""
-        loss, kld = self.forward(feats, caps, sentiment, eps)
+        loss, kld = self.forward(feats, caps, sentiment, eps, obj_atts)
         B = loss.numel()
         key = (B, float(kld_weight))
         if getattr(self, "_upstream_key", None) != key:   # d(mean loss + mean kld / KLD_WEIGHT) / d(loss_b, kld_b): constant per (B, weight)

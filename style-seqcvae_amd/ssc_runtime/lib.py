@@ -53,14 +53,14 @@ class LatentFwdDesc(C.Structure):
     _fields_ = [("B", C.c_int), ("Z", C.c_int), ("mulv", vp), ("ldmulv", C.c_int), ("nslab", C.c_int),
                 ("slab_stride", C.c_size_t), ("bmu", vp), ("blv", vp), ("eps", vp), ("ldeps", C.c_int),
                 ("kld_mode", C.c_int), ("sent", vp), ("pm_scale", C.c_float), ("prior_var", C.c_float), ("w", vp),
-                ("mu", vp), ("lv", vp), ("z", vp), ("ldz", C.c_int), ("kld_acc", vp)]
+                ("mu", vp), ("lv", vp), ("z", vp), ("ldz", C.c_int), ("kld_acc", vp), ("pm", vp), ("ldpm", C.c_int)]
 
 
 class LatentBwdDesc(C.Structure):
     _fields_ = [("B", C.c_int), ("Z", C.c_int), ("dz", vp), ("lddz", C.c_int), ("eps", vp), ("ldeps", C.c_int),
                 ("mu", vp), ("lv", vp), ("ldz", C.c_int), ("kld_mode", C.c_int), ("sent", vp), ("pm_scale", C.c_float),
                 ("prior_var", C.c_float), ("w", vp), ("gk", vp), ("dmulv", vp), ("lddmulv", C.c_int),
-                ("nslab", C.c_int), ("slab_stride", C.c_size_t)]
+                ("nslab", C.c_int), ("slab_stride", C.c_size_t), ("pm", vp), ("ldpm", C.c_int), ("dpm", vp), ("lddpm", C.c_int)]
 
 
 class ModelCfg(C.Structure):
@@ -92,7 +92,14 @@ class Params(C.Structure):
 
 class Batch(C.Structure):
     _fields_ = [("B", C.c_int), ("R", C.c_int), ("L", C.c_int), ("feats", vp), ("caps", vp), ("sentiment", vp),
-                ("eps", vp)]
+                ("eps", vp), ("obj_atts", vp)]
+
+
+SSC_XGMI_MAX_RANKS = 8
+
+
+class XgmiComm(C.Structure):
+    _fields_ = [("world", C.c_int), ("rank", C.c_int), ("buf", vp * SSC_XGMI_MAX_RANKS), ("flags", vp * SSC_XGMI_MAX_RANKS)]
 
 
 class DecodeStepDesc(C.Structure):
@@ -123,6 +130,8 @@ SYMBOLS = {
     "ssc_attn_logits": (_i, [vp, _i, vp, vp, _i, _i, _i, _i, vp, vp]),
     "ssc_attn_fwd": (_i, [vp, _i, vp, vp, vp, vp, _i, _i, _i, _i, _i, vp, vp, vp, _i, vp]),
     "ssc_attn_pool": (_i, [vp, vp, _i, _i, _i, _i, vp, _i, vp]),
+    "ssc_attn_fwd_pool": (_i, [vp, _i, vp, vp, vp, vp, _i, _i, _i, _i, _i, vp, vp, vp, _i, vp, _i, vp, _i, vp]),
+    "ssc_attn_bwd_pool": (_i, [vp, _i, vp, _i, vp, vp, vp, vp, _i, _i, _i, _i, vp, _i, vp, vp, vp, vp, _i, vp, _i, vp, _i, vp]),
     "ssc_attn_bwd": (_i, [vp, _i, vp, _i, vp, vp, vp, vp, _i, _i, _i, _i, vp, _i, vp, vp, vp, vp]),
     "ssc_latent_fwd": (_i, [C.POINTER(LatentFwdDesc), vp]),
     "ssc_latent_prior_sample": (_i, [vp, _i, vp, _f, _f, _i, _i, vp, _i, vp]),
@@ -144,6 +153,8 @@ SYMBOLS = {
     "ssc_train_bwd_phases": (_i, [C.POINTER(ModelCfg), C.POINTER(Params), C.POINTER(Batch), vp, _sz, vp, vp, C.POINTER(Params),
                                   C.c_uint, vp]),
     "ssc_train_workspace_view": (vp, [C.POINTER(ModelCfg), _i, _i, _i, vp, _i, C.POINTER(C.c_int)]),
+    "ssc_xgmi_enable_peer": (_i, [_i]),
+    "ssc_xgmi_allreduce": (_i, [C.POINTER(XgmiComm), _sz, _sz, C.c_uint, C.c_uint, vp, vp]),
     "ssc_decode_image_bytes": (_sz, [C.POINTER(ModelCfg), _i, _i]),
     "ssc_decode_prepare": (_i, [C.POINTER(ModelCfg), C.POINTER(Params), vp, _i, _i, vp, _sz, vp]),
     "ssc_decode_step_workspace_bytes": (_sz, [C.POINTER(ModelCfg), _i, _i]),

@@ -1,0 +1,121 @@
+"""Direct gradient all-reduce over peer-mapped buffers (hipIpc) - the hand-written fallback SURVEY 8(e) plans for the case that
+RCCL keeps the 446 MB gradient all-reduce on rings: every rank maps every other rank's flat gradient buffer and a flag block into
+its address space, then `ssc_xgmi_allreduce` (csrc/collective.hip) runs reduce-scatter + all-gather as plain HIP kernels that read
+the peers' memory directly, all xGMI links of a GPU at once.  Replaces the reduce-add of nn.DataParallel
+(var_updown/scripts/train.py:123-124); `torch.distributed` (RCCL) stays the reference it is verified against at set-up.
+
+Set-up is collective: every rank of `group` constructs XgmiAllReduce on its own flat buffer.  The handles travel through
+`dist.all_gather_object` (torch.multiprocessing's CUDA-IPC reductions: the owner keeps the memory alive, the peers map it).
+`HSA_ENABLE_IPC_MODE_LEGACY=0` must be in the environment before the first HIP call (dmabuf IPC: this pool's driver has no other).
+"""
+import ctypes as C
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+from . import lib as L
+
+
+class XgmiError(RuntimeError):
+    pass
+
+
+class XgmiAllReduce:
+    def __init__(self, flat: torch.Tensor, group=None, verify: bool = True):
+        if not (flat.is_cuda and flat.dtype == torch.float32 and flat.is_contiguous() and flat.data_ptr() % 16 == 0):
+            raise XgmiError("flat buffer must be a contiguous, 16-byte aligned fp32 CUDA tensor")
+        self.group = group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        if self.world > L.SSC_XGMI_MAX_RANKS:
+            raise XgmiError(f"world size {self.world} > {L.SSC_XGMI_MAX_RANKS}")
+        self.lib = L.load()
+        self.flat = flat
+        self.device = flat.device
+        self.flags = torch.zeros(4 * L.SSC_XGMI_MAX_RANKS, dtype=torch.int32, device=self.device)
+        self.err = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.seq = 0
+        torch.cuda.synchronize(self.device)
+        from torch.multiprocessing.reductions import reduce_tensor
+        mine = (self.device.index, reduce_tensor(flat)[1], reduce_tensor(self.flags)[1])
+        handles = [None] * self.world
+        dist.all_gather_object(handles, mine, group=group)
+        self._peers = []   # keep the mapped tensors alive
+        comm = L.XgmiComm()
+        comm.world, comm.rank = self.world, self.rank
+        from torch.multiprocessing.reductions import rebuild_cuda_tensor
+        for j, (dev_j, h_flat, h_flags) in enumerate(handles):
+            if j == self.rank:
+                comm.buf[j], comm.flags[j] = flat.data_ptr(), self.flags.data_ptr()
+                continue
+            if dev_j != self.device.index:   # a peer GPU: kernels on this device must be allowed to touch its memory
+                with torch.cuda.device(self.device):
+                    self.lib.ssc_xgmi_enable_peer(dev_j)
+            pf, pg = rebuild_cuda_tensor(*h_flat), rebuild_cuda_tensor(*h_flags)
+            if pf.numel() != flat.numel():
+                raise XgmiError("ranks disagree on the buffer size")
+            self._peers.append((pf, pg))
+            comm.buf[j], comm.flags[j] = pf.data_ptr(), pg.data_ptr()
+        self.comm = comm
+        dist.barrier(group=group)   # every rank has mapped every buffer before anyone signals
+        if verify:
+            self.self_test()
+
+    def allreduce(self, lo: int = 0, hi: Optional[int] = None, stream: Optional[torch.cuda.Stream] = None):
+        """Enqueue the in-place sum over all ranks of flat[lo:hi] on `stream` (default: the current stream).  Every rank must
+        issue the same sequence of calls.  lo / hi: multiples of 4 floats."""
+        hi = self.flat.numel() if hi is None else hi
+        if hi == lo:
+            return
+        self.seq += 1
+        st = stream if stream is not None else torch.cuda.current_stream(self.device)
+        self.lib.ssc_xgmi_allreduce(C.byref(self.comm), lo, hi, self.seq, 0, L.ptr(self.err), C.c_void_p(st.cuda_stream))
+
+    def check(self):
+        """Synchronises; raises if any bounded wait of the collectives issued so far gave up (a peer never arrived)."""
+        code = int(self.err.item())
+        if code:
+            raise XgmiError(f"xgmi all-reduce: rank {self.rank} timed out waiting for its peers at stage {code - 1}")
+
+    def self_test(self, n: int = 1 << 16):
+        """A small all-reduce of known per-rank values through the direct path, compared with torch.distributed's result of the
+        same input - exact equality is required (integer-valued floats: no rounding in either).  Uses the head of the buffer and
+        restores it."""
+        n = min(n, self.flat.numel()) & ~3
+        if n == 0:
+            return
+        keep = self.flat[:n].clone()
+        g = torch.Generator(device="cpu").manual_seed(1234 + self.rank)
+        vals = torch.randint(-1000, 1000, (n,), generator=g).float().to(self.device)
+        want = vals.clone()
+        dist.all_reduce(want, op=dist.ReduceOp.SUM, group=self.group)
+        self.flat[:n].copy_(vals)
+        torch.cuda.synchronize(self.device)
+        dist.barrier(group=self.group)
+        self.allreduce(0, n)
+        self.check()
+        ok = torch.equal(self.flat[:n], want)
+        self.flat[:n].copy_(keep)
+        torch.cuda.synchronize(self.device)
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device if dist.get_backend(self.group) == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        if int(flag.item()) != 1:
+            raise XgmiError("xgmi all-reduce self-test: result differs from torch.distributed.all_reduce")
+
+
+def try_create(flat: torch.Tensor, group=None, log=None) -> Optional[XgmiAllReduce]:
+    """XgmiAllReduce, or None (with the reason logged) when the peers cannot be mapped or the self-test fails on ANY rank: the
+    caller then stays on torch.distributed.  The decision is made collectively, so that all ranks take the same path."""
+    obj, why = None, ""
+    try:
+        obj = XgmiAllReduce(flat, group=group, verify=True)
+    except Exception as e:   # noqa: BLE001 - any failure means "use RCCL"
+        why = f"{type(e).__name__}: {e}"
+    ok = torch.tensor([1 if obj is not None else 0], dtype=torch.int32,
+                      device=flat.device if dist.get_backend(group) == "nccl" else "cpu")
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+    if int(ok.item()) != 1:
+        if log:
+            log(f"xgmi all-reduce unavailable ({why or 'a peer failed'}): using torch.distributed")
+        return None
+    return obj

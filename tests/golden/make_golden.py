@@ -684,8 +684,70 @@ def filter_fixture(name="g13_filter"):
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **data)
 
 
+def sv2_train_fixture(name="g14_train_sv2"):
+    """SENTIMENT_VAE = 2 as a TRAINABLE path.  The reference captioner cannot be constructed in this mode
+    (updown_captioner.py:79,89), so the fixture drives the reference's own ``UpDownCell`` (var_updown/var_updown/modules/
+    updown_cell.py:86-231, unmodified: attention-pooled ``obj_atts`` as prior mean :160-163 and as the 150-wide conditioning of
+    both language LSTMs :185-188,219-222) through T teacher-forced steps under autograd, inside a thin loop that restates the
+    captioner's training branch around it with plain torch modules (nn.Embedding / nn.Linear, the KL formula :298-303 on the
+    prior mean the cell RETURNS, allennlp boundary tokens + masked CE via the stand-ins pinned by g1-g8).  Stored: weights,
+    inputs, loss, kld, every gradient, states / alpha / mean / log_var / prior mean of steps 0, 1, T-1."""
+    from var_updown.modules import UpDownCell
+    V, E, H, A, F, Z, L, B, R = 120, 40, 48, 32, 64, 150, 6, 4, 5
+    T = L + 1
+    torch.manual_seed(11)
+    emb = torch.nn.Embedding(V, E, padding_idx=0)
+    cell = UpDownCell(F, E, H, A, Z, 2, False, torch.device("cpu"), "glove")
+    out = torch.nn.Linear(H, V)
+    feats, caps, senti, eps = make_inputs(2024, B, R, F, L, V, Z, T, unk=True)
+    g = torch.Generator().manual_seed(77)
+    obj = torch.randn(B, R, 150, generator=g) * 0.4
+    obj[1, R - 2:] = 0          # the zero-padded regions carry no attribute means
+    obj[2, 1] = 0               # an object without attributes (translate_obj_atts2obj_means: zeros, :521-522)
+    tokens, _ = oracle.add_sentence_boundary_token_ids(caps, caps != 0, 1, 1)
+    mask = tokens != 0
+    prior_mean = torch.zeros(B, Z)
+    prior_var = (torch.ones(B, Z) * 0.9).pow(2)            # PRIOR_STD = 0.9
+    states, logits, klds, steps = None, [], [], []
+    with EpsInjector([eps[t] for t in range(T)]):
+        for t in range(T):
+            hd, states, mean, log_var, prior_mean, prior_log_var, alpha = cell(
+                feats if t else feats.clone(), obj, emb(tokens[:, t]), states, True, None, None, prior_mean, prior_var)
+            kld = 1 + log_var - prior_log_var - ((mean - prior_mean).pow(2) + log_var.exp()) / (prior_var + 0.00001)
+            klds.append((-0.5 * kld.sum(1)).unsqueeze(1))
+            logits.append(out(hd).unsqueeze(1))
+            steps.append({**{k: v.detach().clone() for k, v in states.items()}, "alpha": alpha.detach().clone(),
+                          "mean": mean.detach().clone(), "log_var": log_var.detach().clone(), "prior_mean": prior_mean.detach().clone()})
+    logits = torch.cat(logits, 1)
+    tmask = mask[:, 1:].contiguous()
+    klds = torch.cat(klds, 1) * tmask.float()
+    loss = tmask.sum(-1).float() * oracle.sequence_cross_entropy_with_logits(logits, tokens[:, 1:].contiguous(), tmask)
+    kld = klds.sum(1)
+    (loss.mean() + kld.mean() / 750.0).backward()
+    data = {"param/_embedding_layer.weight": emb.weight.detach().numpy().copy(),
+            "param/_output_layer.weight": out.weight.detach().numpy().copy(), "param/_output_layer.bias": out.bias.detach().numpy().copy(),
+            "grad/_embedding_layer.weight": emb.weight.grad.numpy().copy(), "grad/_output_layer.weight": out.weight.grad.numpy().copy(),
+            "grad/_output_layer.bias": out.bias.grad.numpy().copy()}
+    for k, v in cell.state_dict().items():
+        data["param/_updown_cell." + k] = v.numpy().copy()
+    for n, p in cell.named_parameters():
+        data["grad/_updown_cell." + n] = p.grad.numpy().copy()
+    data.update({"in/feats": feats.numpy(), "in/caps": caps.numpy(), "in/eps": eps.numpy(), "in/obj_atts": obj.numpy(),
+                 "out/loss": loss.detach().numpy(), "out/kld": kld.detach().numpy()})
+    for t in (0, 1, T - 1):
+        for k, v in steps[t].items():
+            data[f"step{t}/{k}"] = v.numpy()
+    cfg = dict(vocab_size=V, image_feature_size=F, embedding_size=E, hidden_size=H, attention_projection_size=A, z_space=Z,
+               max_caption_length=L, sentiment_vae=2, simple_vae=False, prior_std=0.9, senti_prior_multip=1.0, tied=False)
+    data["cfg"] = np.array(repr(cfg))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **data)
+    print(name, "loss", loss.detach().numpy(), "kld", kld.detach().numpy())
+
+
 def main():
     UpDownCaptioner = import_reference()
+    if "--only-sv2" in sys.argv:
+        return sv2_train_fixture()
     filter_fixture()
     if "--only-filter" in sys.argv:
         return
@@ -694,6 +756,7 @@ def main():
     if "--only-cbs" in sys.argv:
         return
     cell_fixture()
+    sv2_train_fixture()
     if "--full" in sys.argv or not os.path.exists(os.path.join(HERE, "g10_full_c2.npz")):
         full_size_fixture(UpDownCaptioner, "g10_full_c1", B=4, unk=False)      # BASELINE configs[0]: batch 4
         full_size_fixture(UpDownCaptioner, "g10_full_c2", B=64, unk=True)      # BASELINE configs[1]: batch 64, with in-caption UNK

@@ -11,7 +11,7 @@ def dims_from_cfg(cfg: "oracle.OracleConfig") -> ModelDims:
     sv1 = cfg.sentiment_vae == 1 and not cfg.simple_vae
     return ModelDims(V=cfg.vocab_size, E=cfg.embedding_size, H=cfg.hidden_size, A=cfg.attention_projection_size,
                      F=cfg.image_feature_size, Z=cfg.z_space, S=cfg.senti_cols, tied=cfg.tied,
-                     kld_mode=0 if cfg.sentiment_vae == 0 else 1,
+                     kld_mode=0 if cfg.sentiment_vae == 0 else (2 if cfg.sentiment_vae == 2 and not cfg.simple_vae else 1),
                      pm_scale=cfg.senti_prior_multip if sv1 else 0.0, prior_var=cfg.prior_std ** 2,
                      pad=cfg.pad_index, boundary=cfg.boundary_index)
 
