@@ -279,6 +279,10 @@ def main():
     ap.add_argument("--images", type=int, default=1000, help="decode mode: synthetic images in total")
     ap.add_argument("--dump-gemm", default="", help="write the per-shape GEMM timing table (roofline leg) to this file")
     ap.add_argument("--no-decode", action="store_true", help="skip the short decode leg of the default run")
+    ap.add_argument("--dp-algo", default="auto", choices=["auto", "rccl", "xgmi"],
+                    help="gradient exchange at N > 1: rccl = torch.distributed all-reduce; xgmi = direct reduce-scatter + all-gather over "
+                         "hipIpc peer mappings (csrc/collective.hip); auto (default) = verify the direct path against RCCL at start-up, "
+                         "time both on the 446 MB gradient buffer and keep the faster (falls back to rccl when peers cannot be mapped)")
     ap.add_argument("--prewarm", type=int, default=150,
                     help="untimed extra train steps before the W warm-up steps when no decode leg ran first (a GPU coming out of "
                          "idle needs > 1 s to reach its sustained state); 0 for the profiler passes")
@@ -327,6 +331,7 @@ def main():
                             z_space=c["Z"], prior_std=1.0, simple_vae=False, latent_embedding="glove", sentiment_vae=1,
                             senti_prior_multip=0.5, device=device).to(device)
     eng = model._engine()  # flat parameter / gradient store + fused kernels; the module's parameters are views of it
+    eng.dp_algo = args.dp_algo
     if args.mode == "decode":
         return bench_decode(args, model, eng, c, rank, world, device)
     # decode leg of the headline metric (BASELINE.json: "captions/sec (train step) + decode tokens/sec"): C4 itself
@@ -380,7 +385,8 @@ def main():
         t = torch.tensor([sum(ex) / max(1, len(ex)), max(ex) if ex else 0.0], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dp_exposure = {"allreduce_exposed_ms_per_step_mean": float(t[0]), "allreduce_exposed_ms_per_step_max": float(t[1]),
-                       "bytes_per_step": int(eng.grads.flat.numel() * 4), "scheme": "4 ranges (output head behind the BPTT loop, then the three weight-gradient groups), async behind the "
+                       "bytes_per_step": int(eng.grads.flat.numel() * 4), "exchange": eng.dp_choice or {"algo": "rccl", "why": "requested"},
+                       "scheme": "4 ranges (output head behind the BPTT loop, then the three weight-gradient groups), async behind the "
                        "backward phases (engine.backward_overlapped)"}
         if rank == 0:
             print("data-parallel exchange:", json.dumps(dp_exposure), file=sys.stderr, flush=True)
@@ -542,6 +548,8 @@ def main():
             result["cpu_baseline"] = cpu_baseline(c)
         print(json.dumps(result), flush=True)
     if world > 1:
+        if eng._xgmi is not None:
+            eng._xgmi.close()
         dist.barrier()
         dist.destroy_process_group()
 

@@ -345,8 +345,8 @@ int ssc_train_bwd(const ssc_model_cfg* cfg, const ssc_params* p, const ssc_batch
 
 /* The same backward in stream-ordered phases (bit mask): 1 = vocabulary head + BPTT time loop, or its two halves
  * 16 = vocabulary head (output-head gradients final) and 32 = BPTT time loop; 2 = embedding / attention-LSTM /
- * attention-projection gradients, 4 = encoder-LSTM and latent-head gradients, 8 = decoder-LSTM gradients; 16 then 32
- * first, then 2 / 4 / 8 in any order.  Lets the caller overlap the RCCL all-reduce of a finished gradient range with the next phases. */
+ * attention-projection gradients (or its halves 64 = the embedding gradient alone, 128 = the rest), 4 = encoder-LSTM and
+ * latent-head gradients, 8 = decoder-LSTM gradients; 16 then 32 first, then 2 (64, 128) / 4 / 8 in any order.  Lets the caller overlap the RCCL all-reduce of a finished gradient range with the next phases. */
 int ssc_train_bwd_phases(const ssc_model_cfg* cfg, const ssc_params* p, const ssc_batch* batch, void* workspace,
                          size_t workspace_bytes, const float* gl, const float* gk, const ssc_params* g, unsigned phases,
                          void* stream);

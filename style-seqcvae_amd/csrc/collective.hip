@@ -53,35 +53,46 @@ __global__ void xgmi_wait_kernel(ssc_xgmi_comm c, int stage, unsigned seq, unsig
   __threadfence_system();   // acquire: the data kernels that follow read what the signalling ranks wrote before their release
 }
 
-// 16-byte load that bypasses this device's caches (sc0 sc1 = system scope): a peer's bytes must come from its memory, not from a
-// line an earlier collective left in this L2
-__device__ __forceinline__ void load_sys(f32x4& v, const float* p) {
-  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=&v"(v) : "v"(p) : "memory");
+// W 16-byte loads that bypass this device's caches (sc0 sc1 = system scope: a peer's bytes must come from its memory, not from a
+// line an earlier collective left in this L2), issued back to back and WAITED FOR INSIDE THE SAME asm statement: hipcc treats an
+// asm output as valid when the statement ends, so a hand-issued load whose wait sits in a later statement may have its
+// destination copied while it is still in flight (seen here: half of every second float4 came back stale).
+#define XL(j) "global_load_dwordx4 %[o" #j "], %[p" #j "], off sc0 sc1\n"
+#define XO(j) [o##j] "=&v"(v[j])
+#define XP(j) [p##j] "v"(p[j])
+#define XW "s_waitcnt vmcnt(0)"
+template <int W>
+__device__ __forceinline__ void load_sys(f32x4 (&v)[W], const float* const (&p)[W]) {
+  static_assert(W >= 1 && W <= 8, "ranks");
+  if constexpr (W == 1) asm volatile(XL(0) XW : XO(0) : XP(0) : "memory");
+  else if constexpr (W == 2) asm volatile(XL(0) XL(1) XW : XO(0), XO(1) : XP(0), XP(1) : "memory");
+  else if constexpr (W == 3) asm volatile(XL(0) XL(1) XL(2) XW : XO(0), XO(1), XO(2) : XP(0), XP(1), XP(2) : "memory");
+  else if constexpr (W == 4) asm volatile(XL(0) XL(1) XL(2) XL(3) XW : XO(0), XO(1), XO(2), XO(3) : XP(0), XP(1), XP(2), XP(3) : "memory");
+  else if constexpr (W == 5) asm volatile(XL(0) XL(1) XL(2) XL(3) XL(4) XW : XO(0), XO(1), XO(2), XO(3), XO(4) : XP(0), XP(1), XP(2), XP(3), XP(4) : "memory");
+  else if constexpr (W == 6) asm volatile(XL(0) XL(1) XL(2) XL(3) XL(4) XL(5) XW : XO(0), XO(1), XO(2), XO(3), XO(4), XO(5) : XP(0), XP(1), XP(2), XP(3), XP(4), XP(5) : "memory");
+  else if constexpr (W == 7) asm volatile(XL(0) XL(1) XL(2) XL(3) XL(4) XL(5) XL(6) XW : XO(0), XO(1), XO(2), XO(3), XO(4), XO(5), XO(6) : XP(0), XP(1), XP(2), XP(3), XP(4), XP(5), XP(6) : "memory");
+  else asm volatile(XL(0) XL(1) XL(2) XL(3) XL(4) XL(5) XL(6) XL(7) XW : XO(0), XO(1), XO(2), XO(3), XO(4), XO(5), XO(6), XO(7) : XP(0), XP(1), XP(2), XP(3), XP(4), XP(5), XP(6), XP(7) : "memory");
 }
-__device__ __forceinline__ void wait_loads() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#undef XL
+#undef XO
+#undef XP
+#undef XW
 
 // out[i] = sum_j src[j][i], i in [0, n4) float4 units, j in fixed rank order; out may alias src[rank].  W = world size (compile
-// time: W x 2 sixteen-byte loads per thread in flight, no per-rank branches around the hand-issued loads)
+// time): one float4 per rank in flight per thread, many waves in flight per CU
 template <int W>
 __global__ __launch_bounds__(256) void xgmi_reduce_kernel(Peers p, float* __restrict__ out, size_t n4) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += 2 * stride) {
-    const size_t i2 = i + stride;
-    const bool two = i2 < n4;
-    const size_t ib = two ? i2 : i;
-    f32x4 a[W], b[W];
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    f32x4 a[W];
+    const float* q[W];
 #pragma unroll
-    for (int j = 0; j < W; ++j) load_sys(a[j], p.src[j] + 4 * i);
+    for (int j = 0; j < W; ++j) q[j] = p.src[j] + 4 * i;
+    load_sys<W>(a, q);
+    f32x4 sa = a[0];
 #pragma unroll
-    for (int j = 0; j < W; ++j) load_sys(b[j], p.src[j] + 4 * ib);
-    wait_loads();
-#pragma unroll
-    for (int j = 0; j < W; ++j) asm volatile("" : "+v"(a[j]), "+v"(b[j])::"memory");
-    f32x4 sa = a[0], sb = b[0];
-#pragma unroll
-    for (int j = 1; j < W; ++j) { sa += a[j]; sb += b[j]; }
+    for (int j = 1; j < W; ++j) sa += a[j];
     *reinterpret_cast<f32x4*>(out + 4 * i) = sa;
-    if (two) *reinterpret_cast<f32x4*>(out + 4 * i2) = sb;
   }
 }
 typedef void (*reduce_fn)(Peers, float*, size_t);
@@ -113,11 +124,10 @@ __global__ __launch_bounds__(256) void xgmi_gather_kernel(Gather g) {
   const size_t n4 = g.n4[j], stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += 4 * stride) {
     f32x4 v[4];
+    const float* q[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) load_sys(v[u], s + 4 * (i + u * stride < n4 ? i + u * stride : i));
-    wait_loads();
-#pragma unroll
-    for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(v[u])::"memory");
+    for (int u = 0; u < 4; ++u) q[u] = s + 4 * (i + u * stride < n4 ? i + u * stride : i);
+    load_sys<4>(v, q);
 #pragma unroll
     for (int u = 0; u < 4; ++u)
       if (i + u * stride < n4) *reinterpret_cast<f32x4*>(d + 4 * (i + u * stride)) = v[u];
@@ -173,8 +183,8 @@ extern "C" int ssc_xgmi_allreduce(const ssc_xgmi_comm* c, size_t lo, size_t hi, 
     p.world = W; p.rank = r;
     for (int j = 0; j < SSC_XGMI_MAX_RANKS; ++j) p.src[j] = j < W ? c->buf[j] + s_lo : nullptr;
     const size_t n4 = (s_hi - s_lo) / 4;
-    int grid = (int)((n4 + 511) / 512);
-    if (grid > 1024) grid = 1024;
+    int grid = (int)((n4 + 255) / 256);
+    if (grid > 4096) grid = 4096;
     if (grid < 1) grid = 1;
     SSC_LAUNCH(pick_reduce(W), dim3(grid), dim3(256), 0, st, p, c->buf[r] + s_lo, n4);
     SSC_CHECK_LAUNCH();

@@ -691,7 +691,8 @@ __global__ void repeat_kernel(const float* __restrict__ src, int n, int reps, fl
 
 // phases (bit mask): 1 = vocabulary head + BPTT time loop, or its halves 16 = vocabulary head (output-head gradients are final
 // after it) and 32 = BPTT time loop; 2 = embedding, attention-LSTM and attention-projection gradients, 4 = encoder-LSTM and
-// latent-head gradients, 8 = decoder-LSTM gradients.  16 and 32 come first, in this order; 2, 4 and 8 are independent of each other (any order); one stream.  Splitting
+// latent-head gradients, 8 = decoder-LSTM gradients; 2 = 64 (the embedding gradient alone) + 128 (attention-LSTM and attention
+// projections).  16 and 32 come first, in this order; 2 (or 64, 128), 4 and 8 are independent of each other (any order); one stream.  Splitting
 // them lets the caller start the all-reduce of a finished gradient range while the next phase computes
 // (ssc_runtime/engine.py): the output head's 48 MB travel under the whole time loop.
 static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const ssc_batch* bt, void* workspace,
@@ -905,7 +906,17 @@ static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const s
   const float* h1_prev = W + l.h1; const float* h1_new = W + l.h1 + sH;
   const float* hd_prev = W + l.hd; const float* he_prev = W + l.he; const float* he_new = W + l.he + sH;
   const float* att = W + l.att;
-  if (phases & 2u) {
+  if (phases & 64u) {   // phase 2a: the embedding gradient alone (its 40 MB range can travel while every other phase computes)
+  if (g->emb && !cfg->tied) {
+    SSC_TRY(ssc_fill(W + l.demb, (size_t)TB * l.Ep, 0.f, st));  // rows of the padding suffix add nothing to the embedding gradient
+    SSC_TRY(gemm_rows(c, false, {{dga, H4, p->att_w_ih, p->ld_att_w_ih, H4}}, TB, E, W + l.demb, l.Ep, nullptr, /*live=*/true));
+    // zero the table gradient, then scatter-add rows by token id (padding_idx row gets none)
+    if (hipMemset2DAsync(g->emb, (size_t)g->ld_emb * sizeof(float), 0, (size_t)E * sizeof(float), V, st) != hipSuccess)
+      return SSC_EHIP;
+    SSC_TRY(ssc_embed_scatter_add(g->emb, g->ld_emb, tok, TB, E, W + l.demb, l.Ep, cfg->pad, st));
+  }
+  }  // phase 2a
+  if (phases & 128u) {  // phase 2b: attention-LSTM and attention-projection gradients
   {  // all weight-gradient products of this phase at once (grouped launches)
     DwBatch q;
     if (g->att_w_ih) {
@@ -939,18 +950,10 @@ static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const s
     if (g->att_b_ih) SSC_TRY(ssc_colsum2(dga, H4, TB, H4, nullptr, g->att_b_ih, 1, nullptr, 0, c.slabs, st));
     if (g->att_b_hh) SSC_TRY(ssc_colsum2(dga, H4, TB, H4, nullptr, g->att_b_hh, 1, nullptr, 0, c.slabs, st));
   }
-  if (g->emb && !cfg->tied) {
-    SSC_TRY(ssc_fill(W + l.demb, (size_t)TB * l.Ep, 0.f, st));  // rows of the padding suffix add nothing to the embedding gradient
-    SSC_TRY(gemm_rows(c, false, {{dga, H4, p->att_w_ih, p->ld_att_w_ih, H4}}, TB, E, W + l.demb, l.Ep, nullptr, /*live=*/true));
-    // zero the table gradient, then scatter-add rows by token id (padding_idx row gets none)
-    if (hipMemset2DAsync(g->emb, (size_t)g->ld_emb * sizeof(float), 0, (size_t)E * sizeof(float), V, st) != hipSuccess)
-      return SSC_EHIP;
-    SSC_TRY(ssc_embed_scatter_add(g->emb, g->ld_emb, tok, TB, E, W + l.demb, l.Ep, cfg->pad, st));
-  }
   // attention projections
   if (g->wv) SSC_TRY(gemm(c, false, false, {{W + l.dpv, A, bt->feats, F, B * R}}, A, F, g->wv, g->ld_wv));
   if (g->wa) SSC_TRY(ssc_colsum(W + l.dwa, A, B, A, nullptr, g->wa, 1, 0, st));
-  }  // phase 2
+  }  // phase 2b
   if (phases & 4u) {
   {
     DwBatch q;
@@ -1048,12 +1051,13 @@ static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const s
 
 extern "C" int ssc_train_bwd(const ssc_model_cfg* cfg, const ssc_params* p, const ssc_batch* bt, void* workspace,
                              size_t workspace_bytes, const float* gl, const float* gk, const ssc_params* g, void* stream) {
-  return train_bwd_impl(cfg, p, bt, workspace, workspace_bytes, gl, gk, g, stream, 15u);
+  return train_bwd_impl(cfg, p, bt, workspace, workspace_bytes, gl, gk, g, stream, 15u | 64u | 128u);
 }
 
 extern "C" int ssc_train_bwd_phases(const ssc_model_cfg* cfg, const ssc_params* p, const ssc_batch* bt, void* workspace,
                                     size_t workspace_bytes, const float* gl, const float* gk, const ssc_params* g,
                                     unsigned phases, void* stream) {
-  if (phases == 0 || phases > 63u) return SSC_EINVAL;
+  if (phases == 0 || phases > 255u) return SSC_EINVAL;
+  if (phases & 2u) phases |= 64u | 128u;   // 2 = both halves of the embedding / attention-LSTM / attention phase
   return train_bwd_impl(cfg, p, bt, workspace, workspace_bytes, gl, gk, g, stream, phases);
 }

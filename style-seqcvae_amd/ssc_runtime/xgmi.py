@@ -71,6 +71,14 @@ class XgmiAllReduce:
         st = stream if stream is not None else torch.cuda.current_stream(self.device)
         self.lib.ssc_xgmi_allreduce(C.byref(self.comm), lo, hi, self.seq, 0, L.ptr(self.err), C.c_void_p(st.cuda_stream))
 
+    def close(self):
+        """Collective: unmap the peers' buffers (before the owning processes exit)."""
+        torch.cuda.synchronize(self.device)
+        dist.barrier(group=self.group)
+        self._peers = []
+        self.comm = None
+        dist.barrier(group=self.group)
+
     def check(self):
         """Synchronises; raises if any bounded wait of the collectives issued so far gave up (a peer never arrived)."""
         code = int(self.err.item())

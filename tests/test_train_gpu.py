@@ -429,7 +429,8 @@ def test_edge_cases_match_oracle():
         assert torch.isfinite(loss).all() and all(torch.isfinite(x).all() for x in got.values())
 
 
-@pytest.mark.parametrize("masks", [(16, 32, 8, 4, 2), (16, 32, 2, 4, 8), (1, 4, 2, 8), (16, 32, 4 | 8, 2), (15,)])
+@pytest.mark.parametrize("masks", [(16, 32, 8, 4, 2), (16, 32, 2, 4, 8), (1, 4, 2, 8), (16, 32, 4 | 8, 2), (15,),
+                                   (16, 32, 64, 8, 4, 128), (16, 32, 128, 4, 64, 8)])   # 2 = 64 (embedding) + 128 (attention LSTM)
 def test_phased_backward_equals_the_one_call_backward(masks):
     """ssc_train_bwd_phases (include/ssc.h): the vocabulary head (16) and the BPTT loop (32) first, then the three weight-gradient
     phases in ANY order - what lets the data-parallel engine reduce a finished gradient range under the phases that follow
