@@ -19,6 +19,7 @@
 // and leading dimension allow it, else 4 B/lane (still coalesced along the contiguous axis).
 // Split-K: grid.z workgroups per tile write partial slabs that a second kernel (or the fused LSTM /
 // latent epilogue kernels) sums in a fixed order -> deterministic, no float atomics.
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -59,6 +60,7 @@ struct KArgs {
   int tile_gm;        // tile rows per group of the launch's tile order (tile_order)
   int store_wt;       // x3w epilogue: 1 = write-through (sc1) stores of the output tile (split-K slabs: nothing left dirty in L2
                       // for the kernel boundary to write back)
+  int member;         // index of this product inside a grouped launch (address-audit build: which record it reports to)
 };
 
 // Tile order of a launch (speed only; a bijection for any grid).  Workgroups are dealt round-robin over the 8 XCDs, each
@@ -1084,6 +1086,19 @@ constexpr int X3W_STAMP_BYTES = 2048;
 #define SSC_STAMP(i) do {} while (0)
 constexpr int X3W_STAMP_BYTES = 0;
 #endif
+// Address-audit build only (tools/x3w_audit.py compiles a second library with -DSSC_X3W_AUDIT; the product build has none of
+// this): every hand-issued operand load of the wave-specialised kernels reports the byte range it touches, relative to the
+// operand base of its K segment; the launch sites synchronise and compare the ranges with the spans the descriptors imply.
+#ifdef SSC_X3W_AUDIT
+__device__ long long g_audit[6][SSC_MAX_SEG][2][2];   // [group member][segment][A | B][lowest offset, highest offset + 16]
+#define SSC_AUDIT_TOUCH(member, seg, op, off)                                       \
+  do {                                                                              \
+    atomicMin(&g_audit[(member)][(seg)][(op)][0], (long long)(off));                \
+    atomicMax(&g_audit[(member)][(seg)][(op)][1], (long long)(off) + 16);           \
+  } while (0)
+#else
+#define SSC_AUDIT_TOUCH(member, seg, op, off) do {} while (0)
+#endif
 template <int R> struct X3wPlane {   // one bf16 plane of an R-row operand tile: k-contiguous or m/n-contiguous image
   static constexpr int MC_ROW_B = 2 * R + 64;                        // [32 k][R bf16 + 64 B pad]: 4 k-rows x 64 B on 64 banks
   static constexpr int KC_BYTES = R * PL_ROW_B, MC_BYTES = 32 * MC_ROW_B;
@@ -1264,6 +1279,12 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
           mb |= (in ? 1u : 0u) << u;
         }
       }
+#ifdef SSC_X3W_AUDIT
+#pragma unroll
+      for (int u = 0; u < NA; ++u) SSC_AUDIT_TOUCH(a.member, cur.seg, 0, (reinterpret_cast<const char*>(sa) - reinterpret_cast<const char*>(cur.A)) + (long long)ea[u]);
+#pragma unroll
+      for (int u = 0; u < NB; ++u) SSC_AUDIT_TOUCH(a.member, cur.seg, 1, (reinterpret_cast<const char*>(sb) - reinterpret_cast<const char*>(cur.B)) + (long long)eb[u]);
+#endif
 #pragma unroll
       for (int u = 0; u < NA; ++u) asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(xa[u]) : "v"(ea[u]), "s"(sa) : "memory");
 #pragma unroll
@@ -1593,6 +1614,7 @@ int build_args(const ssc_gemm_desc* d, KArgs& k) {
   if (!d || d->nseg < 1 || d->nseg > SSC_MAX_SEG || d->M <= 0 || d->N <= 0) return SSC_EINVAL;
   k.tile_gm = g_tile_gm;
   k.store_wt = g_store_wt;
+  k.member = 0;
   k.nseg = d->nseg;
   k.M = d->M;
   k.N = d->N;
@@ -1666,9 +1688,72 @@ int g_wide_min_n = 1024;
 inline bool wide_tile(int M, int N) { return M <= 64 && N >= g_wide_min_n; }
 
 typedef void (*group_fn)(const KGroup);
+#ifdef SSC_X3W_AUDIT
+static_assert(SSC_GROUP_MAX == 6, "g_audit");
+long g_audit_launches = 0, g_audit_records = 0, g_audit_violations = 0;
+struct AuditSummary { ~AuditSummary() { fprintf(stderr, "[x3w audit] %ld launches, %ld (member, segment, operand) ranges checked, %ld VIOLATIONS\n", g_audit_launches, g_audit_records, g_audit_violations); } } g_audit_summary;
+void audit_begin() {
+  long long init[6][SSC_MAX_SEG][2][2];
+  for (auto& m : init) for (auto& sg : m) for (auto& op : sg) { op[0] = 0x7fffffffffffffffLL; op[1] = -0x7fffffffffffffffLL; }
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_audit), init, sizeof(init));
+}
+// highest entry + 1 of a device-side row list of *count entries (<= nominal), or `nominal` without a list
+long audit_rows(const int* list, const int* count, int nominal) {
+  int n = nominal;
+  if (count) { (void)hipMemcpy(&n, count, sizeof(int), hipMemcpyDeviceToHost); if (n > nominal) n = nominal; if (n < 0) n = 0; }
+  if (!list) return n;
+  if (n == 0) return 0;
+  int* h = (int*)malloc((size_t)n * sizeof(int));
+  (void)hipMemcpy(h, list, (size_t)n * sizeof(int), hipMemcpyDeviceToHost);
+  long mx = 0;
+  for (int i = 0; i < n; ++i) if (h[i] + 1 > mx) mx = h[i] + 1;
+  free(h);
+  return mx;
+}
+void audit_end(const KGroup& g, bool a_kc, bool b_kc, const char* what, hipStream_t st) {
+  (void)hipStreamSynchronize(st);
+  long long got[6][SSC_MAX_SEG][2][2];
+  (void)hipMemcpyFromSymbol(got, HIP_SYMBOL(g_audit), sizeof(got));
+  ++g_audit_launches;
+  for (int m = 0; m < g.n; ++m) {
+    const KArgs& k = g.a[m];
+    for (int sg = 0; sg < k.nseg; ++sg) {
+      const long K = k.kcount ? audit_rows(nullptr, k.kcount, k.seg[sg].K) : k.seg[sg].K;
+      for (int op = 0; op < 2; ++op) {
+        const long long lo = got[m][sg][op][0], hi = got[m][sg][op][1];
+        if (hi <= lo) continue;   // never touched (e.g. no k-step of this segment in any workgroup's range)
+        const bool kc = op == 0 ? a_kc : b_kc;
+        const long ld = op == 0 ? k.seg[sg].lda : k.seg[sg].ldb;
+        const long width = op == 0 ? k.M : k.N;   // rows (k-contiguous) or columns (m/n-contiguous) of the operand
+        long long span;
+        if (kc) {
+          const long rows = op == 0 ? audit_rows(k.arows, k.mcount, k.M) : width;
+          span = rows > 0 ? ((long long)(rows - 1) * ld + k.seg[sg].K) * 4 : 0;
+        } else {
+          const long krows = audit_rows(op == 0 ? k.karows : k.kbrows, k.kcount, k.seg[sg].K);
+          span = krows > 0 ? ((long long)(krows - 1) * ld + width) * 4 : (long long)width * 4;   // (an empty k range re-reads k-row 0)
+        }
+        (void)K;
+        ++g_audit_records;
+        if (lo < 0 || hi > span) {
+          ++g_audit_violations;
+          fprintf(stderr, "[x3w audit] VIOLATION %s member %d segment %d operand %c: touched bytes [%lld, %lld) of a span of %lld (M %d N %d K %d ld %ld)\n",
+                  what, m, sg, op == 0 ? 'A' : 'B', lo, hi, span, k.M, k.N, k.seg[sg].K, ld);
+        }
+      }
+    }
+  }
+}
+#define SSC_AUDIT_BEGIN() audit_begin()
+#define SSC_AUDIT_END(g, a_kc, b_kc, what, st) audit_end(g, a_kc, b_kc, what, st)
+#else
+#define SSC_AUDIT_BEGIN() do {} while (0)
+#define SSC_AUDIT_END(g, a_kc, b_kc, what, st) do {} while (0)
+#endif
 // a single product as a group of one
 inline void group_of_one(KGroup& g, const KArgs& k, dim3 grid) {
   g.a[0] = k;
+  g.a[0].member = 0;
   g.n = 1;
   g.first[0] = 0;
   for (int i = 0; i < SSC_GROUP_MAX; ++i) {
@@ -1774,7 +1859,9 @@ int launch(const ssc_gemm_desc* d, KArgs& k, int splits, hipStream_t st) {
     SSC_TRY(x3w_prepare());
     KGroup g1;
     group_of_one(g1, k, grid);
+    SSC_AUDIT_BEGIN();
     SSC_LAUNCH(x3w_skinny_fn(d->b_kc), dim3(g1.first[1]), dim3(x3w_skinny_threads()), (x3w_lds_bytes<64, 256>()), st, g1);
+    SSC_AUDIT_END(g1, true, d->b_kc != 0, "64x256", st);
     if (rec) (void)hipEventRecord(rec->e1, st);
     SSC_CHECK_LAUNCH();
     return SSC_OK;
@@ -1803,7 +1890,9 @@ int launch(const ssc_gemm_desc* d, KArgs& k, int splits, hipStream_t st) {
       SSC_TRY(x3w_prepare());
       KGroup g1;
       group_of_one(g1, k, grid);
+      SSC_AUDIT_BEGIN();
       SSC_LAUNCH(fn, dim3(g1.first[1]), dim3(x3w_big_threads()), (x3w_lds_bytes<128, 128>()), st, g1);
+      SSC_AUDIT_END(g1, d->a_kc != 0, d->b_kc != 0, "128x128", st);
     } else
     if (d->a_kc && d->b_kc) SSC_LAUNCH((gemm_x3b_kernel<true, true, false>), grid, dim3(256), 0, st, k);
     else if (d->a_kc) SSC_LAUNCH((gemm_x3b_kernel<true, false, false>), grid, dim3(256), 0, st, k);
@@ -2008,6 +2097,7 @@ int ssc_gemm_slabs_group(const ssc_gemm_desc* const* d, int n, float* const* reg
   int Ksum = 0, Nmax = 0;
   for (int i = 0; i < n; ++i) {
     KArgs& k = g.a[i];
+    k.member = i;
     const size_t mn = (size_t)d[i]->M * d[i]->N;
     int splits = ssc_cdiv(k.steps_total, per);
     const int cap = (int)(caps[i] / mn);
@@ -2042,12 +2132,16 @@ int ssc_gemm_slabs_group(const ssc_gemm_desc* const* d, int n, float* const* reg
     (void)hipEventRecord(rec->e0, st);
   }
   if (mid) {
+    SSC_AUDIT_BEGIN();
     SSC_LAUNCH(x3w_big_fn(true, d[0]->b_kc != 0, false), dim3(g.first[n]), dim3(x3w_big_threads()), (x3w_lds_bytes<128, 128>()), st, g);
+    SSC_AUDIT_END(g, true, d[0]->b_kc != 0, "128x128 group", st);
     if (rec) (void)hipEventRecord(rec->e1, st);
     SSC_CHECK_LAUNCH();
     return SSC_OK;
   }
+  SSC_AUDIT_BEGIN();
   SSC_LAUNCH(x3w_skinny_fn(d[0]->b_kc), dim3(g.first[n]), dim3(x3w_skinny_threads()), (x3w_lds_bytes<64, 256>()), st, g);
+  SSC_AUDIT_END(g, true, d[0]->b_kc != 0, "64x256 group", st);
   if (rec) (void)hipEventRecord(rec->e1, st);
   SSC_CHECK_LAUNCH();
   return SSC_OK;
@@ -2071,6 +2165,7 @@ int ssc_gemm_dw_group(const ssc_gemm_desc* const* d, int n, hipStream_t st) {
       const ssc_gemm_desc* dj = d[j];
       KArgs& k = g.a[m];
       SSC_TRY(build_args(dj, k));
+      k.member = m;
       const bool vec = k.nseg == 1 && k.seg[0].avec && k.seg[0].bvec;
       const bool kg = k.karows || k.kbrows;
       const bool ok = group_on && gemm_mode() == 1 && vec && !dj->a_kc && !dj->b_kc && dj->C && dj->ldc >= dj->N && !k.mcount &&
@@ -2100,7 +2195,9 @@ int ssc_gemm_dw_group(const ssc_gemm_desc* const* d, int n, hipStream_t st) {
         for (int q = i; q < j; ++q) prof_desc(rec, d[q], st);
         (void)hipEventRecord(rec->e0, st);
       }
+      SSC_AUDIT_BEGIN();
       SSC_LAUNCH(x3w_big_fn(false, false, kg0), dim3(g.first[m]), dim3(x3w_big_threads()), (x3w_lds_bytes<128, 128>()), st, g);
+      SSC_AUDIT_END(g, false, false, "128x128 TN group", st);
       if (rec) (void)hipEventRecord(rec->e1, st);
       SSC_CHECK_LAUNCH();
       i += m;

@@ -376,9 +376,16 @@ class TrainEngine:
             self.grads.flat.zero_()
             r_ms = timed(lambda: dist.all_reduce(self.grads.flat, op=dist.ReduceOp.SUM, group=group))
             x_ms = timed(lambda: obj.allreduce(0, self.grads.flat.numel()))
-            obj.check()
+            try:
+                obj.check()
+                healthy = True
+            except Exception:   # noqa: BLE001 - a bounded wait gave up on this rank
+                healthy = False
+            healthy = obj._agree(healthy)   # collective: every rank takes the same path
             choice.update(rccl_ms=r_ms, xgmi_ms=x_ms)
-            if x_ms < r_ms:
+            if not healthy:
+                choice.update(why="a rank timed out in the direct path")
+            elif x_ms < r_ms:
                 choice.update(algo="xgmi", why="faster than torch.distributed on this node")
             else:
                 choice.update(why="torch.distributed is faster on this node")

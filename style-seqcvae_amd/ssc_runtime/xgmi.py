@@ -41,25 +41,40 @@ class XgmiAllReduce:
         handles = [None] * self.world
         dist.all_gather_object(handles, mine, group=group)
         self._peers = []   # keep the mapped tensors alive
-        comm = L.XgmiComm()
-        comm.world, comm.rank = self.world, self.rank
-        from torch.multiprocessing.reductions import rebuild_cuda_tensor
-        for j, (dev_j, h_flat, h_flags) in enumerate(handles):
-            if j == self.rank:
-                comm.buf[j], comm.flags[j] = flat.data_ptr(), self.flags.data_ptr()
-                continue
-            if dev_j != self.device.index:   # a peer GPU: kernels on this device must be allowed to touch its memory
-                with torch.cuda.device(self.device):
-                    self.lib.ssc_xgmi_enable_peer(dev_j)
-            pf, pg = rebuild_cuda_tensor(*h_flat), rebuild_cuda_tensor(*h_flags)
-            if pf.numel() != flat.numel():
-                raise XgmiError("ranks disagree on the buffer size")
-            self._peers.append((pf, pg))
-            comm.buf[j], comm.flags[j] = pf.data_ptr(), pg.data_ptr()
-        self.comm = comm
-        dist.barrier(group=group)   # every rank has mapped every buffer before anyone signals
-        if verify:
-            self.self_test()
+        # Every step that can fail on ONE rank only (mapping a peer, the self-test's comparison) is followed by a collective vote,
+        # so that all ranks raise - or go on - together and never wait for each other in different collectives.
+        why = self._map_peers(handles)
+        if not self._agree(why is None):
+            raise XgmiError(why or "a peer rank could not map the buffers")
+        if verify and not self._agree(self._self_test_local()):
+            raise XgmiError("xgmi all-reduce self-test: result differs from torch.distributed.all_reduce (on this or a peer rank)")
+
+    def _agree(self, ok: bool) -> bool:
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device if dist.get_backend(self.group) == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        return int(t.item()) == 1
+
+    def _map_peers(self, handles) -> Optional[str]:
+        try:
+            from torch.multiprocessing.reductions import rebuild_cuda_tensor
+            comm = L.XgmiComm()
+            comm.world, comm.rank = self.world, self.rank
+            for j, (dev_j, h_flat, h_flags) in enumerate(handles):
+                if j == self.rank:
+                    comm.buf[j], comm.flags[j] = self.flat.data_ptr(), self.flags.data_ptr()
+                    continue
+                if dev_j != self.device.index:   # a peer GPU: kernels on this device must be allowed to touch its memory
+                    with torch.cuda.device(self.device):
+                        self.lib.ssc_xgmi_enable_peer(dev_j)
+                pf, pg = rebuild_cuda_tensor(*h_flat), rebuild_cuda_tensor(*h_flags)
+                if pf.numel() != self.flat.numel():
+                    return "ranks disagree on the buffer size"
+                self._peers.append((pf, pg))
+                comm.buf[j], comm.flags[j] = pf.data_ptr(), pg.data_ptr()
+            self.comm = comm
+            return None
+        except Exception as e:   # noqa: BLE001 - reported through the vote
+            return f"{type(e).__name__}: {e}"
 
     def allreduce(self, lo: int = 0, hi: Optional[int] = None, stream: Optional[torch.cuda.Stream] = None):
         """Enqueue the in-place sum over all ranks of flat[lo:hi] on `stream` (default: the current stream).  Every rank must
@@ -86,12 +101,17 @@ class XgmiAllReduce:
             raise XgmiError(f"xgmi all-reduce: rank {self.rank} timed out waiting for its peers at stage {code - 1}")
 
     def self_test(self, n: int = 1 << 16):
+        """Collective.  Raises on every rank if the direct path's result differs from torch.distributed's on any rank."""
+        if not self._agree(self._self_test_local(n)):
+            raise XgmiError("xgmi all-reduce self-test: result differs from torch.distributed.all_reduce (on this or a peer rank)")
+
+    def _self_test_local(self, n: int = 1 << 16) -> bool:
         """A small all-reduce of known per-rank values through the direct path, compared with torch.distributed's result of the
         same input - exact equality is required (integer-valued floats: no rounding in either).  Uses the head of the buffer and
-        restores it."""
+        restores it.  The collectives inside are issued unconditionally; the verdict is this rank's own."""
         n = min(n, self.flat.numel()) & ~3
         if n == 0:
-            return
+            return True
         keep = self.flat[:n].clone()
         g = torch.Generator(device="cpu").manual_seed(1234 + self.rank)
         vals = torch.randint(-1000, 1000, (n,), generator=g).float().to(self.device)
@@ -100,30 +120,25 @@ class XgmiAllReduce:
         self.flat[:n].copy_(vals)
         torch.cuda.synchronize(self.device)
         dist.barrier(group=self.group)
-        self.allreduce(0, n)
-        self.check()
-        ok = torch.equal(self.flat[:n], want)
+        ok = True
+        try:
+            self.allreduce(0, n)
+            self.check()
+        except Exception:   # noqa: BLE001
+            ok = False
+        ok = ok and torch.equal(self.flat[:n], want)
+        dist.barrier(group=self.group)   # nobody restores its buffer while a peer may still read it
         self.flat[:n].copy_(keep)
         torch.cuda.synchronize(self.device)
-        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device if dist.get_backend(self.group) == "nccl" else "cpu")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
-        if int(flag.item()) != 1:
-            raise XgmiError("xgmi all-reduce self-test: result differs from torch.distributed.all_reduce")
+        return ok
 
 
 def try_create(flat: torch.Tensor, group=None, log=None) -> Optional[XgmiAllReduce]:
     """XgmiAllReduce, or None (with the reason logged) when the peers cannot be mapped or the self-test fails on ANY rank: the
     caller then stays on torch.distributed.  The decision is made collectively, so that all ranks take the same path."""
-    obj, why = None, ""
     try:
-        obj = XgmiAllReduce(flat, group=group, verify=True)
+        return XgmiAllReduce(flat, group=group, verify=True)   # raises on every rank or on none (votes after each fallible step)
     except Exception as e:   # noqa: BLE001 - any failure means "use RCCL"
-        why = f"{type(e).__name__}: {e}"
-    ok = torch.tensor([1 if obj is not None else 0], dtype=torch.int32,
-                      device=flat.device if dist.get_backend(group) == "nccl" else "cpu")
-    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
-    if int(ok.item()) != 1:
         if log:
-            log(f"xgmi all-reduce unavailable ({why or 'a peer failed'}): using torch.distributed")
+            log(f"xgmi all-reduce unavailable ({type(e).__name__}: {e}): using torch.distributed")
         return None
-    return obj
