@@ -371,6 +371,11 @@ typedef struct {
   unsigned* flags[SSC_XGMI_MAX_RANKS];
 } ssc_xgmi_comm;
 int ssc_xgmi_enable_peer(int peer_device);   /* hipDeviceEnablePeerAccess from the current device (idempotent) */
+/* hipIpc plumbing: export the allocation containing `ptr` (64-byte handle + ptr's offset in it); open a handle in another
+ * process UNDER THE CALLER'S CURRENT DEVICE (the device whose kernels will read the mapping); close it again. */
+int ssc_xgmi_ipc_export(const void* ptr, void* handle64, size_t* offset);
+int ssc_xgmi_ipc_open(const void* handle64, void** base_out);
+int ssc_xgmi_ipc_close(void* base);
 int ssc_xgmi_allreduce(const ssc_xgmi_comm* c, size_t lo, size_t hi, unsigned seq, unsigned timeout, int* err, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

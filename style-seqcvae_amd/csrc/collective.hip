@@ -147,6 +147,36 @@ int check_comm(const ssc_xgmi_comm* c) {
 
 }  // namespace
 
+// IPC plumbing in plain HIP (no framework internals): the owner exports the ALLOCATION that contains `ptr` (hipIpcGetMemHandle
+// wants its base address) plus ptr's offset inside it; a peer process opens the handle UNDER ITS OWN CURRENT DEVICE - the mapping
+// is then made for the device whose kernels will read it (and its P2P peers), not for the device that owns the memory - and
+// adds the offset.
+extern "C" int ssc_xgmi_ipc_export(const void* ptr, void* handle64, size_t* offset) {
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle size");
+  if (!ptr || !handle64 || !offset) return SSC_EINVAL;
+  hipDeviceptr_t base = nullptr;
+  size_t size = 0;
+  hipError_t e = hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)ptr);
+  if (e == hipSuccess) e = hipIpcGetMemHandle((hipIpcMemHandle_t*)handle64, (void*)base);
+  if (e != hipSuccess) { ssc_tls_hip_error = (int)e; (void)hipGetLastError(); return SSC_EHIP; }
+  *offset = (size_t)((const char*)ptr - (const char*)base);
+  return SSC_OK;
+}
+extern "C" int ssc_xgmi_ipc_open(const void* handle64, void** base_out) {
+  if (!handle64 || !base_out) return SSC_EINVAL;
+  hipIpcMemHandle_t h;
+  memcpy(&h, handle64, sizeof(h));
+  hipError_t e = hipIpcOpenMemHandle(base_out, h, hipIpcMemLazyEnablePeerAccess);
+  if (e != hipSuccess) { ssc_tls_hip_error = (int)e; (void)hipGetLastError(); return SSC_EHIP; }
+  return SSC_OK;
+}
+extern "C" int ssc_xgmi_ipc_close(void* base) {
+  if (!base) return SSC_OK;
+  hipError_t e = hipIpcCloseMemHandle(base);
+  if (e != hipSuccess) { ssc_tls_hip_error = (int)e; (void)hipGetLastError(); return SSC_EHIP; }
+  return SSC_OK;
+}
+
 extern "C" int ssc_xgmi_enable_peer(int peer_device) {
   hipError_t e = hipDeviceEnablePeerAccess(peer_device, 0);
   if (e == hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); return SSC_OK; }

@@ -4,8 +4,11 @@ its address space, then `ssc_xgmi_allreduce` (csrc/collective.hip) runs reduce-s
 the peers' memory directly, all xGMI links of a GPU at once.  Replaces the reduce-add of nn.DataParallel
 (var_updown/scripts/train.py:123-124); `torch.distributed` (RCCL) stays the reference it is verified against at set-up.
 
-Set-up is collective: every rank of `group` constructs XgmiAllReduce on its own flat buffer.  The handles travel through
-`dist.all_gather_object` (torch.multiprocessing's CUDA-IPC reductions: the owner keeps the memory alive, the peers map it).
+Set-up is collective: every rank of `group` constructs XgmiAllReduce on its own flat buffer.  The owner exports the hipMalloc
+allocation that contains its buffer (`ssc_xgmi_ipc_export`: hipIpcGetMemHandle of the allocation base + the buffer's offset), the
+64-byte handles travel through `dist.all_gather_object`, and every peer opens them UNDER ITS OWN DEVICE (`ssc_xgmi_ipc_open`:
+the mapping is made for the device whose kernels read it - torch.multiprocessing's CUDA-IPC rebuild would map it for the owner's
+device index instead).
 `HSA_ENABLE_IPC_MODE_LEGACY=0` must be in the environment before the first HIP call (dmabuf IPC: this pool's driver has no other).
 """
 import ctypes as C
@@ -36,11 +39,10 @@ class XgmiAllReduce:
         self.err = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.seq = 0
         torch.cuda.synchronize(self.device)
-        from torch.multiprocessing.reductions import reduce_tensor
-        mine = (self.device.index, reduce_tensor(flat)[1], reduce_tensor(self.flags)[1])
+        self._opened = {}   # (rank, handle bytes) -> mapped allocation base (an allocation may hold both buffers)
+        mine = (self.device.index, self._export(flat), self._export(self.flags), flat.numel())
         handles = [None] * self.world
         dist.all_gather_object(handles, mine, group=group)
-        self._peers = []   # keep the mapped tensors alive
         # Every step that can fail on ONE rank only (mapping a peer, the self-test's comparison) is followed by a collective vote,
         # so that all ranks raise - or go on - together and never wait for each other in different collectives.
         why = self._map_peers(handles)
@@ -54,23 +56,37 @@ class XgmiAllReduce:
         dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
         return int(t.item()) == 1
 
+    def _export(self, t: torch.Tensor):
+        handle = C.create_string_buffer(64)
+        off = C.c_size_t(0)
+        with torch.cuda.device(self.device):
+            self.lib.ssc_xgmi_ipc_export(L.ptr(t), handle, C.byref(off))
+        return bytes(handle.raw), int(off.value)
+
+    def _open(self, j: int, exported) -> int:
+        handle, off = exported
+        key = (j, handle)
+        if key not in self._opened:
+            base = C.c_void_p()
+            with torch.cuda.device(self.device):   # the mapping is made for THIS device
+                self.lib.ssc_xgmi_ipc_open(C.create_string_buffer(handle, 64), C.byref(base))
+            self._opened[key] = int(base.value)
+        return self._opened[key] + off
+
     def _map_peers(self, handles) -> Optional[str]:
         try:
-            from torch.multiprocessing.reductions import rebuild_cuda_tensor
             comm = L.XgmiComm()
             comm.world, comm.rank = self.world, self.rank
-            for j, (dev_j, h_flat, h_flags) in enumerate(handles):
+            for j, (dev_j, h_flat, h_flags, numel) in enumerate(handles):
                 if j == self.rank:
                     comm.buf[j], comm.flags[j] = self.flat.data_ptr(), self.flags.data_ptr()
                     continue
+                if numel != self.flat.numel():
+                    return "ranks disagree on the buffer size"
                 if dev_j != self.device.index:   # a peer GPU: kernels on this device must be allowed to touch its memory
                     with torch.cuda.device(self.device):
                         self.lib.ssc_xgmi_enable_peer(dev_j)
-                pf, pg = rebuild_cuda_tensor(*h_flat), rebuild_cuda_tensor(*h_flags)
-                if pf.numel() != self.flat.numel():
-                    return "ranks disagree on the buffer size"
-                self._peers.append((pf, pg))
-                comm.buf[j], comm.flags[j] = pf.data_ptr(), pg.data_ptr()
+                comm.buf[j], comm.flags[j] = self._open(j, h_flat), self._open(j, h_flags)
             self.comm = comm
             return None
         except Exception as e:   # noqa: BLE001 - reported through the vote
@@ -90,7 +106,12 @@ class XgmiAllReduce:
         """Collective: unmap the peers' buffers (before the owning processes exit)."""
         torch.cuda.synchronize(self.device)
         dist.barrier(group=self.group)
-        self._peers = []
+        for base in self._opened.values():
+            try:
+                self.lib.ssc_xgmi_ipc_close(C.c_void_p(base))
+            except Exception:   # noqa: BLE001 - best effort at shutdown
+                pass
+        self._opened = {}
         self.comm = None
         dist.barrier(group=self.group)
 

@@ -26,9 +26,6 @@ def worker(rank, world, port, mb):
         t0 = time.time()
         xg = XgmiAllReduce(flat, verify=False)
         print(f"[{rank}] mapped peers in {time.time() - t0:.2f}s", flush=True)
-        for pf, pg in xg._peers:
-            bad = (pf != float(2 - rank)).nonzero().flatten()
-            print(f"[{rank}] peer view: numel {pf.numel()} ptr {pf.data_ptr():x} own ptr {flat.data_ptr():x} mismatches {bad.numel()} first {bad[:8].tolist()} vals {pf[bad[:8]].tolist() if bad.numel() else []}", flush=True)
         dist.barrier()
         xg.allreduce(0, n)
         torch.cuda.synchronize()
