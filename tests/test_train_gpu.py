@@ -104,8 +104,8 @@ def test_train_sv2_matches_oracle_medium():
     oracle.train_objective(out, cfg).backward()
     eng = engine_from(cfg, params)
     loss, kld = eng.forward(dev(feats), dev(caps), None, dev(eps), dev(obj))
-    assert maxdiff(loss, out["loss"]) <= 1e-5 * float(out["loss"].abs().max()) + 1e-4
-    assert maxdiff(kld, out["kld"]) <= 1e-5 * float(out["kld"].abs().max()) + 1e-4
+    assert maxdiff(loss, out["loss"]) <= 1e-5 * float(out["loss"].detach().abs().max()) + 1e-4
+    assert maxdiff(kld, out["kld"]) <= 1e-5 * float(out["kld"].detach().abs().max()) + 1e-4
     eng.backward(torch.full((B,), 1.0 / B, device="cuda"), torch.full((B,), 1.0 / (B * cfg.kld_weight), device="cuda"))
     got = eng.grad_dict()
     for k, v in p.items():
@@ -146,8 +146,9 @@ def test_train_matches_oracle_medium(sv, B, R, dims):
     oracle.train_objective(out, cfg).backward()
     eng = engine_from(cfg, params)
     loss, kld = eng.forward(dev(feats), dev(caps), dev(senti), dev(eps))
-    assert maxdiff(loss, out["loss"]) < TOL * 5  # loss ~ O(80): relative 1e-5
-    assert maxdiff(kld, out["kld"]) < TOL * 5
+    # north_star tolerance as the full-size tests state it: 1e-4 absolute + 1e-5 relative (losses here are O(80): one fp32 ulp is 8e-6)
+    assert maxdiff(loss, out["loss"]) <= 1e-4 + 1e-5 * float(out["loss"].detach().abs().max())
+    assert maxdiff(kld, out["kld"]) <= 1e-4 + 1e-5 * float(out["kld"].detach().abs().max())
     gl = torch.full((B,), 1.0 / B, device="cuda")
     gk = torch.full((B,), 1.0 / (B * cfg.kld_weight), device="cuda")
     eng.backward(gl, gk)
@@ -177,8 +178,8 @@ def test_stress_shape_c5_like_regions_and_length():
     oracle.train_objective(out, cfg).backward()
     eng = engine_from(cfg, params)
     loss, kld = eng.forward(dev(feats), dev(caps), dev(senti), dev(eps))
-    assert maxdiff(loss, out["loss"]) < 1e-3      # loss ~ O(250): 4e-6 relative
-    assert maxdiff(kld, out["kld"]) < 1e-3
+    assert maxdiff(loss, out["loss"]) <= 1e-4 + 1e-5 * float(out["loss"].detach().abs().max())   # loss ~ O(250)
+    assert maxdiff(kld, out["kld"]) <= 1e-4 + 1e-5 * float(out["kld"].detach().abs().max())
     eng.backward(torch.full((B,), 1.0 / B, device="cuda"), torch.full((B,), 1.0 / (B * cfg.kld_weight), device="cuda"))
     got = eng.grad_dict()
     for k, v in p.items():
@@ -249,7 +250,7 @@ def test_full_size_c2_batch_permutation_and_padding_invariance():
     l1, k1, g1 = _step(eng, batch)
     perm = torch.randperm(feats.shape[0], generator=torch.Generator().manual_seed(5)).cuda()
     l2, k2, g2 = _step(eng, (feats[perm].contiguous(), caps[perm].contiguous(), senti[perm].contiguous(), eps[:, perm].contiguous()))
-    assert maxdiff(l2, l1[perm]) < 1e-3 and maxdiff(k2, k1[perm]) < 1e-3
+    assert maxdiff(l2, l1[perm]) <= 1e-4 + 1e-5 * float(l1.abs().max()) and maxdiff(k2, k1[perm]) <= 1e-4 + 1e-5 * float(k1.abs().max())
     for k in g1:
         scale = max(g1[k].abs().max().item(), 1e-6)
         assert maxdiff(g1[k], g2[k]) <= 2e-4 * scale + 1e-7, k
@@ -385,7 +386,7 @@ def test_full_size_c5_properties():
         l0, k0, g0 = _step(eng, batch)
     finally:
         lib.ssc_set_gemm_mode(1)
-    assert ((l1 - l0).abs() <= 2e-5 * l0.abs() + 1e-3).all() and ((k1 - k0).abs() <= 2e-5 * k0.abs() + 1e-3).all()
+    assert ((l1 - l0).abs() <= 1e-5 * l0.abs().max() + 1e-4).all() and ((k1 - k0).abs() <= 1e-5 * k0.abs().max() + 1e-4).all()
     for k in g1:
         scale = max(g0[k].abs().max().item(), 1e-6)
         assert maxdiff(g1[k], g0[k]) <= 2e-4 * scale + 1e-7, (k, maxdiff(g1[k], g0[k]), scale)
