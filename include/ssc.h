@@ -376,6 +376,7 @@ int ssc_xgmi_enable_peer(int peer_device);   /* hipDeviceEnablePeerAccess from t
 int ssc_xgmi_ipc_export(const void* ptr, void* handle64, size_t* offset);
 int ssc_xgmi_ipc_open(const void* handle64, void** base_out);
 int ssc_xgmi_ipc_close(void* base);
+int ssc_xgmi_peek(const void* src, void* dst_host, size_t bytes);   /* hipMemcpy D2H from a (peer-mapped) device pointer */
 int ssc_xgmi_allreduce(const ssc_xgmi_comm* c, size_t lo, size_t hi, unsigned seq, unsigned timeout, int* err, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

@@ -177,6 +177,15 @@ extern "C" int ssc_xgmi_ipc_close(void* base) {
   return SSC_OK;
 }
 
+// Copies `bytes` from a (peer-mapped) device pointer to host memory with the runtime's copy engine: the first touch of a fresh
+// mapping happens here, where a bad mapping comes back as an error code instead of a GPU fault inside a kernel.
+extern "C" int ssc_xgmi_peek(const void* src, void* dst_host, size_t bytes) {
+  if (!src || !dst_host || !bytes) return SSC_EINVAL;
+  hipError_t e = hipMemcpy(dst_host, src, bytes, hipMemcpyDeviceToHost);
+  if (e != hipSuccess) { ssc_tls_hip_error = (int)e; (void)hipGetLastError(); return SSC_EHIP; }
+  return SSC_OK;
+}
+
 extern "C" int ssc_xgmi_enable_peer(int peer_device) {
   hipError_t e = hipDeviceEnablePeerAccess(peer_device, 0);
   if (e == hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); return SSC_OK; }

@@ -157,6 +157,7 @@ SYMBOLS = {
     "ssc_xgmi_ipc_export": (_i, [vp, vp, C.POINTER(C.c_size_t)]),
     "ssc_xgmi_ipc_open": (_i, [vp, C.POINTER(vp)]),
     "ssc_xgmi_ipc_close": (_i, [vp]),
+    "ssc_xgmi_peek": (_i, [vp, vp, _sz]),
     "ssc_xgmi_allreduce": (_i, [C.POINTER(XgmiComm), _sz, _sz, C.c_uint, C.c_uint, vp, vp]),
     "ssc_decode_image_bytes": (_sz, [C.POINTER(ModelCfg), _i, _i]),
     "ssc_decode_prepare": (_i, [C.POINTER(ModelCfg), C.POINTER(Params), vp, _i, _i, vp, _sz, vp]),

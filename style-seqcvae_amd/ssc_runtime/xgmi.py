@@ -35,7 +35,10 @@ class XgmiAllReduce:
         self.lib = L.load()
         self.flat = flat
         self.device = flat.device
-        self.flags = torch.zeros(4 * L.SSC_XGMI_MAX_RANKS, dtype=torch.int32, device=self.device)
+        # 3 stages x MAX_RANKS sequence words, then (from word 32) a 32-word pattern block the peers read back through the copy
+        # engine before any kernel touches a fresh mapping (_probe_peers)
+        self.flags = torch.zeros(64, dtype=torch.int32, device=self.device)
+        self.flags[32:] = torch.arange(32, dtype=torch.int32, device=self.device) * 7919 + 1000003 * (self.rank + 1)
         self.err = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.seq = 0
         torch.cuda.synchronize(self.device)
@@ -48,6 +51,9 @@ class XgmiAllReduce:
         why = self._map_peers(handles)
         if not self._agree(why is None):
             raise XgmiError(why or "a peer rank could not map the buffers")
+        why = self._probe_peers()
+        if not self._agree(why is None):
+            raise XgmiError(why or "a peer rank could not read a mapped buffer")
         if verify and not self._agree(self._self_test_local()):
             raise XgmiError("xgmi all-reduce self-test: result differs from torch.distributed.all_reduce (on this or a peer rank)")
 
@@ -72,6 +78,24 @@ class XgmiAllReduce:
                 self.lib.ssc_xgmi_ipc_open(C.create_string_buffer(handle, 64), C.byref(base))
             self._opened[key] = int(base.value)
         return self._opened[key] + off
+
+    def _probe_peers(self) -> Optional[str]:
+        """First touch of every fresh mapping by the runtime's copy engine (an error code on failure, never a GPU fault): each
+        peer's pattern block must read back as that peer wrote it."""
+        try:
+            import numpy as np
+            for j in range(self.world):
+                if j == self.rank:
+                    continue
+                got = np.zeros(32, dtype=np.int32)
+                with torch.cuda.device(self.device):
+                    self.lib.ssc_xgmi_peek(C.c_void_p(int(self.comm.flags[j]) + 32 * 4), got.ctypes.data_as(C.c_void_p), 32 * 4)
+                want = np.arange(32, dtype=np.int64) * 7919 + 1000003 * (j + 1)
+                if not np.array_equal(got.astype(np.int64), want):
+                    return f"rank {j}'s mapped flag block does not read back as written"
+            return None
+        except Exception as e:   # noqa: BLE001 - reported through the vote
+            return f"{type(e).__name__}: {e}"
 
     def _map_peers(self, handles) -> Optional[str]:
         try:
