@@ -196,15 +196,17 @@ def _xgmi_worker(rank, world, port, ret):
     dist.destroy_process_group()
 
 
-def test_xgmi_direct_allreduce_two_ranks_sharing_the_gpu():
-    """ssc_xgmi_allreduce (reduce-scatter + all-gather kernels over hipIpc peer mappings, flag-ordered across the two processes)
-    against torch.distributed: exact sums of integer-valued floats over whole buffers, sub-ranges, one-unit ranges, a side stream."""
+@pytest.mark.parametrize("world", [2, 3])
+def test_xgmi_direct_allreduce_ranks_sharing_the_gpu(world):
+    """ssc_xgmi_allreduce (reduce-scatter + all-gather kernels over hipIpc peer mappings, flag-ordered across the processes)
+    against torch.distributed: exact sums of integer-valued floats over whole buffers, sub-ranges, one-unit ranges (some ranks'
+    shards empty), a side stream; two ranks, and three (an odd world size: uneven shards, two peers per rank)."""
     ctx = mp.get_context("spawn")
     ret = ctx.SimpleQueue()
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    procs = [ctx.Process(target=_xgmi_worker, args=(r, 2, port, ret)) for r in range(2)]
+    procs = [ctx.Process(target=_xgmi_worker, args=(r, world, port, ret)) for r in range(world)]
     for p in procs:
         p.start()
     assert _join_then_get(procs, ret) == "ok"
