@@ -138,6 +138,12 @@ int ssc_lstm_fwd_z(const ssc_lstm_fwd_desc* d, const float* z, int ldz, const fl
  *   pout[s][b,n] = sum_{j in [16 s, 16 s + 16)} h_out[b,j] wp[n,j],   s < ceil(H/16), each slab (B,NP) ld NP
  * (the encoder LSTM's h feeds fc_mean | fc_log_var in the same step, updown_cell.py:196-197: ssc_latent_fwd sums the slabs). */
 int ssc_lstm_fwd_p(const ssc_lstm_fwd_desc* d, const float* wp, int ldwp, int NP, float* pout, void* stream);
+/* ssc_lstm_fwd for rows that share per-image operands (decode), with one more addend from a per-image table:
+ *   pre[b,n] += sum_r alpha[b,r] P[(img(b) R + r) 4H + n],  img(b) = b / rows_per_image;  alpha (B,R) ld ldalpha; R <= 128.
+ * With P[img,r,:] = W_ih^dec[:, :F] v_{img,r} (ssc_decode_prepare) this IS the attended-feature segment of the decoder gate
+ * product (updown_cell.py:156-158,211-229), by linearity of the product in att = sum_r alpha_r v_r. */
+int ssc_lstm_fwd_img(const ssc_lstm_fwd_desc* d, const float* alpha, int ldalpha, const float* P, int R, int rows_per_image,
+                     void* stream);
 
 /* LSTMCell pointwise backward (SURVEY Appendix A.4 "LSTM^-1"):
  *   dh (B,H) (+ dh2 optional second addend), dc_in (B,H), gates (activated), c_prev, c_new
@@ -180,6 +186,10 @@ int ssc_attn_fwd(const float* q, int ldq, const float* pv, const float* wa, cons
 
 /* out (G,D) = sum_r alpha[g,r] x[img(g),r,:]: attention pooling of a per-region tensor x (nimg,R,D) with the step's weights -
  * the grounded style prior of SENTIMENT_VAE = 2 (updown_cell.py:160-163: per-region attribute means obj_atts, D = 150). */
+/* the attention weights alone (no weighted feature sum): decode consumes alpha through ssc_lstm_fwd_img */
+int ssc_attn_weights(const float* q, int ldq, const float* pv, const float* wa, const float* mask, int G, int R, int A,
+                     int rows_per_image, float* logits, float* alpha, void* stream);
+
 int ssc_attn_pool(const float* alpha, const float* x, int G, int R, int D, int rows_per_image, float* out, int ldo,
                   void* stream);
 /* ssc_attn_fwd that also pools a second per-region tensor with the same weights, in the same launch:
@@ -405,6 +415,10 @@ typedef struct {
   int emb_override;          /* 1: p->emb of THIS call is not the embedding ssc_decode_prepare saw (a caller that hands token
                               * embeddings instead of ids, UpDownCell.forward): the per-token gate table of the image context
                               * is not used, the embedding goes through the gate product */
+  int att_table;             /* attended-feature term of the decoder gates (updown_cell.py:156-158,211-229): 0 = weighted feature sum +
+                              * K = F segment of the gate product; 1 = from the per-image table P[img,r,:] = W_ih^dec[:, :F] v_r in the
+                              * image buffer (ssc_lstm_fwd_img, K = R; R <= 128); 2 = form that table first (once per image
+                              * context, by the first step that uses it), then as 1.  Pays from ~500 rows with >= 16 rows per image */
 } ssc_decode_step_desc;
 size_t ssc_decode_step_workspace_bytes(const ssc_model_cfg* cfg, int G, int R);
 int ssc_decode_step(const ssc_model_cfg* cfg, const ssc_params* p, const ssc_decode_step_desc* d, void* workspace,

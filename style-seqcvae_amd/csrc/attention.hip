@@ -172,6 +172,7 @@ __global__ __launch_bounds__(64) void attn_apply_kernel(const float* __restrict_
     }
   }
   __syncthreads();
+  if (!att) return;   // weights only (ssc_attn_weights)
   if (chunk >= fchunks) {   // pooled obj columns (rows of D floats: no 16-byte alignment to rely on)
     const float* op = obj + (size_t)img * R * D;
     for (int k = 0; k < 4; ++k) {
@@ -371,6 +372,16 @@ extern "C" int ssc_attn_fwd(const float* q, int ldq, const float* pv, const floa
   SSC_TRY(ssc_attn_logits(q, ldq, pv, wa, G, R, A, rows_per_image, logits, stream));
   SSC_LAUNCH(attn_apply_kernel, dim3(ssc_cdiv(F, 256), G), dim3(64), 0, (hipStream_t)stream, logits, mask, feats,
                      G, R, F, rows_per_image, alpha, att, ldatt, (const float*)nullptr, 0, (float*)nullptr, 0);
+  SSC_CHECK_LAUNCH();
+  return SSC_OK;
+}
+
+extern "C" int ssc_attn_weights(const float* q, int ldq, const float* pv, const float* wa, const float* mask, int G, int R, int A,
+                                int rows_per_image, float* logits, float* alpha, void* stream) {
+  if (!mask || !alpha || !logits || R > 64 * MAXR_LANE) return SSC_EINVAL;
+  SSC_TRY(ssc_attn_logits(q, ldq, pv, wa, G, R, A, rows_per_image, logits, stream));
+  SSC_LAUNCH(attn_apply_kernel, dim3(1, G), dim3(64), 0, (hipStream_t)stream, logits, mask, (const float*)nullptr, G, R, 4,
+             rows_per_image, alpha, (float*)nullptr, 0, (const float*)nullptr, 0, (float*)nullptr, 0);
   SSC_CHECK_LAUNCH();
   return SSC_OK;
 }

@@ -18,15 +18,19 @@ inline size_t r4(size_t x) { return (x + 3) & ~(size_t)3; }
 inline size_t r64(size_t x) { return (x + 63) & ~(size_t)63; }
 
 struct ImgLayout {
-  size_t mask, avg, pv, ga_avg, wsum_att, wsum_dec, wz, emb_gates, scratch, scratch_floats, total;
+  size_t mask, avg, pv, ga_avg, wsum_att, wsum_dec, wz, emb_gates, pd, scratch, scratch_floats, total;
   int Fp, Hp, Zp;
   bool token_table;   // emb_gates holds the (V, 4H) table emb . W_ih^att[:, :E]^T
+  bool att_table;     // pd holds P[img, r, :] = W_ih^dec[:, :F] v_{img,r} (nimg*R x 4H): the decoder gates' attended-feature term per region
 };
 // The embedding's contribution to the attention LSTM gates depends on the token only: from this many images per call on it is
 // formed once per call for the whole vocabulary ((V, E) x (E, 4H): 96 GFLOP at C4, 0.5 ms) and the cell kernel picks the row
 // of the beam's last token (ssc_lstm_fwd_desc.add0_rows), instead of a K = E segment of the gate product in every step
 // (5000 x 4800 x 1000 per step at C4: 0.25 ms x 20 steps).  Below it (a handful of rows per step) the segment is cheaper.
 constexpr int DEC_TOKEN_TABLE_MIN_IMAGES = 8;
+}  // namespace
+int ssc_g_dec_att_table = ssc_env_int("SSC_DEC_ATT_TABLE", 1);   // ssc_debug_set("dec_att_table"): 0 = attended features + K = F segment in every step
+namespace {
 ImgLayout img_layout(const ssc_model_cfg* c, int nimg, int R) {
   ImgLayout l;
   l.Fp = (int)r4(c->F);
@@ -44,6 +48,12 @@ ImgLayout img_layout(const ssc_model_cfg* c, int nimg, int R) {
   l.wz = o; o += r64((size_t)4 * c->H * l.Zp);
   l.token_table = nimg >= DEC_TOKEN_TABLE_MIN_IMAGES;
   l.emb_gates = o; o += r64(l.token_table ? (size_t)c->V * 4 * c->H : 0);
+  // The attended-feature segment of the decoder gate product, att . W_ih^dec[:, :F]^T with att = sum_r alpha_r v_r, is linear in
+  // att: sum_r alpha_r (v_r . W^T).  The R region terms of an image are formed once per call (one (nimg R) x 4H x F product) and
+  // the decoder cell contracts them with the step's attention weights (ssc_lstm_fwd_img, K = R): the largest product of a decode
+  // step (K = F + 2H + Z = 4576) loses its K = F = 2048 segment, and the weighted feature sum itself is no longer needed.
+  l.att_table = ssc_g_dec_att_table != 0 && R <= 128;
+  l.pd = o; o += r64(l.att_table ? (size_t)nimg * R * 4 * c->H : 0);
   size_t a = (size_t)nimg * R * c->A, b = (size_t)nimg * 4 * c->H;
   l.scratch_floats = 33 * (a > b ? a : b);
   l.scratch = o; o += r64(l.scratch_floats);
@@ -332,6 +342,7 @@ extern "C" int ssc_decode_prepare(const ssc_model_cfg* cfg, const ssc_params* p,
   if (l.token_table)
     SSC_TRY(gemm_nt(st, W + l.scratch, l.scratch_floats, {{p->emb, p->ld_emb, p->att_w_ih, p->ld_att_w_ih, E}}, cfg->V, H4,
                     W + l.emb_gates, H4));
+  // (the attended-feature table l.pd is formed by the first decode step that asks for it: ssc_decode_step_desc.att_table = 2)
   {
     const int H = cfg->H, Z = cfg->Z, S = cfg->S;
     dim3 grid(ssc_cdiv(H, 256), H4);
@@ -372,6 +383,11 @@ extern "C" int ssc_decode_step(const ssc_model_cfg* cfg, const ssc_params* p, co
   const int E = cfg->E, H = cfg->H, A = cfg->A, F = cfg->F, Z = cfg->Z, S = cfg->S, V = cfg->V, H4 = 4 * H;
   float* slabs = W + l.slabs;
   int ns = 0;
+  if (d->att_table < 0 || d->att_table > 2 || (d->att_table && !il.att_table)) return SSC_EINVAL;
+  const bool att_table = d->att_table != 0;
+  if (d->att_table == 2)   // P[img, r, :] = W_ih^dec[:, :F] v_{img,r}: one (nimg R) x 4H x F product per image context
+    SSC_TRY(gemm_nt(st, slabs, l.slab_floats, {{d->feats, F, p->dec_w_ih, p->ld_dec_w_ih, F}}, nimg * R, H4,
+                    const_cast<float*>(I) + il.pd, H4));
 
   // embedding + attention LSTM (updown_captioner.py:430, updown_cell.py:143-148)
   {
@@ -397,16 +413,24 @@ extern "C" int ssc_decode_step(const ssc_model_cfg* cfg, const ssc_params* p, co
   }
   // attention over the image's regions (attention.py:69-95, updown_cell.py:151-158)
   SSC_TRY(gemm_nt(st, slabs, l.slab_floats, {{d->h1_out, H, p->wq, p->ld_wq, H}}, G, A, W + l.q, l.Ap));
-  SSC_TRY(ssc_attn_fwd(W + l.q, l.Ap, I + il.pv, p->wa, I + il.mask, d->feats, G, R, A, F, rpi, W + l.attn_logits, d->alpha,
-                       W + l.att, l.Fp, st));
+  if (att_table)
+    SSC_TRY(ssc_attn_weights(W + l.q, l.Ap, I + il.pv, p->wa, I + il.mask, G, R, A, rpi, W + l.attn_logits, d->alpha, st));
+  else
+    SSC_TRY(ssc_attn_fwd(W + l.q, l.Ap, I + il.pv, p->wa, I + il.mask, d->feats, G, R, A, F, rpi, W + l.attn_logits, d->alpha,
+                         W + l.att, l.Fp, st));
   // z ~ N(prior_mean, prior_var) (updown_cell.py:200-208)
   SSC_TRY(ssc_latent_prior_sample(d->eps, Z, cfg->pm_scale != 0.f ? d->sentiment : nullptr, cfg->pm_scale, cfg->prior_var,
                                   G, Z, W + l.z, l.Zp, st));
   // decoder LSTM (updown_cell.py:211-229)
   {
-    SSC_TRY(gemm_slabs(st, slabs, l.slab_floats,
-                       {{W + l.att, l.Fp, p->dec_w_ih, p->ld_dec_w_ih, F}, {d->h1_out, H, p->dec_w_ih + F, p->ld_dec_w_ih, H},
-                        {d->hd, H, I + il.wsum_dec, il.Hp, H}, {W + l.z, l.Zp, I + il.wz, il.Zp, Z}}, G, H4, &ns));
+    if (att_table)   // the attended-feature segment comes from the per-image table inside the cell kernel
+      SSC_TRY(gemm_slabs(st, slabs, l.slab_floats,
+                         {{d->h1_out, H, p->dec_w_ih + F, p->ld_dec_w_ih, H}, {d->hd, H, I + il.wsum_dec, il.Hp, H},
+                          {W + l.z, l.Zp, I + il.wz, il.Zp, Z}}, G, H4, &ns));
+    else
+      SSC_TRY(gemm_slabs(st, slabs, l.slab_floats,
+                         {{W + l.att, l.Fp, p->dec_w_ih, p->ld_dec_w_ih, F}, {d->h1_out, H, p->dec_w_ih + F, p->ld_dec_w_ih, H},
+                          {d->hd, H, I + il.wsum_dec, il.Hp, H}, {W + l.z, l.Zp, I + il.wz, il.Zp, Z}}, G, H4, &ns));
     ssc_lstm_fwd_desc f{};
     f.B = G; f.H = H;
     f.slabs = slabs; f.nslab = ns; f.slab_stride = (size_t)G * H4;
@@ -417,7 +441,8 @@ extern "C" int ssc_decode_step(const ssc_model_cfg* cfg, const ssc_params* p, co
     }
     f.c_prev = d->cd; f.ld_cprev = H;
     f.c_out = d->cd_out; f.ld_cout = H; f.h_out = d->hd_out; f.ld_hout = H;
-    SSC_TRY(ssc_lstm_fwd(&f, st));
+    if (att_table) SSC_TRY(ssc_lstm_fwd_img(&f, d->alpha, R, I + il.pd, R, rpi, st));
+    else SSC_TRY(ssc_lstm_fwd(&f, st));
   }
   // vocabulary log-probabilities (updown_captioner.py:444-450); skipped when only the cell output is wanted
   if (!d->log_probs) return SSC_OK;

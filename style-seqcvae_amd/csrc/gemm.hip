@@ -2300,6 +2300,7 @@ extern "C" int ssc_set_gemm_mode(int mode) {
 }
 
 // ---- include/ssc_debug.h -----------------------------------------------------------------------------------------
+extern int ssc_g_dec_att_table;   // decode.hip
 namespace {
 struct DebugKey { const char* name; int* var; };
 const DebugKey g_debug_keys[] = {
@@ -2317,6 +2318,7 @@ const DebugKey g_debug_keys[] = {
     {"x3w_pf", &g_x3w_pf},           // 64x256 kernels: k-steps in flight in the producers' registers (2 | 3)   (SSC_X3W_PF)
     {"store_wt", &g_store_wt},       // wave-specialised kernels: write-through (sc1) output stores (0 | 1)   (SSC_STORE_WT)
     {"tile_gm", &g_tile_gm},         // tile rows per group of the tile order (8; 0 = row-major)   (SSC_TILE_GM)
+    {"dec_att_table", &ssc_g_dec_att_table},   // decode: attended-feature term of the decoder gates from a per-image table (1 | 0)   (SSC_DEC_ATT_TABLE)
     {"big_min_m", &g_big_min_m},     // rows from which a product with N >= 512 takes 128x128 tiles (65; 512 = the behaviour until late in round 2)   (SSC_BIG_MIN_M)
 };
 }  // namespace

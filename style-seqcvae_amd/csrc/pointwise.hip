@@ -277,6 +277,98 @@ __global__ __launch_bounds__(512, 2) void lstm_fwd_z_kernel(const ssc_lstm_fwd_d
   d.c_out[(size_t)b * d.ld_cout + j] = c;
   d.h_out[(size_t)b * d.ld_hout + j] = h;
 }
+// lstm_fwd_kernel for rows that share per-IMAGE operands (decode: rows_per_image beam rows per image), with one more addend of the
+// gate pre-activations formed in the kernel from a per-image table:
+//   pre[b, n] += sum_r alpha[b, r] * P[(img(b) R + r) 4H + n],   img(b) = b / rows_per_image
+// P[img, r, :] = W_ih^dec[:, :F] v_{img,r} is the decoder-gate contribution of region r, formed ONCE per image
+// (ssc_decode_prepare); since the attended feature vector is sum_r alpha_r v_r (updown_cell.py:156-158) and the gate product is
+// linear in it, sum_r alpha_r P_r IS the att segment of the decoder gate product (updown_cell.py:211-229) - K = R = 36 against a
+// table the image's 100 rows share, instead of K = F = 2048 against the weights in every step: the largest product of a decode
+// step loses 45 % of its k-steps (same value up to fp32 reassociation; SURVEY Appendix A.5 / B: per-image terms are computed
+// once per image).  One 256-thread workgroup per (image, 16 hidden units): the (R x 4 gates x 16 units) table tile goes to LDS
+// once, then the image's rows are taken 16 at a time, one cell per thread, alpha rows through LDS; R <= 128.
+constexpr int IMG_MAXR = 128;
+// (cpw: 16-row chunks per workgroup - a whole image per workgroup at C4's 50 x 100 rows, one chunk each for a single image, so that
+// the grid fills the chip either way; blockIdx.y = image * ceil(chunks / cpw) + chunk group)
+__global__ __launch_bounds__(256) void lstm_fwd_img_kernel(const ssc_lstm_fwd_desc d, const float* __restrict__ alpha, int ldalpha,
+                                                           const float* __restrict__ P, int R, int rpi, int cpw) {
+  __shared__ float sP[IMG_MAXR * 64];
+  __shared__ float sA[16 * (IMG_MAXR + 1)];
+  const int tid = threadIdx.x, rr = tid >> 4, jj = tid & 15;
+  const int H = d.H, H4 = 4 * d.H;
+  const int chunks = (rpi + 15) / 16, groups = (chunks + cpw - 1) / cpw;
+  const int img = blockIdx.y / groups, grp = blockIdx.y - img * groups;
+  const int j0 = blockIdx.x * 16, j = j0 + jj;
+  const int jc = j < H ? j : 0;
+  for (int idx = tid; idx < R * 64; idx += 256) {
+    const int r = idx >> 6, c = idx & 63, g = c >> 4, ju = j0 + (c & 15);
+    sP[idx] = ju < H ? P[((size_t)img * R + r) * H4 + (size_t)g * H + ju] : 0.f;
+  }
+  float bi[4], bh[4], sw[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int n = g * H + jc;
+    bi[g] = d.b_ih ? d.b_ih[n] : 0.f;
+    bh[g] = d.b_hh ? d.b_hh[n] : 0.f;
+    sw[g] = d.sent ? d.wcol[(size_t)n * d.ldwcol] : 0.f;
+  }
+  const int row_end = min(d.B, (img + 1) * rpi);
+  for (int c0 = grp * cpw * 16; c0 < min(rpi, (grp + 1) * cpw * 16); c0 += 16) {
+    const int b = img * rpi + c0 + rr;
+    const bool live = c0 + rr < rpi && b < row_end && j < H;
+    const int bc = live ? b : min(img * rpi, d.B - 1);
+    // this thread's cell operands first (independent of the table term)
+    float a0[4], a1[4], t0[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int n = g * H + jc;
+      a0[g] = d.add0 ? d.add0[(size_t)(d.add0_rows ? d.add0_rows[bc] : (int64_t)bc) * d.ld_add0 + n] : 0.f;
+      a1[g] = d.add1 ? d.add1[(size_t)(bc / d.rows_per_add1) * d.ld_add1 + n] : 0.f;
+      t0[g] = d.nslab > 0 ? d.slabs[(size_t)bc * H4 + n] : 0.f;
+    }
+    const float sv = d.sent ? d.sent[bc] : 0.f;
+    const float cp = d.c_prev ? d.c_prev[(size_t)bc * d.ld_cprev + jc] : 0.f;
+    __syncthreads();   // (the previous chunk's alpha rows have been consumed; first pass: nothing to wait for but sP's writers)
+    for (int idx = tid; idx < 16 * R; idx += 256) {
+      const int row = idx / R, r = idx - row * R, ab = img * rpi + c0 + row;
+      sA[row * (IMG_MAXR + 1) + r] = (c0 + row < rpi && ab < row_end) ? alpha[(size_t)ab * ldalpha + r] : 0.f;
+    }
+    __syncthreads();
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* ar = sA + rr * (IMG_MAXR + 1);
+    for (int r = 0; r < R; ++r) {   // region order: fixed summation order
+      const float a = ar[r];
+      const float* pr = sP + r * 64 + jj;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[g] += a * pr[g * 16];
+    }
+    float pre[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float v = t0[g];
+      for (int sl = 1; sl < d.nslab; ++sl) v += d.slabs[(size_t)sl * d.slab_stride + (size_t)bc * H4 + g * H + jc];
+      v += a0[g];
+      v += a1[g];
+      v += bi[g];
+      v += bh[g];
+      if (d.sent) v += sv * sw[g];
+      v += acc[g];
+      pre[g] = v;
+    }
+    if (live) {
+      const float ig = ssc_sigmoid(pre[0]), fg = ssc_sigmoid(pre[1]), gg = tanhf(pre[2]), og = ssc_sigmoid(pre[3]);
+      const float c = fg * cp + ig * gg;
+      const float h = og * tanhf(c);
+      if (d.gates_out) {
+        float* go = d.gates_out + (size_t)b * H4 + j;
+        go[0] = ig; go[H] = fg; go[2 * H] = gg; go[3 * H] = og;
+      }
+      d.c_out[(size_t)b * d.ld_cout + j] = c;
+      d.h_out[(size_t)b * d.ld_hout + j] = h;
+    }
+  }
+}
+
 // lstm_fwd_kernel that also leaves partial products of its OUTPUT: pout[blockIdx.x][b, n] = sum_{j in the workgroup's 16 units}
 // h[b,j] wp[n,j]  (wp (NP,H) ld ldwp: an nn.Linear weight; NP <= 256).  The encoder LSTM's h feeds fc_mean | fc_log_var
 // (updown_cell.py:196-197) in the same step: as a product of its own that was a 10 us launch on the dependency chain for 1.2 MB
@@ -969,6 +1061,23 @@ extern "C" int ssc_lstm_fwd_z(const ssc_lstm_fwd_desc* d, const float* z, int ld
   if (d->add1 && d->rows_per_add1 <= 0) return SSC_EINVAL;
   if (!z || !wz || Z <= 0 || ldz < Z || ldwz < Z) return SSC_EINVAL;
   SSC_LAUNCH(lstm_fwd_z_kernel, dim3(ssc_cdiv(d->H, 16), ssc_cdiv(d->B, 32)), dim3(512), 0, S(stream), *d, z, ldz, wz, ldwz, Z);
+  SSC_CHECK_LAUNCH();
+  return SSC_OK;
+}
+
+extern "C" int ssc_lstm_fwd_img(const ssc_lstm_fwd_desc* d, const float* alpha, int ldalpha, const float* P, int R,
+                                int rows_per_image, void* stream) {
+  if (!d || d->B <= 0 || d->H <= 0 || !d->c_out || !d->h_out) return SSC_EINVAL;
+  if (d->nslab < 0 || (d->nslab > 0 && !d->slabs)) return SSC_EINVAL;
+  if (d->sent && !d->wcol) return SSC_EINVAL;
+  if (d->add1 && d->rows_per_add1 <= 0) return SSC_EINVAL;
+  if (!alpha || !P || R <= 0 || R > IMG_MAXR || ldalpha < R || rows_per_image <= 0 || d->B % rows_per_image != 0) return SSC_EINVAL;
+  const int nimg = d->B / rows_per_image, chunks = ssc_cdiv(rows_per_image, 16), gx = ssc_cdiv(d->H, 16);
+  int cpw = (int)(((long)gx * nimg * chunks) / 2048);   // ~2048 workgroups when the rows allow it
+  if (cpw < 1) cpw = 1;
+  if (cpw > chunks) cpw = chunks;
+  SSC_LAUNCH(lstm_fwd_img_kernel, dim3(gx, nimg * ssc_cdiv(chunks, cpw)), dim3(256), 0, S(stream), *d, alpha, ldalpha, P, R,
+             rows_per_image, cpw);
   SSC_CHECK_LAUNCH();
   return SSC_OK;
 }

@@ -21,6 +21,7 @@ class ImageContext:
         self.feats = feats
         self.buf = buf
         self.nimg, self.R, _ = feats.shape
+        self.att_table_ready = False   # the per-image attended-feature table is formed by the first step that uses it
 
 
 class DecodeEngine:
@@ -43,6 +44,23 @@ class DecodeEngine:
         self.lib.ssc_decode_prepare(C.byref(self._cfg), C.byref(p), _lib.ptr(feats), nimg, R, _lib.ptr(buf), buf.numel() * 4,
                                     _lib.stream_ptr())
         return ImageContext(feats, buf)
+
+    # The attended-feature term of the decoder gates from a per-image table (ssc_decode_step_desc.att_table): worth its one-off
+    # product per image context once a step has a few hundred rows that share their image sixteen or more at a time (C4: 5000
+    # rows, 100 per image: -13 % per call); below that the K = F segment is cheaper (one image x 100 rows: 3.8 vs 4.7 ms).
+    ATT_TABLE_MIN_ROWS = 512
+    ATT_TABLE_MIN_ROWS_PER_IMAGE = 16
+
+    def _att_table_mode(self, ctx: "ImageContext", G: int, rpi: int) -> int:
+        if ctx.R > 128 or G < self.ATT_TABLE_MIN_ROWS or rpi < self.ATT_TABLE_MIN_ROWS_PER_IMAGE:
+            return 0
+        on = C.c_int(1)   # ssc_debug_set("dec_att_table", 0): A/B switch of include/ssc_debug.h
+        if self.lib._raw_ssc_debug_get(b"dec_att_table", C.byref(on)) != 0 or not on.value:
+            return 0
+        if not ctx.att_table_ready:
+            ctx.att_table_ready = True
+            return 2
+        return 1
 
     def zero_states(self, G: int) -> Dict[str, torch.Tensor]:
         return {k: torch.zeros(G, self.dims.H, dtype=torch.float32, device=self.device) for k in STATE_KEYS}
@@ -80,7 +98,7 @@ class DecodeEngine:
                                    st["c_decoder"].data_ptr(), new["h1"].data_ptr(), new["c1"].data_ptr(),
                                    new["h_decoder"].data_ptr(), new["c_decoder"].data_ptr(), alpha.data_ptr(),
                                    lp.data_ptr() if lp is not None else None, 1 if raw_logits else 0,
-                                   1 if emb_table is not None else 0)
+                                   1 if emb_table is not None else 0, self._att_table_mode(ctx, G, rpi))
         p = self._params()
         if emb_table is not None:  # rows of `emb_table` are the token embeddings themselves (UpDownCell.forward API)
             p.emb = emb_table.data_ptr()

@@ -106,7 +106,7 @@ class DecodeStepDesc(C.Structure):
     _fields_ = [("G", C.c_int), ("R", C.c_int), ("rows_per_image", C.c_int), ("feats", vp), ("imgbuf", vp),
                 ("tokens", vp), ("sentiment", vp), ("eps", vp), ("h1", vp), ("c1", vp), ("hd", vp), ("cd", vp),
                 ("h1_out", vp), ("c1_out", vp), ("hd_out", vp), ("cd_out", vp), ("alpha", vp), ("log_probs", vp),
-                ("raw_logits", C.c_int), ("emb_override", C.c_int)]
+                ("raw_logits", C.c_int), ("emb_override", C.c_int), ("att_table", C.c_int)]
 
 
 # name -> (restype, argtypes).  Every symbol include/ssc.h declares is listed; tests check they all resolve.
@@ -125,10 +125,12 @@ SYMBOLS = {
     "ssc_lstm_fwd": (_i, [C.POINTER(LstmFwdDesc), vp]),
     "ssc_lstm_fwd_z": (_i, [C.POINTER(LstmFwdDesc), vp, _i, vp, _i, _i, vp]),
     "ssc_lstm_fwd_p": (_i, [C.POINTER(LstmFwdDesc), vp, _i, _i, vp, vp]),
+    "ssc_lstm_fwd_img": (_i, [C.POINTER(LstmFwdDesc), vp, _i, vp, _i, _i, vp]),
     "ssc_lstm_bwd_x": (_i, [C.POINTER(LstmBwdDesc), vp, _i, vp, _i, _i, vp]),
     "ssc_lstm_bwd": (_i, [C.POINTER(LstmBwdDesc), vp]),
     "ssc_attn_logits": (_i, [vp, _i, vp, vp, _i, _i, _i, _i, vp, vp]),
     "ssc_attn_fwd": (_i, [vp, _i, vp, vp, vp, vp, _i, _i, _i, _i, _i, vp, vp, vp, _i, vp]),
+    "ssc_attn_weights": (_i, [vp, _i, vp, vp, vp, _i, _i, _i, _i, vp, vp, vp]),
     "ssc_attn_pool": (_i, [vp, vp, _i, _i, _i, _i, vp, _i, vp]),
     "ssc_attn_fwd_pool": (_i, [vp, _i, vp, vp, vp, vp, _i, _i, _i, _i, _i, vp, vp, vp, _i, vp, _i, vp, _i, vp]),
     "ssc_attn_bwd_pool": (_i, [vp, _i, vp, _i, vp, vp, vp, vp, _i, _i, _i, _i, vp, _i, vp, vp, vp, vp, _i, vp, _i, vp, _i, vp]),

@@ -406,3 +406,51 @@ def test_decode_step_token_table_equals_embedding_segment():
     assert maxdiff(a_ids, a_emb) < 1e-6
     for k in ("h1", "c1", "h_decoder", "c_decoder"):
         assert maxdiff(st_ids[k], st_emb[k]) < 2e-6, k
+
+
+def test_decode_step_attended_feature_table_equals_the_feature_segment():
+    """ssc_decode_prepare forms P[img, r, :] = W_ih^dec[:, :F] v_{img,r} once per image and the decoder cell contracts it with the
+    step's attention weights (ssc_lstm_fwd_img) instead of running att = sum_r alpha_r v_r through a K = F segment of the gate
+    product (updown_cell.py:156-158,211-229): the same value by linearity.  Two consecutive steps with the table (default) and
+    without it (ssc_debug_set("dec_att_table", 0)) agree to fp32 level: log-probs, states, attention weights; rows of one image
+    that are not a multiple of the kernel's 16-row chunk, a zero-padded region, R not a multiple of 4."""
+    import ctypes as C
+    from ssc_runtime import lib as L
+    from ssc_runtime.vocab import Vocabulary
+    from var_updown.models import UpDownCaptioner
+    lib = L.load()
+    V, F, E, H, A, Z, R = 300, 64, 40, 48, 24, 8, 7
+    torch.manual_seed(5)
+    m = UpDownCaptioner(Vocabulary.synthetic(V), image_feature_size=F, embedding_size=E, hidden_size=H,
+                        attention_projection_size=A, max_caption_length=8, beam_size=3, z_space=Z, prior_std=1.0,
+                        simple_vae=False, latent_embedding="glove", sentiment_vae=1, senti_prior_multip=0.5,
+                        device=torch.device("cuda")).to("cuda")
+    m.eval()
+    m._engine()
+    dec = m._dec
+    g = torch.Generator().manual_seed(9)
+    nimg, rpi = 5, 21
+    G = nimg * rpi
+    feats = torch.randn(nimg, R, F, generator=g)
+    feats[2, R - 2:] = 0
+    feats = feats.cuda()
+    tok, tok2 = torch.randint(0, V, (G,), generator=g).cuda(), torch.randint(0, V, (G,), generator=g).cuda()
+    sent = torch.randint(-1, 2, (G,), generator=g).float().cuda()
+    eps1, eps2 = torch.randn(G, Z, generator=g).cuda(), torch.randn(G, Z, generator=g).cuda()
+
+    def run(table):
+        lib.ssc_debug_set(b"dec_att_table", table)
+        dec.ATT_TABLE_MIN_ROWS = 1   # (the table path is a large-call optimisation: force it at this toy size)
+        try:
+            ctx = dec.prepare(feats)
+            lp1, st1, a1 = dec.step(ctx, tok, None, sent, eps1)
+            lp2, st2, a2 = dec.step(ctx, tok2, st1, sent, eps2)
+            return lp2.clone(), {k: v.clone() for k, v in st2.items()}, a2.clone()
+        finally:
+            lib.ssc_debug_set(b"dec_att_table", 1)
+            del dec.ATT_TABLE_MIN_ROWS
+
+    with_table, without = run(1), run(0)
+    assert maxdiff(with_table[0], without[0]) < 2e-5 and maxdiff(with_table[2], without[2]) < 1e-6
+    for k in with_table[1]:
+        assert maxdiff(with_table[1][k], without[1][k]) < 2e-6, k
