@@ -128,6 +128,10 @@ typedef struct {
   float* h_out; int ld_hout;
   const int64_t* add0_rows;    /* optional: add0 is indexed by add0_rows[b] instead of b (decode: a per-token table of the
                                 * embedding's gate contribution, row = the beam's last token) */
+  /* decode, beams that share their parent (ssc_decode_step_desc.parent): row b's slab values are read from row slab_rows[b] of
+   * `slabs` (a product formed on the distinct parents only); slabs2: a second slab list with its own row index (0 = row b) */
+  const int* slab_rows;
+  const float* slabs2; int nslab2; size_t slab2_stride; const int* slab2_rows;
 } ssc_lstm_fwd_desc;
 int ssc_lstm_fwd(const ssc_lstm_fwd_desc* d, void* stream);
 /* The same with one more addend formed inside the kernel: pre[b,n] += z[b,:Z] . wz[n,:Z]  (z (B,Z) ld ldz; wz (4H,Z) ld ldwz;
@@ -415,6 +419,12 @@ typedef struct {
   int emb_override;          /* 1: p->emb of THIS call is not the embedding ssc_decode_prepare saw (a caller that hands token
                               * embeddings instead of ids, UpDownCell.forward): the per-token gate table of the image context
                               * is not used, the embedding goes through the gate product */
+  const int64_t* parent;     /* optional (G): after a beam re-ordering, parent[g] = index WITHIN row g's group of `group` consecutive rows of
+                              * the beam it descends from (the back-pointer of cbs.py:231).  Rows of a group with equal parent[] hold
+                              * identical recurrent states, so the products fed only by h1 / hd of the previous step are formed on
+                              * the distinct parents (device-side row lists) and every beam reads its parent's row: at beam 5 /
+                              * per-node 2 a third of the rows of those products go away.  0 = every row on its own */
+  int group;                 /* rows per group (S * beam); used with `parent` */
   int att_table;             /* attended-feature term of the decoder gates (updown_cell.py:156-158,211-229): 0 = weighted feature sum +
                               * K = F segment of the gate product; 1 = from the per-image table P[img,r,:] = W_ih^dec[:, :F] v_r in the
                               * image buffer (ssc_lstm_fwd_img, K = R; R <= 128); 2 = form that table first (once per image

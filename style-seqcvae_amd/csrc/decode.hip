@@ -29,6 +29,7 @@ struct ImgLayout {
 // (5000 x 4800 x 1000 per step at C4: 0.25 ms x 20 steps).  Below it (a handful of rows per step) the segment is cheaper.
 constexpr int DEC_TOKEN_TABLE_MIN_IMAGES = 8;
 }  // namespace
+int ssc_g_dec_dedup = ssc_env_int("SSC_DEC_DEDUP", 1);   // ssc_debug_set("dec_dedup"): products fed only by the parent's states run on distinct parents
 int ssc_g_dec_att_table = ssc_env_int("SSC_DEC_ATT_TABLE", 1);   // ssc_debug_set("dec_att_table"): 0 = attended features + K = F segment in every step
 namespace {
 ImgLayout img_layout(const ssc_model_cfg* c, int nimg, int R) {
@@ -63,6 +64,7 @@ ImgLayout img_layout(const ssc_model_cfg* c, int nimg, int R) {
 
 struct StepLayout {
   size_t emb, q, att, z, attn_logits, proj, wcol, slabs, slab_floats, total;
+  size_t dedup;   // int32: [0] = number of distinct parents, [4 .. 4+G) = their representative rows (ascending), [4+G .. 4+2G) = slot of every row
   int Ep, Ap, Fp, Zp;
 };
 StepLayout step_layout(const ssc_model_cfg* c, int G, int R) {
@@ -76,6 +78,7 @@ StepLayout step_layout(const ssc_model_cfg* c, int G, int R) {
   l.attn_logits = o; o += r64((size_t)G * R);
   l.proj = o; o += r64(c->tied ? (size_t)G * l.Ep : 0);
   l.wcol = o; o += r64((size_t)4 * c->H);
+  l.dedup = o; o += r64((size_t)2 * G + 8);
   size_t skinny = (size_t)33 * G * 4 * c->H;
   size_t full = (size_t)16 * 1024 * 1024;  // 64 MB: split-K slabs of the large GEMMs
   l.slab_floats = skinny > full ? skinny : full;
@@ -109,9 +112,11 @@ int gemm_nt(hipStream_t st, float* ws, size_t ws_floats, std::initializer_list<S
   return ssc_gemm(&d, st);
 }
 
-int gemm_slabs(hipStream_t st, float* ws, size_t ws_floats, std::initializer_list<Seg> segs, int M, int N, int* nslab) {
+int gemm_slabs(hipStream_t st, float* ws, size_t ws_floats, std::initializer_list<Seg> segs, int M, int N, int* nslab,
+               const int* m_count = nullptr, const int* a_rows = nullptr) {
   ssc_gemm_desc d;
   fill_desc(d, segs, M, N);
+  d.m_count = m_count; d.a_rows = a_rows;   // product over the listed A rows only, output rows compact (slab row i <-> a_rows[i])
   return ssc_gemm_slabs_auto(&d, ws, ws_floats, nslab, st);
 }
 
@@ -314,6 +319,48 @@ __global__ void gather_rows_kernel(const float* __restrict__ src, int ld, const 
   dst[(size_t)row * ld + x] = src[srow * ld + x];
 }
 
+// Beams of one group (S * beam consecutive rows) that descend from the same parent hold identical recurrent states after the
+// re-ordering of cbs.py:236-250.  One workgroup: rep = the first row of each (group, parent) class; out[0] = number of classes,
+// out[4 .. ) their representative rows in ascending order, out[4 + n .. ) the class index (slot) of every row.
+__global__ __launch_bounds__(1024) void dedup_rows_kernel(const int64_t* __restrict__ parent, int n, int group, int* __restrict__ out) {
+  __shared__ int part[1024];
+  const int tid = threadIdx.x;
+  int* urows = out + 4;
+  int* slot = out + 4 + n;
+  auto first_of = [&](int g) -> int {   // the first row of g's group with the same parent
+    const int g0 = g - g % group;
+    const int64_t pg = parent[g];
+    for (int k = g0; k < g; ++k)
+      if (parent[k] == pg) return k;
+    return g;
+  };
+  const int per = (n + 1023) / 1024;
+  const int lo = min(tid * per, n), hi = min(lo + per, n);
+  int cnt = 0;
+  for (int g = lo; g < hi; ++g) cnt += first_of(g) == g;
+  part[tid] = cnt;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {  // inclusive scan
+    const int v = tid >= off ? part[tid - off] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  int pos = part[tid] - cnt;
+  for (int g = lo; g < hi; ++g)
+    if (first_of(g) == g) { urows[pos] = g; slot[g] = pos; ++pos; }
+  if (tid == 1023) out[0] = part[1023];
+  for (int i = part[1023] + tid; i < n; i += 1024) urows[i] = 0;   // entries past the count are never used; keep them in range
+  __syncthreads();
+  __threadfence_block();
+  // slots of the non-representative rows: their representative lies EARLIER in the same group; its slot was written above by this
+  // or another thread of the workgroup (global memory, one workgroup: visible after the barrier)
+  for (int g = lo; g < hi; ++g) {
+    const int f = first_of(g);
+    if (f != g) slot[g] = slot[f];
+  }
+}
+
 __global__ void dec_add2d_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb, int cols,
                                  float* __restrict__ o, int ldo) {
   int r = blockIdx.y, x = blockIdx.x * blockDim.x + threadIdx.x;
@@ -389,13 +436,28 @@ extern "C" int ssc_decode_step(const ssc_model_cfg* cfg, const ssc_params* p, co
     SSC_TRY(gemm_nt(st, slabs, l.slab_floats, {{d->feats, F, p->dec_w_ih, p->ld_dec_w_ih, F}}, nimg * R, H4,
                     const_cast<float*>(I) + il.pd, H4));
 
+  // Beams that share their parent: the products fed only by the previous step's h1 / hd run on the distinct parents
+  // (ssc_decode_step_desc.parent).  Used where the token's gate term is not part of the product (token table) and the rows are
+  // many enough for the 128x128 kernels with device-side row lists.
+  const bool dedup = d->parent && d->group > 1 && G % d->group == 0 && il.token_table && !d->emb_override && G >= 512 && ssc_g_dec_dedup;
+  const int* ucount = nullptr; const int* urows = nullptr; const int* slot = nullptr;
+  if (dedup) {
+    int* dd = reinterpret_cast<int*>(W + l.dedup);
+    SSC_LAUNCH(dedup_rows_kernel, dim3(1), dim3(1024), 0, st, d->parent, G, d->group, dd);
+    SSC_CHECK_LAUNCH();
+    ucount = dd; urows = dd + 4; slot = dd + 4 + G;
+  }
+  float* slabs_u = slabs + (size_t)G * H4;   // second product of the decoder gates (distinct parents): behind the first one's rows
+
   // embedding + attention LSTM (updown_captioner.py:430, updown_cell.py:143-148)
   {
     const float* wr = p->att_w_ih + E + F;
     ssc_lstm_fwd_desc f{};
     if (il.token_table && !d->emb_override) {   // the embedding's gate term comes from the per-token table, row = the beam's last token
       SSC_TRY(gemm_slabs(st, slabs, l.slab_floats, {{d->h1, H, I + il.wsum_att, il.Hp, H}, {d->hd, H, wr + H, p->ld_att_w_ih, H}}, G, H4,
-                         &ns));
+                         &ns, ucount, urows));
+      if (dedup && ns != 1) return SSC_EINVAL;   // (row lists and split-K slabs do not combine; G >= 512 never splits)
+      f.slab_rows = slot;
       f.add0 = I + il.emb_gates; f.ld_add0 = H4; f.add0_rows = d->tokens;
     } else {
       SSC_TRY(ssc_embed_gather(p->emb, p->ld_emb, d->tokens, G, E, W + l.emb, l.Ep, st));
@@ -423,7 +485,13 @@ extern "C" int ssc_decode_step(const ssc_model_cfg* cfg, const ssc_params* p, co
                                   G, Z, W + l.z, l.Zp, st));
   // decoder LSTM (updown_cell.py:211-229)
   {
-    if (att_table)   // the attended-feature segment comes from the per-image table inside the cell kernel
+    int ns_u = 0;
+    if (att_table && dedup) {   // hd' segment on the distinct parents, [h1 | z] on every row
+      SSC_TRY(gemm_slabs(st, slabs_u, l.slab_floats - (size_t)G * H4, {{d->hd, H, I + il.wsum_dec, il.Hp, H}}, G, H4, &ns_u, ucount, urows));
+      if (ns_u != 1) return SSC_EINVAL;
+      SSC_TRY(gemm_slabs(st, slabs, (size_t)G * H4, {{d->h1_out, H, p->dec_w_ih + F, p->ld_dec_w_ih, H}, {W + l.z, l.Zp, I + il.wz, il.Zp, Z}},
+                         G, H4, &ns));
+    } else if (att_table)   // the attended-feature segment comes from the per-image table inside the cell kernel
       SSC_TRY(gemm_slabs(st, slabs, l.slab_floats,
                          {{d->h1_out, H, p->dec_w_ih + F, p->ld_dec_w_ih, H}, {d->hd, H, I + il.wsum_dec, il.Hp, H},
                           {W + l.z, l.Zp, I + il.wz, il.Zp, Z}}, G, H4, &ns));
@@ -434,6 +502,7 @@ extern "C" int ssc_decode_step(const ssc_model_cfg* cfg, const ssc_params* p, co
     ssc_lstm_fwd_desc f{};
     f.B = G; f.H = H;
     f.slabs = slabs; f.nslab = ns; f.slab_stride = (size_t)G * H4;
+    if (ns_u) { f.slabs2 = slabs_u; f.nslab2 = ns_u; f.slab2_stride = (size_t)G * H4; f.slab2_rows = slot; }
     f.b_ih = p->dec_b_ih; f.b_hh = p->dec_b_hh;
     if (S) {
       SSC_TRY(ssc_copy_strided(p->dec_w_ih + F + 2 * H, p->ld_dec_w_ih, H4, W + l.wcol, st));

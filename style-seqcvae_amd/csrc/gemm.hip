@@ -797,9 +797,16 @@ __global__ __launch_bounds__(256, 2) void gemm_x3b_kernel(const KArgs a) {
   const int wm = wave >> 1, wn = wave & 1;
   const int half = lane >> 5, l31 = lane & 31;
   int bx, by;
-  tile_order(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x, gridDim.y, a.tile_gm, bx, by);
-  const int n0 = bx * 128, m0 = by * 128, z = blockIdx.z;
+  // With a device-side row count only the first ceil(Meff / 128) tile rows hold work.  The tile order deals a CONTIGUOUS run of its
+  // linear order to each XCD, so ordering the full grid and letting the workgroups of empty rows exit left all work on the
+  // first XCDs (5000 x 4800 x 2400 with 1000 live rows: 552 us against 743 us for all rows - 6 of 8 XCDs idle).  The order is
+  // therefore taken over the LIVE tile rows only; workgroups past them exit.
   const int Meff = a.mcount ? min(a.M, *a.mcount) : a.M;  // uniform per launch
+  const int gy_live = min((int)gridDim.y, (Meff + 127) / 128);
+  const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+  if (lin >= (int)gridDim.x * gy_live) return;
+  tile_order(lin, gridDim.x, gy_live, a.tile_gm, bx, by);
+  const int n0 = bx * 128, m0 = by * 128, z = blockIdx.z;
   if (m0 >= Meff) return;
   const int Kc = a.kcount ? max(0, min(a.seg[0].K, *a.kcount)) : 0;
   int steps_total = a.steps_total, steps_per_split = a.steps_per_split;
@@ -1130,9 +1137,12 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
   const int tid = producer ? (int)threadIdx.x - 256 : (int)threadIdx.x;  // index within the role's threads
   const int lane = tid & 63;
   int bx, by;
-  tile_order(blk_y * grid_x + blk_x, grid_x, grid_y, a.tile_gm, bx, by);
-  const int n0 = bx * TN, m0 = by * TM, z = blk_z;
   const int Meff = (RL && a.mcount) ? min(a.M, *a.mcount) : a.M;  // uniform per launch
+  // (tile order over the LIVE tile rows only: see gemm_x3b_kernel)
+  const int gy_live = min(grid_y, (Meff + TM - 1) / TM);
+  if (blk_y * grid_x + blk_x >= grid_x * gy_live) return;
+  tile_order(blk_y * grid_x + blk_x, grid_x, gy_live, a.tile_gm, bx, by);
+  const int n0 = bx * TN, m0 = by * TM, z = blk_z;
   if (m0 >= Meff) return;
   const int Kc = a.kcount ? max(0, min(a.seg[0].K, *a.kcount)) : 0;
   int steps_total = a.steps_total, steps_per_split = a.steps_per_split;
@@ -2300,7 +2310,7 @@ extern "C" int ssc_set_gemm_mode(int mode) {
 }
 
 // ---- include/ssc_debug.h -----------------------------------------------------------------------------------------
-extern int ssc_g_dec_att_table;   // decode.hip
+extern int ssc_g_dec_att_table, ssc_g_dec_dedup;   // decode.hip
 namespace {
 struct DebugKey { const char* name; int* var; };
 const DebugKey g_debug_keys[] = {
@@ -2318,6 +2328,7 @@ const DebugKey g_debug_keys[] = {
     {"x3w_pf", &g_x3w_pf},           // 64x256 kernels: k-steps in flight in the producers' registers (2 | 3)   (SSC_X3W_PF)
     {"store_wt", &g_store_wt},       // wave-specialised kernels: write-through (sc1) output stores (0 | 1)   (SSC_STORE_WT)
     {"tile_gm", &g_tile_gm},         // tile rows per group of the tile order (8; 0 = row-major)   (SSC_TILE_GM)
+    {"dec_dedup", &ssc_g_dec_dedup},           // decode: parent-state products on the distinct parents of a beam group (1 | 0)   (SSC_DEC_DEDUP)
     {"dec_att_table", &ssc_g_dec_att_table},   // decode: attended-feature term of the decoder gates from a per-image table (1 | 0)   (SSC_DEC_ATT_TABLE)
     {"big_min_m", &g_big_min_m},     // rows from which a product with N >= 512 takes 128x128 tiles (65; 512 = the behaviour until late in round 2)   (SSC_BIG_MIN_M)
 };

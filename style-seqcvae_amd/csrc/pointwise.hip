@@ -107,13 +107,14 @@ __global__ void lstm_fwd_kernel(const ssc_lstm_fwd_desc d) {
   // split-K slabs: summed in index order per gate (a `v += load` loop with a dynamic trip count would serialise one
   // memory latency per slab), U loads per gate in flight.  U follows the slab count: the decode step hands ONE slab (the gate
   // product of 5000 rows is not split) and a fixed batch of 16 made it issue 64 loads per cell for the 4 it needs.
+  const size_t srow = d.slab_rows ? (size_t)d.slab_rows[b] : (size_t)b;   // (decode: the row of this beam's parent in a product over distinct parents)
   auto add_slabs = [&](auto uc) __attribute__((always_inline)) {
     constexpr int U = decltype(uc)::value;
     for (int s0 = 0; s0 < d.nslab; s0 += U) {
       float t[4][U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const float* sp = d.slabs + (size_t)min(s0 + u, d.nslab - 1) * d.slab_stride + (size_t)b * H4 + j;
+        const float* sp = d.slabs + (size_t)min(s0 + u, d.nslab - 1) * d.slab_stride + srow * H4 + j;
 #pragma unroll
         for (int g = 0; g < 4; ++g) t[g][u] = sp[g * H];
       }
@@ -127,6 +128,12 @@ __global__ void lstm_fwd_kernel(const ssc_lstm_fwd_desc d) {
   else if (d.nslab <= 4) add_slabs(std::integral_constant<int, 4>{});
   else if (d.nslab <= 8) add_slabs(std::integral_constant<int, 8>{});
   else add_slabs(std::integral_constant<int, 16>{});
+  if (d.nslab2 > 0) {
+    const size_t r2 = d.slab2_rows ? (size_t)d.slab2_rows[b] : (size_t)b;
+    for (int sl = 0; sl < d.nslab2; ++sl)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) pre[g] += d.slabs2[(size_t)sl * d.slab2_stride + r2 * H4 + g * H + j];
+  }
 #pragma unroll
   for (int g = 0; g < 4; ++g) {  // absent terms add +0.f, which leaves every value unchanged
     float v = pre[g];
@@ -324,7 +331,13 @@ __global__ __launch_bounds__(256) void lstm_fwd_img_kernel(const ssc_lstm_fwd_de
       const int n = g * H + jc;
       a0[g] = d.add0 ? d.add0[(size_t)(d.add0_rows ? d.add0_rows[bc] : (int64_t)bc) * d.ld_add0 + n] : 0.f;
       a1[g] = d.add1 ? d.add1[(size_t)(bc / d.rows_per_add1) * d.ld_add1 + n] : 0.f;
-      t0[g] = d.nslab > 0 ? d.slabs[(size_t)bc * H4 + n] : 0.f;
+      t0[g] = d.nslab > 0 ? d.slabs[(d.slab_rows ? (size_t)d.slab_rows[bc] : (size_t)bc) * H4 + n] : 0.f;
+    }
+    float t2[4] = {0.f, 0.f, 0.f, 0.f};
+    if (d.nslab2 > 0) {
+      const size_t r2 = d.slab2_rows ? (size_t)d.slab2_rows[bc] : (size_t)bc;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) t2[g] = d.slabs2[r2 * H4 + g * H + jc];
     }
     const float sv = d.sent ? d.sent[bc] : 0.f;
     const float cp = d.c_prev ? d.c_prev[(size_t)bc * d.ld_cprev + jc] : 0.f;
@@ -346,7 +359,11 @@ __global__ __launch_bounds__(256) void lstm_fwd_img_kernel(const ssc_lstm_fwd_de
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       float v = t0[g];
-      for (int sl = 1; sl < d.nslab; ++sl) v += d.slabs[(size_t)sl * d.slab_stride + (size_t)bc * H4 + g * H + jc];
+      for (int sl = 1; sl < d.nslab; ++sl)
+        v += d.slabs[(size_t)sl * d.slab_stride + (d.slab_rows ? (size_t)d.slab_rows[bc] : (size_t)bc) * H4 + g * H + jc];
+      v += t2[g];
+      for (int sl = 1; sl < d.nslab2; ++sl)
+        v += d.slabs2[(size_t)sl * d.slab2_stride + (d.slab2_rows ? (size_t)d.slab2_rows[bc] : (size_t)bc) * H4 + g * H + jc];
       v += a0[g];
       v += a1[g];
       v += bi[g];

@@ -79,7 +79,10 @@ class DecodeEngine:
         rpi = G // ctx.nimg
         if states is None:
             states = self.zero_states(G)
-        st = {k: v.contiguous() for k, v in states.items()}
+        # "_parent" (B, S*beam) int64: set by cbs_search after a beam re-ordering - row g descends from beam parent[g] of its group;
+        # beams with the same parent hold identical states (ssc_decode_step_desc.parent: their shared products are formed once)
+        parent = states.get("_parent")
+        st = {k: v.contiguous() for k, v in states.items() if not k.startswith("_")}
         tokens = tokens.to(torch.int64).contiguous()
         eps = eps.to(self.device, torch.float32).contiguous()
         assert tuple(eps.shape) == (G, d.Z), eps.shape
@@ -98,7 +101,10 @@ class DecodeEngine:
                                    st["c_decoder"].data_ptr(), new["h1"].data_ptr(), new["c1"].data_ptr(),
                                    new["h_decoder"].data_ptr(), new["c_decoder"].data_ptr(), alpha.data_ptr(),
                                    lp.data_ptr() if lp is not None else None, 1 if raw_logits else 0,
-                                   1 if emb_table is not None else 0, self._att_table_mode(ctx, G, rpi))
+                                   1 if emb_table is not None else 0,
+                                   parent.data_ptr() if parent is not None and parent.numel() == G else None,
+                                   parent.shape[-1] if parent is not None and parent.numel() == G else 0,
+                                   self._att_table_mode(ctx, G, rpi))
         p = self._params()
         if emb_table is not None:  # rows of `emb_table` are the token embeddings themselves (UpDownCell.forward API)
             p.emb = emb_table.data_ptr()
@@ -156,7 +162,8 @@ def cbs_search(start_predictions: torch.Tensor, start_state, step: Callable, fsm
         _, *rest = t.shape
         return t.view(B, 1, 1, *rest).expand(B, S, beam_size, *rest).reshape(-1, *rest).contiguous()
 
-    state = {k: enlarge(v) for k, v in state.items()}
+    state = {k: enlarge(v) for k, v in state.items() if not k.startswith("_")}
+    state["_parent"] = torch.zeros(B, SB, dtype=torch.int64, device=dev)   # every beam of a group descends from the one start row
     sval = torch.empty(B * S * SB * per_node_beam_size, dtype=torch.float32, device=dev)
     sidx = torch.empty(B * S * SB * per_node_beam_size, dtype=torch.int64, device=dev)
     nsteps = 1
@@ -176,10 +183,13 @@ def cbs_search(start_predictions: torch.Tensor, start_state, step: Callable, fsm
         last_lp = new_lp
         new_state = {}
         for k, v in state.items():  # cbs.py:236-250
+            if k.startswith("_"):
+                continue
             v2 = v.reshape(B * SB, -1).contiguous()
             dst = torch.empty_like(v2)
             lib.ssc_gather_rows(_lib.ptr(v2), v2.stride(0), _lib.ptr(backs[t - 1]), B, SB, v2.size(1), _lib.ptr(dst), st())
             new_state[k] = dst.view_as(v)
+        new_state["_parent"] = backs[t - 1]   # for the step function: which rows of a group now hold the same states
         state = new_state
         nsteps += 1
     allp = torch.empty(B, SB, nsteps, dtype=torch.int64, device=dev)

@@ -454,3 +454,62 @@ def test_decode_step_attended_feature_table_equals_the_feature_segment():
     assert maxdiff(with_table[0], without[0]) < 2e-5 and maxdiff(with_table[2], without[2]) < 1e-6
     for k in with_table[1]:
         assert maxdiff(with_table[1][k], without[1][k]) < 2e-6, k
+
+
+def test_sibling_dedup_and_table_paths_leave_the_search_unchanged():
+    """A whole diverse decode at a size where the large-call paths engage (8 images x 16 samples x beam 5 = 640 rows per step:
+    per-token gate table, per-image attended-feature table, products of the parent's states formed on the distinct parents of each
+    beam group - ssc_decode_step_desc.parent) against the same decode with both switched off: identical captions, and one step's
+    log-probs / states from re-ordered states agree to fp32 level."""
+    from ssc_runtime import lib as L
+    from ssc_runtime.inference import diverse_decode
+    from ssc_runtime.vocab import Vocabulary
+    from var_updown.models import UpDownCaptioner
+    lib = L.load()
+    V, F, E, H, A, Z, R = 400, 64, 40, 64, 24, 8, 9
+    torch.manual_seed(7)
+    m = UpDownCaptioner(Vocabulary.synthetic(V), image_feature_size=F, embedding_size=E, hidden_size=H,
+                        attention_projection_size=A, max_caption_length=7, beam_size=5, z_space=Z, prior_std=1.0,
+                        simple_vae=False, latent_embedding="glove", sentiment_vae=1, senti_prior_multip=0.5,
+                        device=torch.device("cuda")).to("cuda")
+    m.eval()
+    m._engine()
+    dec = m._dec
+    g = torch.Generator().manual_seed(3)
+    nimg, ns, beam = 8, 16, 5
+    feats = torch.randn(nimg, R, F, generator=g).cuda()
+    senti = torch.tensor([1.0, -1.0, 0.0, 1.0, 1.0, -1.0, 0.0, 0.0]).cuda()
+    B = nimg * ns
+    eps = [torch.randn(B, Z, generator=g).cuda()] + [torch.randn(B * beam, Z, generator=g).cuda() for _ in range(8)]
+
+    def run(on):
+        lib.ssc_debug_set(b"dec_dedup", on)
+        lib.ssc_debug_set(b"dec_att_table", on)
+        try:
+            return diverse_decode(dec, feats, senti, ns, beam, 7, 1, eps_steps=[e.clone() for e in eps], early_stop=False)[0].clone()
+        finally:
+            lib.ssc_debug_set(b"dec_dedup", 1)
+            lib.ssc_debug_set(b"dec_att_table", 1)
+
+    assert torch.equal(run(1), run(0))
+    # one step from re-ordered states: groups of 5 rows whose members 0, 2 and 1, 3 share a parent
+    G = B * beam
+    ctx = dec.prepare(feats)
+    tok = torch.randint(2, V, (G,), generator=g).cuda()
+    base = {k: torch.randn(B, 5, H, generator=g).cuda() * 0.3 for k in ("h1", "c1", "h_decoder", "c_decoder")}
+    parent = torch.tensor([0, 3, 0, 3, 4]).repeat(B, 1).cuda()
+    st = {k: v.gather(1, parent.view(B, 5, 1).expand(B, 5, H)).reshape(G, H).contiguous() for k, v in base.items()}
+    sent_rows = senti.view(nimg, 1).expand(nimg, G // nimg).reshape(G).contiguous()
+    outs = []
+    for on in (1, 0):
+        lib.ssc_debug_set(b"dec_dedup", on)
+        try:
+            s_in = dict(st)
+            s_in["_parent"] = parent
+            lp, so, al = dec.step(ctx, tok, s_in, sent_rows, eps[1])
+            outs.append((lp.clone(), {k: v.clone() for k, v in so.items()}, al.clone()))
+        finally:
+            lib.ssc_debug_set(b"dec_dedup", 1)
+    assert maxdiff(outs[0][0], outs[1][0]) < 2e-5 and maxdiff(outs[0][2], outs[1][2]) < 1e-6
+    for k in ("h1", "c1", "h_decoder", "c_decoder"):
+        assert maxdiff(outs[0][1][k], outs[1][1][k]) < 2e-6, k
