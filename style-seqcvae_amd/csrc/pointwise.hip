@@ -297,18 +297,24 @@ __global__ __launch_bounds__(512, 2) void lstm_fwd_z_kernel(const ssc_lstm_fwd_d
 constexpr int IMG_MAXR = 128;
 // (cpw: 16-row chunks per workgroup - a whole image per workgroup at C4's 50 x 100 rows, one chunk each for a single image, so that
 // the grid fills the chip either way; blockIdx.y = image * ceil(chunks / cpw) + chunk group)
-__global__ __launch_bounds__(256) void lstm_fwd_img_kernel(const ssc_lstm_fwd_desc d, const float* __restrict__ alpha, int ldalpha,
+// 512 threads = 16 rows x 32 hidden units: a wave reads two full 128-byte lines per row-gate access (the first form had 16 units
+// per workgroup: 64-byte half lines whose other half a neighbouring workgroup fetched again later - 198 us for ~300 MB).
+__global__ __launch_bounds__(512) void lstm_fwd_img_kernel(const ssc_lstm_fwd_desc d, const float* __restrict__ alpha, int ldalpha,
                                                            const float* __restrict__ P, int R, int rpi, int cpw) {
-  __shared__ float sP[IMG_MAXR * 64];
-  __shared__ float sA[16 * (IMG_MAXR + 1)];
-  const int tid = threadIdx.x, rr = tid >> 4, jj = tid & 15;
+  constexpr int TJ = 32, TR = 16, PW = 4 * TJ;   // units, rows per chunk, table tile width (4 gates x TJ)
+  // dynamic LDS sized by R (R = 36: 20.7 KB)
+  extern __shared__ float img_lds[];
+  float* sP = img_lds;                     // [R][PW]
+  float* sA = img_lds + (size_t)R * PW;    // [TR][R + 1]
+  const int LDA = R + 1;
+  const int tid = threadIdx.x, rr = tid >> 5, jj = tid & 31;
   const int H = d.H, H4 = 4 * d.H;
-  const int chunks = (rpi + 15) / 16, groups = (chunks + cpw - 1) / cpw;
+  const int chunks = (rpi + TR - 1) / TR, groups = (chunks + cpw - 1) / cpw;
   const int img = blockIdx.y / groups, grp = blockIdx.y - img * groups;
-  const int j0 = blockIdx.x * 16, j = j0 + jj;
+  const int j0 = blockIdx.x * TJ, j = j0 + jj;
   const int jc = j < H ? j : 0;
-  for (int idx = tid; idx < R * 64; idx += 256) {
-    const int r = idx >> 6, c = idx & 63, g = c >> 4, ju = j0 + (c & 15);
+  for (int idx = tid; idx < R * PW; idx += 512) {
+    const int r = idx / PW, c = idx - r * PW, g = c / TJ, ju = j0 + (c - g * TJ);
     sP[idx] = ju < H ? P[((size_t)img * R + r) * H4 + (size_t)g * H + ju] : 0.f;
   }
   float bi[4], bh[4], sw[4];
@@ -320,50 +326,49 @@ __global__ __launch_bounds__(256) void lstm_fwd_img_kernel(const ssc_lstm_fwd_de
     sw[g] = d.sent ? d.wcol[(size_t)n * d.ldwcol] : 0.f;
   }
   const int row_end = min(d.B, (img + 1) * rpi);
-  for (int c0 = grp * cpw * 16; c0 < min(rpi, (grp + 1) * cpw * 16); c0 += 16) {
+  for (int c0 = grp * cpw * TR; c0 < min(rpi, (grp + 1) * cpw * TR); c0 += TR) {
     const int b = img * rpi + c0 + rr;
     const bool live = c0 + rr < rpi && b < row_end && j < H;
-    const int bc = live ? b : min(img * rpi, d.B - 1);
+    const int bc = (c0 + rr < rpi && b < row_end) ? b : min(img * rpi, d.B - 1);
     // this thread's cell operands first (independent of the table term)
     float a0[4], a1[4], t0[4];
+    const size_t r1 = d.slab_rows ? (size_t)d.slab_rows[bc] : (size_t)bc;
+    const size_t r2 = d.slab2_rows ? (size_t)d.slab2_rows[bc] : (size_t)bc;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int n = g * H + jc;
       a0[g] = d.add0 ? d.add0[(size_t)(d.add0_rows ? d.add0_rows[bc] : (int64_t)bc) * d.ld_add0 + n] : 0.f;
       a1[g] = d.add1 ? d.add1[(size_t)(bc / d.rows_per_add1) * d.ld_add1 + n] : 0.f;
-      t0[g] = d.nslab > 0 ? d.slabs[(d.slab_rows ? (size_t)d.slab_rows[bc] : (size_t)bc) * H4 + n] : 0.f;
+      t0[g] = d.nslab > 0 ? d.slabs[r1 * H4 + n] : 0.f;
     }
     float t2[4] = {0.f, 0.f, 0.f, 0.f};
     if (d.nslab2 > 0) {
-      const size_t r2 = d.slab2_rows ? (size_t)d.slab2_rows[bc] : (size_t)bc;
 #pragma unroll
       for (int g = 0; g < 4; ++g) t2[g] = d.slabs2[r2 * H4 + g * H + jc];
     }
     const float sv = d.sent ? d.sent[bc] : 0.f;
     const float cp = d.c_prev ? d.c_prev[(size_t)bc * d.ld_cprev + jc] : 0.f;
-    __syncthreads();   // (the previous chunk's alpha rows have been consumed; first pass: nothing to wait for but sP's writers)
-    for (int idx = tid; idx < 16 * R; idx += 256) {
+    __syncthreads();   // (the previous chunk's alpha rows have been consumed; first pass: sP's writers)
+    for (int idx = tid; idx < TR * R; idx += 512) {
       const int row = idx / R, r = idx - row * R, ab = img * rpi + c0 + row;
-      sA[row * (IMG_MAXR + 1) + r] = (c0 + row < rpi && ab < row_end) ? alpha[(size_t)ab * ldalpha + r] : 0.f;
+      sA[row * LDA + r] = (c0 + row < rpi && ab < row_end) ? alpha[(size_t)ab * ldalpha + r] : 0.f;
     }
     __syncthreads();
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    const float* ar = sA + rr * (IMG_MAXR + 1);
+    const float* ar = sA + rr * LDA;
     for (int r = 0; r < R; ++r) {   // region order: fixed summation order
       const float a = ar[r];
-      const float* pr = sP + r * 64 + jj;
+      const float* pr = sP + r * PW + jj;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) acc[g] += a * pr[g * 16];
+      for (int g = 0; g < 4; ++g) acc[g] += a * pr[g * TJ];
     }
     float pre[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       float v = t0[g];
-      for (int sl = 1; sl < d.nslab; ++sl)
-        v += d.slabs[(size_t)sl * d.slab_stride + (d.slab_rows ? (size_t)d.slab_rows[bc] : (size_t)bc) * H4 + g * H + jc];
+      for (int sl = 1; sl < d.nslab; ++sl) v += d.slabs[(size_t)sl * d.slab_stride + r1 * H4 + g * H + jc];
       v += t2[g];
-      for (int sl = 1; sl < d.nslab2; ++sl)
-        v += d.slabs2[(size_t)sl * d.slab2_stride + (d.slab2_rows ? (size_t)d.slab2_rows[bc] : (size_t)bc) * H4 + g * H + jc];
+      for (int sl = 1; sl < d.nslab2; ++sl) v += d.slabs2[(size_t)sl * d.slab2_stride + r2 * H4 + g * H + jc];
       v += a0[g];
       v += a1[g];
       v += bi[g];
@@ -383,6 +388,157 @@ __global__ __launch_bounds__(256) void lstm_fwd_img_kernel(const ssc_lstm_fwd_de
       d.c_out[(size_t)b * d.ld_cout + j] = c;
       d.h_out[(size_t)b * d.ld_hout + j] = h;
     }
+  }
+}
+
+// The same cell with the table contraction on the fp32 matrix cores (v_mfma_f32_16x16x4_f32; fp32 products and sums, fixed order).
+// One workgroup of eight waves per (16 hidden units, image[, row group]); the waves take the 16-row chunks round robin (one each at
+// C4's 100 rows per image) and issue their chunk's operand loads before the tile is staged:
+//   A operand = the image's table tile transposed, P[img][r][gate*H + u] for 16 units x 4 gates x R regions, staged once per
+//               workgroup in LDS (row stride 80 floats: the four k-rows of a k-step fall on disjoint banks) - one ds_read per MFMA;
+//               rows R and R + 1 of the tile hold b_ih + b_hh and the sentiment column, contracted with 1 and the row's sentiment;
+//   B operand = alpha^T of the 16-row chunk (KS = ceil((R + 2) / 4) values per lane, read straight from global - alpha is L2-resident);
+//   D[unit][row]: lane l holds units 4 * (l / 16) .. + 3 of row l % 16 for each gate -> the lane's 16 accumulators are exactly the
+//               four gate pre-activations of four adjacent units of one row, so the cell update follows in registers and every
+//               slab / state access is a float4 (H % 4 == 0, 16-byte aligned rows - checked by the caller).
+// The VALU form above spent ~100 of its 190 us at C4 (5000 rows, R = 36) on LDS reads for the contraction (5 reads per 4 FMAs).
+// (A first matrix-core form held the table tile in 36 registers per lane, one wave per image: ~200 registers, two waves per SIMD,
+// 96 us; with the next chunk's operands prefetched by hand 114 us.)
+// MODE 0: one slab read by row index, no second slab; MODE 1: + a second slab read through slab2_rows (the sibling-dedup decode
+// step); MODE 2: every option of the descriptor.  Modes 0 and 1 have NO conditional loads: hipcc turns `p ? *p : 0` into a branch
+// with s_waitcnt vmcnt(0) at the join, which serialises the loads of a lane (the first forms of this kernel: 120-135 us).
+template <int KS, int MODE>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(KS <= 17 && MODE < 2 ? 4 : 2, 8))) void lstm_fwd_img_mfma_kernel(
+    const ssc_lstm_fwd_desc d, const float* __restrict__ alpha, int ldalpha, const float* __restrict__ P, int R, int rpi, int cpw) {
+  constexpr int LDP = 80, NW = 8;
+  constexpr bool RARE = MODE == 2;
+  extern __shared__ float img_lds[];   // [4 * KS][LDP], rows >= R + 2 zero
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const int H = d.H, H4 = 4 * d.H;
+  const int ub = blockIdx.x;
+  const int chunks = (rpi + 15) / 16, groups = (chunks + cpw - 1) / cpw;
+  const int img = blockIdx.y / groups, grp = blockIdx.y - img * groups;
+  const int u = ub * 16 + 4 * lk;   // this lane's four units
+  const bool uok = u < H;            // (H % 4 == 0: all four or none)
+  const int uc = uok ? u : 0;
+  const int row_end = min(d.B, (img + 1) * rpi);
+  const int c_end = min(rpi, (grp + 1) * cpw * 16);
+  const float* sentp = d.sent ? d.sent : alpha;   // (always a readable address: the value is dropped when there is no sentiment)
+  const float sflag = d.sent ? 1.f : 0.f;
+  struct Ops { ssc_f32x4v pre[4], t2[4], cp; float al[KS], sv; int b, bc; bool rok; size_t r1, r2; };
+  // a chunk's operands: issued before anything that waits (the tile staging and its barrier for a wave's first chunk)
+  auto issue = [&](int c0, Ops& o) {
+    o.b = img * rpi + c0 + li;
+    o.rok = c0 + li < rpi && o.b < row_end;
+    o.bc = o.rok ? o.b : img * rpi;
+    if (MODE == 2) {
+      o.r1 = d.slab_rows ? (size_t)d.slab_rows[o.bc] : (size_t)o.bc;
+      o.r2 = d.slab2_rows ? (size_t)d.slab2_rows[o.bc] : (size_t)o.bc;
+    } else {
+      o.r1 = (size_t)o.bc;
+      o.r2 = MODE == 1 ? (size_t)d.slab2_rows[o.bc] : 0;
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int n = g * H + uc;
+      if (MODE == 2) o.pre[g] = d.nslab > 0 ? *reinterpret_cast<const ssc_f32x4v*>(d.slabs + o.r1 * H4 + n) : ssc_f32x4v{0.f, 0.f, 0.f, 0.f};
+      else o.pre[g] = *reinterpret_cast<const ssc_f32x4v*>(d.slabs + o.r1 * H4 + n);
+    }
+    if (MODE == 2) o.cp = d.c_prev ? *reinterpret_cast<const ssc_f32x4v*>(d.c_prev + (size_t)o.bc * d.ld_cprev + uc) : ssc_f32x4v{0.f, 0.f, 0.f, 0.f};
+    else o.cp = *reinterpret_cast<const ssc_f32x4v*>(d.c_prev + (size_t)o.bc * d.ld_cprev + uc);
+    const float* ap = alpha + (size_t)o.bc * ldalpha;
+    o.sv = sentp[o.bc];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int r = ks * 4 + lk;
+      o.al[ks] = ap[min(r, R - 1)];   // (raw: masked in `finish`, after the waits of the tile staging)
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int n = g * H + uc;
+      if (MODE == 2) o.t2[g] = d.nslab2 > 0 ? *reinterpret_cast<const ssc_f32x4v*>(d.slabs2 + o.r2 * H4 + n) : ssc_f32x4v{0.f, 0.f, 0.f, 0.f};
+      else if (MODE == 1) o.t2[g] = *reinterpret_cast<const ssc_f32x4v*>(d.slabs2 + o.r2 * H4 + n);
+    }
+  };
+  Ops o;
+  int c0 = (grp * cpw + wave) * 16;
+  if (c0 < c_end) issue(c0, o);
+  // the tile: rows < R from the table, row R the bias sum, row R + 1 the sentiment column, the rest zero
+  {
+    const int c = lane, g = c >> 4, ua = ub * 16 + (c & 15);
+    const bool cok = ua < H;
+    const size_t n = (size_t)g * H + (cok ? ua : 0);
+    const float* pi = P + (size_t)img * R * H4 + n;
+    constexpr int NIT = (4 * KS + NW - 1) / NW;
+    float v[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) v[it] = pi[(size_t)min(wave + it * NW, R - 1) * H4];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int r = wave + it * NW;
+      if (r < 4 * KS && r != R && r != R + 1) img_lds[r * LDP + c] = (r < R && cok) ? v[it] : 0.f;
+    }
+    if (wave == 0) {
+      const float bs = (d.b_ih ? d.b_ih[n] : 0.f) + (d.b_hh ? d.b_hh[n] : 0.f);
+      img_lds[R * LDP + c] = cok ? bs : 0.f;
+    } else if (wave == 1) {
+      img_lds[(R + 1) * LDP + c] = (d.sent && cok) ? d.wcol[n * d.ldwcol] : 0.f;
+    }
+  }
+  __syncthreads();
+  const float* sp = img_lds + lk * LDP + li;
+  while (c0 < c_end) {
+    // alpha^T with the rows beyond R: 1 for the bias row, the sentiment for its column, 0 elsewhere (arithmetic, not a select
+    // around the load: the compiler sinks a load whose value is used on one side only into a branch)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int r = ks * 4 + lk;
+      const float m = (r < R && o.rok) ? 1.f : 0.f;
+      o.al[ks] = o.al[ks] * m + (r == R ? 1.f : r == R + 1 ? o.sv * sflag : 0.f);
+    }
+    ssc_f32x4v acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = ssc_f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(sp[ks * 4 * LDP + g * 16], o.al[ks], acc[g], 0, 0, 0);
+      if ((ks & 1) == 1) __builtin_amdgcn_sched_barrier(0);   // (keeps the tile reads two k-steps ahead at most: registers)
+    }
+    const int b = o.b, bc = o.bc;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int n = g * H + uc;
+      if (MODE >= 1) o.pre[g] += o.t2[g];
+      if (RARE) {   // split-K slabs beyond the first, the per-token and per-image rows
+        for (int sl = 1; sl < d.nslab; ++sl) o.pre[g] += *reinterpret_cast<const ssc_f32x4v*>(d.slabs + (size_t)sl * d.slab_stride + o.r1 * H4 + n);
+        for (int sl = 1; sl < d.nslab2; ++sl) o.pre[g] += *reinterpret_cast<const ssc_f32x4v*>(d.slabs2 + (size_t)sl * d.slab2_stride + o.r2 * H4 + n);
+        if (d.add0) o.pre[g] += *reinterpret_cast<const ssc_f32x4v*>(d.add0 + (size_t)(d.add0_rows ? d.add0_rows[bc] : (int64_t)bc) * d.ld_add0 + n);
+        if (d.add1) o.pre[g] += *reinterpret_cast<const ssc_f32x4v*>(d.add1 + (size_t)(bc / d.rows_per_add1) * d.ld_add1 + n);
+      }
+      o.pre[g] += acc[g];
+    }
+    if (o.rok && uok) {
+      ssc_f32x4v ig, fg, gg, og, c, h;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        ig[v] = ssc_sigmoid(o.pre[0][v]); fg[v] = ssc_sigmoid(o.pre[1][v]); gg[v] = tanhf(o.pre[2][v]); og[v] = ssc_sigmoid(o.pre[3][v]);
+        c[v] = fg[v] * o.cp[v] + ig[v] * gg[v];
+        h[v] = og[v] * tanhf(c[v]);
+      }
+      if (RARE && d.gates_out) {
+        float* go = d.gates_out + (size_t)b * H4 + u;
+        *reinterpret_cast<ssc_f32x4v*>(go) = ig;
+        *reinterpret_cast<ssc_f32x4v*>(go + H) = fg;
+        *reinterpret_cast<ssc_f32x4v*>(go + 2 * H) = gg;
+        *reinterpret_cast<ssc_f32x4v*>(go + 3 * H) = og;
+      }
+      *reinterpret_cast<ssc_f32x4v*>(d.c_out + (size_t)b * d.ld_cout + u) = c;
+      *reinterpret_cast<ssc_f32x4v*>(d.h_out + (size_t)b * d.ld_hout + u) = h;
+    }
+    c0 += NW * 16;
+    if (c0 < c_end) issue(c0, o);
   }
 }
 
@@ -1082,6 +1238,8 @@ extern "C" int ssc_lstm_fwd_z(const ssc_lstm_fwd_desc* d, const float* z, int ld
   return SSC_OK;
 }
 
+int ssc_g_img_mfma = ssc_env_int("SSC_IMG_MFMA", 1);   // 0: the VALU form of lstm_fwd_img_kernel (the fallback for H % 4 != 0)
+int ssc_g_img_cpw = ssc_env_int("SSC_IMG_CPW", 0);   // tuning: 16-row chunks per workgroup of lstm_fwd_img_kernel (0 = by grid size)
 extern "C" int ssc_lstm_fwd_img(const ssc_lstm_fwd_desc* d, const float* alpha, int ldalpha, const float* P, int R,
                                 int rows_per_image, void* stream) {
   if (!d || d->B <= 0 || d->H <= 0 || !d->c_out || !d->h_out) return SSC_EINVAL;
@@ -1089,11 +1247,51 @@ extern "C" int ssc_lstm_fwd_img(const ssc_lstm_fwd_desc* d, const float* alpha, 
   if (d->sent && !d->wcol) return SSC_EINVAL;
   if (d->add1 && d->rows_per_add1 <= 0) return SSC_EINVAL;
   if (!alpha || !P || R <= 0 || R > IMG_MAXR || ldalpha < R || rows_per_image <= 0 || d->B % rows_per_image != 0) return SSC_EINVAL;
-  const int nimg = d->B / rows_per_image, chunks = ssc_cdiv(rows_per_image, 16), gx = ssc_cdiv(d->H, 16);
+  const int nimg = d->B / rows_per_image, chunks = ssc_cdiv(rows_per_image, 16);
+  // matrix-core form: every row access is a float4
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  const bool vec = d->H % 4 == 0 && al16(d->slabs) && al16(d->slabs2) && al16(d->c_prev) && al16(d->c_out) && al16(d->h_out) &&
+                   al16(d->gates_out) && al16(d->add0) && al16(d->add1) && al16(d->b_ih) && al16(d->b_hh) && d->ld_cprev % 4 == 0 &&
+                   d->ld_cout % 4 == 0 && d->ld_hout % 4 == 0 && d->ld_add0 % 4 == 0 && d->ld_add1 % 4 == 0 &&
+                   d->slab_stride % 4 == 0 && d->slab2_stride % 4 == 0;
+  if (vec && ssc_g_img_mfma) {
+    const int gx = ssc_cdiv(d->H, 16);
+    int cpw = (int)(((long)gx * nimg * chunks) / 4096);   // >= ~4096 workgroups when the rows allow it (the table tile is staged per row group)
+    if (ssc_g_img_cpw > 0) cpw = ssc_g_img_cpw;
+    cpw = std::min(std::max(cpw, 8), std::max(chunks, 8));   // (eight waves, a chunk each)
+    const dim3 grid(gx, nimg * ssc_cdiv(chunks, cpw));
+    // (mode 2: split-K slabs beyond the first, per-token / per-image rows, saved gates, a missing state or slab - the decode step
+    // uses none of them)
+    const bool rare = d->nslab != 1 || d->nslab2 > 1 || d->add0 || d->add1 || d->gates_out || d->slab_rows || !d->c_prev ||
+                      (d->nslab2 == 1 && !d->slab2_rows);
+    const int mode = rare ? 2 : d->nslab2 == 1 ? 1 : 0;
+#define SSC_IMG_LAUNCH(KS)                                                                                                           \
+  do {                                                                                                                             \
+    const size_t lds = (size_t)4 * KS * 80 * sizeof(float);                                                                        \
+    const void* fn = mode == 2 ? (const void*)lstm_fwd_img_mfma_kernel<KS, 2>                                                      \
+                               : mode == 1 ? (const void*)lstm_fwd_img_mfma_kernel<KS, 1> : (const void*)lstm_fwd_img_mfma_kernel<KS, 0>; \
+    if (lds > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return SSC_EHIP; \
+    if (mode == 2) SSC_LAUNCH((lstm_fwd_img_mfma_kernel<KS, 2>), grid, dim3(512), lds, S(stream), *d, alpha, ldalpha, P, R, rows_per_image, cpw); \
+    else if (mode == 1) SSC_LAUNCH((lstm_fwd_img_mfma_kernel<KS, 1>), grid, dim3(512), lds, S(stream), *d, alpha, ldalpha, P, R, rows_per_image, cpw); \
+    else SSC_LAUNCH((lstm_fwd_img_mfma_kernel<KS, 0>), grid, dim3(512), lds, S(stream), *d, alpha, ldalpha, P, R, rows_per_image, cpw); \
+  } while (0)
+    if (R <= 38) SSC_IMG_LAUNCH(10);   // (KS k-steps of 4 cover the R regions + the bias and sentiment rows)
+    else if (R <= 66) SSC_IMG_LAUNCH(17);
+    else SSC_IMG_LAUNCH(33);
+#undef SSC_IMG_LAUNCH
+    SSC_CHECK_LAUNCH();
+    return SSC_OK;
+  }
+  const int gx = ssc_cdiv(d->H, 32);
   int cpw = (int)(((long)gx * nimg * chunks) / 2048);   // ~2048 workgroups when the rows allow it
+  if (ssc_g_img_cpw > 0) cpw = ssc_g_img_cpw;
   if (cpw < 1) cpw = 1;
   if (cpw > chunks) cpw = chunks;
-  SSC_LAUNCH(lstm_fwd_img_kernel, dim3(gx, nimg * ssc_cdiv(chunks, cpw)), dim3(256), 0, S(stream), *d, alpha, ldalpha, P, R,
+  const size_t lds = ((size_t)R * 128 + 16 * (size_t)(R + 1)) * sizeof(float);   // <= 64 KB + 8 KB at R = 128
+  if (lds > 64 * 1024) {
+    if (hipFuncSetAttribute((const void*)lstm_fwd_img_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) return SSC_EHIP;
+  }
+  SSC_LAUNCH(lstm_fwd_img_kernel, dim3(gx, nimg * ssc_cdiv(chunks, cpw)), dim3(512), lds, S(stream), *d, alpha, ldalpha, P, R,
              rows_per_image, cpw);
   SSC_CHECK_LAUNCH();
   return SSC_OK;
