@@ -29,6 +29,7 @@ struct ImgLayout {
 // (5000 x 4800 x 1000 per step at C4: 0.25 ms x 20 steps).  Below it (a handful of rows per step) the segment is cheaper.
 constexpr int DEC_TOKEN_TABLE_MIN_IMAGES = 8;
 }  // namespace
+int ssc_g_beam_reg = ssc_env_int("SSC_BEAM_REG", 1);   // 0: the LDS-staged selection kernel for every vocabulary size
 int ssc_g_dec_dedup = ssc_env_int("SSC_DEC_DEDUP", 1);   // ssc_debug_set("dec_dedup"): products fed only by the parent's states run on distinct parents
 int ssc_g_dec_att_table = ssc_env_int("SSC_DEC_ATT_TABLE", 1);   // ssc_debug_set("dec_att_table"): 0 = attended features + K = F segment in every step
 namespace {
@@ -257,6 +258,78 @@ __global__ __launch_bounds__(256) void beam_row_topk_kernel(const float* __restr
     }
     best = block_best(best, sh);
     if (threadIdx.x == 0) {
+      sval[base + n] = best.v;
+      sidx[base + n] = best.i;
+    }
+    prev = best;
+  }
+}
+
+// The same selection with the row in REGISTERS (V <= 256 * BEAM_REG_NV): thread t holds v = t, t + 256, ... - the assignment of
+// row_prepare, so the maxima, the sums (same per-thread order, same block reduction) and therefore lse and lp[v] - lse are
+// bit-identical to it.  One memory round trip per row (all loads of a thread in flight at once), no LDS row: the staged form
+// took five dependent load batches, four passes over a 40 KB LDS row and three workgroups per CU (160 us for 5000 x 10000).
+constexpr int BEAM_REG_NV = 40;
+template <bool NORM>
+__global__ __launch_bounds__(256) void beam_row_topk_reg_kernel(const float* __restrict__ lp, int ldlp,
+                                                                const uint8_t* __restrict__ fsm,
+                                                                const int64_t* __restrict__ last_pred, int S, int V, int beam,
+                                                                int per_node, int end_index, float* __restrict__ sval,
+                                                                int64_t* __restrict__ sidx) {
+  __shared__ Cand sh[4];
+  __shared__ float shr[16];
+  const int g = blockIdx.x, i = blockIdx.y, t = threadIdx.x;
+  const int b = g / (S * beam), s = (g / beam) % S, k = g % beam;
+  const uint8_t* m = fsm ? fsm + (((size_t)b * S + s) * S + i) * V : nullptr;
+  const bool ended = last_pred[g] == end_index;   // workgroup-uniform; an ended beam never looks at its row
+  const float* row = lp + (size_t)g * ldlp;
+  float x[BEAM_REG_NV];
+  float lse = 0.f;
+  if (!ended) {
+#pragma unroll
+    for (int u = 0; u < BEAM_REG_NV; ++u) x[u] = row[min(t + u * 256, V - 1)];
+    if (NORM) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int u = 0; u < BEAM_REG_NV; ++u)
+        if (t + u * 256 < V) mx = fmaxf(mx, x[u]);
+      mx = dec_block_reduce(mx, shr, true);
+      float sum = 0.f;
+#pragma unroll
+      for (int u = 0; u < BEAM_REG_NV; ++u)
+        if (t + u * 256 < V) sum += expf(x[u] - mx);
+      sum = dec_block_reduce(sum, shr, false);
+      lse = mx + logf(sum);
+    }
+    if (NORM) {
+#pragma unroll
+      for (int u = 0; u < BEAM_REG_NV; ++u) x[u] -= lse;
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < BEAM_REG_NV; ++u) x[u] = t + u * 256 == end_index ? 0.f : -INFINITY;
+  }
+  if (m) {   // (uniform; the mask bytes of a thread all in flight at once)
+    uint8_t mk[BEAM_REG_NV];
+#pragma unroll
+    for (int u = 0; u < BEAM_REG_NV; ++u) mk[u] = m[min(t + u * 256, V - 1)];
+#pragma unroll
+    for (int u = 0; u < BEAM_REG_NV; ++u)
+      if (!mk[u]) x[u] = -1e20f;
+  }
+  const size_t base = ((((size_t)b * S + i) * S + s) * beam + k) * per_node;   // scratch layout (b, i, s, k, n)
+  Cand prev{INFINITY, -1};
+  for (int n = 0; n < per_node; ++n) {
+    Cand best{-INFINITY, -1};
+#pragma unroll
+    for (int u = 0; u < BEAM_REG_NV; ++u) {
+      const int v = t + u * 256;
+      const float y = x[u];
+      const bool after_prev = (prev.i < 0) || (y < prev.v) || (y == prev.v && v > prev.i);
+      if (v < V && after_prev && (best.i < 0 || better(y, v, best))) best = Cand{y, v};
+    }
+    best = block_best(best, sh);
+    if (t == 0) {
       sval[base + n] = best.v;
       sidx[base + n] = best.i;
     }
@@ -547,7 +620,14 @@ int beam_step_impl(bool norm, const float* lp, int ldlp, const uint8_t* fsm, con
     return SSC_EINVAL;
   const int staged = norm && (size_t)V * sizeof(float) <= BEAM_STAGE_MAX;
   const size_t lds = staged ? (size_t)V * sizeof(float) : 0;
-  if (norm)
+  if (V <= 256 * BEAM_REG_NV && ssc_g_beam_reg) {
+    if (norm)
+      SSC_LAUNCH(beam_row_topk_reg_kernel<true>, dim3(B * S * beam, S), dim3(256), 0, st, lp, ldlp, fsm, last_pred, S, V, beam,
+                 per_node, end_index, scratch_val, scratch_idx);
+    else
+      SSC_LAUNCH(beam_row_topk_reg_kernel<false>, dim3(B * S * beam, S), dim3(256), 0, st, lp, ldlp, fsm, last_pred, S, V, beam,
+                 per_node, end_index, scratch_val, scratch_idx);
+  } else if (norm)
     SSC_LAUNCH(beam_row_topk_kernel<true>, dim3(B * S * beam, S), dim3(256), lds, st, lp, ldlp, fsm, last_pred, S, V, beam,
                        per_node, end_index, scratch_val, scratch_idx, staged);
   else

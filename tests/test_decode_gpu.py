@@ -154,10 +154,13 @@ def test_full_size_c4_decode_steps_two_kernel_paths_agree():
     assert maxdiff(torch.logsumexp(x[1], 1), torch.zeros(G)) < 1e-4
 
 
-@pytest.mark.parametrize("B,S,V,beam,per_node", [(3, 1, 50, 3, 2), (2, 3, 200, 2, 2), (2, 2, 20000, 3, 1)])
+@pytest.mark.parametrize("B,S,V,beam,per_node", [(3, 1, 50, 3, 2), (2, 3, 200, 2, 2), (2, 2, 20000, 3, 1), (2, 2, 10000, 3, 2),
+                                                 (1, 2, 777, 2, 2), (2, 1, 10240, 2, 2)])
 def test_beam_selection_from_raw_logits_is_bit_identical(B, S, V, beam, per_node):
     """ssc_beam_first_logits / ssc_beam_step_logits (log-sum-exp inside the selection kernel; the V = 20000 case does not
-    fit the LDS staging and reads the row from HBM) against ssc_log_softmax followed by ssc_beam_first / ssc_beam_step."""
+    fit the LDS staging and reads the row from HBM) against ssc_log_softmax followed by ssc_beam_first / ssc_beam_step; for
+    V <= 10240 the later steps run with the row in registers (beam_row_topk_reg_kernel) - compared with the LDS-staged kernel
+    through the diagnostics switch."""
     from ssc_runtime import lib as L
     lib = L.load()
     g = torch.Generator().manual_seed(B * 100 + V)
@@ -182,17 +185,23 @@ def test_beam_selection_from_raw_logits_is_bit_identical(B, S, V, beam, per_node
     last[1] = 1                      # one ended beam (end_index = 1)
     last_lp = outs[0][1]
     res = []
-    for fn, src in ((lib.ssc_beam_step, lp), (lib.ssc_beam_step_logits, logits)):
-        pred = torch.empty(B, S * beam, dtype=torch.int64, device=dev_)
-        nlp = torch.empty(B, S, beam, device=dev_)
-        back = torch.empty(B, S * beam, dtype=torch.int64, device=dev_)
-        sval = torch.empty(B * S * S * beam * per_node, device=dev_)
-        sidx = torch.empty(B * S * S * beam * per_node, dtype=torch.int64, device=dev_)
-        fn(L.ptr(src), V, L.ptr(fsm), L.ptr(last), L.ptr(last_lp), B, S, V, beam, per_node, 1, L.ptr(pred), L.ptr(nlp), L.ptr(back),
-           L.ptr(sval), L.ptr(sidx), L.stream_ptr())
-        res.append((pred.clone(), nlp.clone(), back.clone()))
-    for a, b in zip(res[0], res[1]):
-        assert torch.equal(a, b)
+    try:
+        for reg in (1, 0):
+            lib.ssc_debug_set(b"beam_reg", reg)
+            for fn, src in ((lib.ssc_beam_step, lp), (lib.ssc_beam_step_logits, logits)):
+                pred = torch.empty(B, S * beam, dtype=torch.int64, device=dev_)
+                nlp = torch.empty(B, S, beam, device=dev_)
+                back = torch.empty(B, S * beam, dtype=torch.int64, device=dev_)
+                sval = torch.empty(B * S * S * beam * per_node, device=dev_)
+                sidx = torch.empty(B * S * S * beam * per_node, dtype=torch.int64, device=dev_)
+                fn(L.ptr(src), V, L.ptr(fsm), L.ptr(last), L.ptr(last_lp), B, S, V, beam, per_node, 1, L.ptr(pred), L.ptr(nlp),
+                   L.ptr(back), L.ptr(sval), L.ptr(sidx), L.stream_ptr())
+                res.append((pred.clone(), nlp.clone(), back.clone(), sval.clone(), sidx.clone()))
+    finally:
+        lib.ssc_debug_set(b"beam_reg", 1)
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            assert torch.equal(a, b)
 
 
 def test_trivial_fsm_none_equals_all_ones_mask():
