@@ -36,7 +36,7 @@ extern "C" {
 
 #define SSC_MAX_SEG 6
 
-int ssc_version(void);              /* ABI version (this header: 2) */
+int ssc_version(void);              /* ABI version (this header: 3) */
 int ssc_last_hip_error(void);       /* last hipError_t observed by this thread */
 const char* ssc_arch(void);         /* "gfx950" */
 
@@ -132,6 +132,8 @@ typedef struct {
    * `slabs` (a product formed on the distinct parents only); slabs2: a second slab list with its own row index (0 = row b) */
   const int* slab_rows;
   const float* slabs2; int nslab2; size_t slab2_stride; const int* slab2_rows;
+  const int* c_prev_rows;      /* optional: row b's previous cell state is row c_prev_rows[b] of c_prev (decode: states left in the
+                                * previous step's row order, ssc_decode_step_desc.ungathered) */
 } ssc_lstm_fwd_desc;
 int ssc_lstm_fwd(const ssc_lstm_fwd_desc* d, void* stream);
 /* The same with one more addend formed inside the kernel: pre[b,n] += z[b,:Z] . wz[n,:Z]  (z (B,Z) ld ldz; wz (4H,Z) ld ldwz;
@@ -429,7 +431,15 @@ typedef struct {
                               * K = F segment of the gate product; 1 = from the per-image table P[img,r,:] = W_ih^dec[:, :F] v_r in the
                               * image buffer (ssc_lstm_fwd_img, K = R; R <= 128); 2 = form that table first (once per image
                               * context, by the first step that uses it), then as 1.  Pays from ~500 rows with >= 16 rows per image */
+  int ungathered;            /* 1: h1 / c1 / hd / cd are the previous step's OUTPUTS in that step's row order - the caller has not
+                              * re-ordered them by back-pointer (cbs.py:236-250); row g's previous state is row
+                              * (g - g % group) + parent[g].  Every reader goes through the row lists the parent sharing builds
+                              * anyway, so the four (G,H) gathers per step go away.  Only where ssc_decode_ungathered_ok() says
+                              * so (parent sharing and the attended-feature table both in use); SSC_EINVAL otherwise */
 } ssc_decode_step_desc;
+/* 1 if a step of G rows in groups of `group` (0: group size not known yet - any divisor of G above 1 will do) over an image context of
+ * nimg images with this att_table mode can take un-gathered states */
+int ssc_decode_ungathered_ok(const ssc_model_cfg* cfg, int nimg, int G, int group, int att_table);
 size_t ssc_decode_step_workspace_bytes(const ssc_model_cfg* cfg, int G, int R);
 int ssc_decode_step(const ssc_model_cfg* cfg, const ssc_params* p, const ssc_decode_step_desc* d, void* workspace,
                     size_t workspace_bytes, void* stream);

@@ -79,7 +79,7 @@ StepLayout step_layout(const ssc_model_cfg* c, int G, int R) {
   l.attn_logits = o; o += r64((size_t)G * R);
   l.proj = o; o += r64(c->tied ? (size_t)G * l.Ep : 0);
   l.wcol = o; o += r64((size_t)4 * c->H);
-  l.dedup = o; o += r64((size_t)2 * G + 8);
+  l.dedup = o; o += r64((size_t)3 * G + 8);
   size_t skinny = (size_t)33 * G * 4 * c->H;
   size_t full = (size_t)16 * 1024 * 1024;  // 64 MB: split-K slabs of the large GEMMs
   l.slab_floats = skinny > full ? skinny : full;
@@ -395,11 +395,15 @@ __global__ void gather_rows_kernel(const float* __restrict__ src, int ld, const 
 // Beams of one group (S * beam consecutive rows) that descend from the same parent hold identical recurrent states after the
 // re-ordering of cbs.py:236-250.  One workgroup: rep = the first row of each (group, parent) class; out[0] = number of classes,
 // out[4 .. ) their representative rows in ascending order, out[4 + n .. ) the class index (slot) of every row.
-__global__ __launch_bounds__(1024) void dedup_rows_kernel(const int64_t* __restrict__ parent, int n, int group, int* __restrict__ out) {
+// out[4 + 2n .. ): prow = the row of every row's previous state; `ungathered` (the states are still in the previous step's row
+// order): prow[g] = (g - g % group) + parent[g] and the representative rows are the classes' parent rows; else prow[g] = g.
+__global__ __launch_bounds__(1024) void dedup_rows_kernel(const int64_t* __restrict__ parent, int n, int group, int* __restrict__ out,
+                                                          int ungathered) {
   __shared__ int part[1024];
   const int tid = threadIdx.x;
   int* urows = out + 4;
   int* slot = out + 4 + n;
+  int* prow = out + 4 + 2 * n;
   auto first_of = [&](int g) -> int {   // the first row of g's group with the same parent
     const int g0 = g - g % group;
     const int64_t pg = parent[g];
@@ -421,7 +425,7 @@ __global__ __launch_bounds__(1024) void dedup_rows_kernel(const int64_t* __restr
   }
   int pos = part[tid] - cnt;
   for (int g = lo; g < hi; ++g)
-    if (first_of(g) == g) { urows[pos] = g; slot[g] = pos; ++pos; }
+    if (first_of(g) == g) { urows[pos] = ungathered ? g - g % group + (int)parent[g] : g; slot[g] = pos; ++pos; }
   if (tid == 1023) out[0] = part[1023];
   for (int i = part[1023] + tid; i < n; i += 1024) urows[i] = 0;   // entries past the count are never used; keep them in range
   __syncthreads();
@@ -431,6 +435,7 @@ __global__ __launch_bounds__(1024) void dedup_rows_kernel(const int64_t* __restr
   for (int g = lo; g < hi; ++g) {
     const int f = first_of(g);
     if (f != g) slot[g] = slot[f];
+    prow[g] = ungathered ? g - g % group + (int)parent[g] : g;
   }
 }
 
@@ -484,6 +489,15 @@ extern "C" size_t ssc_decode_step_workspace_bytes(const ssc_model_cfg* cfg, int 
   return step_layout(cfg, G, R).total * sizeof(float);
 }
 
+int ssc_g_dec_ungathered = ssc_env_int("SSC_DEC_UNGATHERED", 1);   // ssc_debug_set("dec_ungathered"): 0 = the caller re-orders the states
+extern "C" int ssc_decode_ungathered_ok(const ssc_model_cfg* cfg, int nimg, int G, int group, int att_table) {
+  if (!cfg || nimg <= 0 || G <= 0) return 0;
+  // the conditions under which ssc_decode_step reads every previous state through its row lists (`dedup` there, and the table)
+  if (group != 0 && (group < 2 || G % group != 0)) return 0;   // (group 0: asked before the group size is known)
+  return ssc_g_dec_ungathered && att_table != 0 && ssc_g_dec_att_table != 0 &&
+         nimg >= DEC_TOKEN_TABLE_MIN_IMAGES && G >= 512 && ssc_g_dec_dedup;
+}
+
 extern "C" int ssc_decode_step(const ssc_model_cfg* cfg, const ssc_params* p, const ssc_decode_step_desc* d, void* workspace,
                                size_t workspace_bytes, void* stream) {
   if (!cfg || !p || !d || !workspace) return SSC_EINVAL;
@@ -513,12 +527,14 @@ extern "C" int ssc_decode_step(const ssc_model_cfg* cfg, const ssc_params* p, co
   // (ssc_decode_step_desc.parent).  Used where the token's gate term is not part of the product (token table) and the rows are
   // many enough for the 128x128 kernels with device-side row lists.
   const bool dedup = d->parent && d->group > 1 && G % d->group == 0 && il.token_table && !d->emb_override && G >= 512 && ssc_g_dec_dedup;
-  const int* ucount = nullptr; const int* urows = nullptr; const int* slot = nullptr;
+  const int* ucount = nullptr; const int* urows = nullptr; const int* slot = nullptr; const int* prow = nullptr;
+  // un-gathered states: every reader of h1 / c1 / hd / cd must go through the row lists
+  if (d->ungathered && !(dedup && att_table)) return SSC_EINVAL;
   if (dedup) {
     int* dd = reinterpret_cast<int*>(W + l.dedup);
-    SSC_LAUNCH(dedup_rows_kernel, dim3(1), dim3(1024), 0, st, d->parent, G, d->group, dd);
+    SSC_LAUNCH(dedup_rows_kernel, dim3(1), dim3(1024), 0, st, d->parent, G, d->group, dd, d->ungathered ? 1 : 0);
     SSC_CHECK_LAUNCH();
-    ucount = dd; urows = dd + 4; slot = dd + 4 + G;
+    ucount = dd; urows = dd + 4; slot = dd + 4 + G; prow = dd + 4 + 2 * G;
   }
   float* slabs_u = slabs + (size_t)G * H4;   // second product of the decoder gates (distinct parents): behind the first one's rows
 
@@ -542,7 +558,7 @@ extern "C" int ssc_decode_step(const ssc_model_cfg* cfg, const ssc_params* p, co
     f.slabs = slabs; f.nslab = ns; f.slab_stride = (size_t)G * H4;
     f.add1 = I + il.ga_avg; f.ld_add1 = H4; f.rows_per_add1 = rpi;
     f.b_ih = p->att_b_ih; f.b_hh = p->att_b_hh;
-    f.c_prev = d->c1; f.ld_cprev = H;
+    f.c_prev = d->c1; f.ld_cprev = H; f.c_prev_rows = prow;
     f.c_out = d->c1_out; f.ld_cout = H; f.h_out = d->h1_out; f.ld_hout = H;
     SSC_TRY(ssc_lstm_fwd(&f, st));
   }
@@ -581,7 +597,7 @@ extern "C" int ssc_decode_step(const ssc_model_cfg* cfg, const ssc_params* p, co
       SSC_TRY(ssc_copy_strided(p->dec_w_ih + F + 2 * H, p->ld_dec_w_ih, H4, W + l.wcol, st));
       f.sent = d->sentiment; f.wcol = W + l.wcol; f.ldwcol = 1;
     }
-    f.c_prev = d->cd; f.ld_cprev = H;
+    f.c_prev = d->cd; f.ld_cprev = H; f.c_prev_rows = prow;
     f.c_out = d->cd_out; f.ld_cout = H; f.h_out = d->hd_out; f.ld_hout = H;
     if (att_table) SSC_TRY(ssc_lstm_fwd_img(&f, d->alpha, R, I + il.pd, R, rpi, st));
     else SSC_TRY(ssc_lstm_fwd(&f, st));

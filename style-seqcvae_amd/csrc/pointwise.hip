@@ -7,7 +7,7 @@
 
 thread_local int ssc_tls_hip_error = 0;
 
-extern "C" int ssc_version(void) { return 2; }
+extern "C" int ssc_version(void) { return 3; }
 extern "C" int ssc_last_hip_error(void) { return ssc_tls_hip_error; }
 extern "C" const char* ssc_arch(void) { return "gfx950"; }
 
@@ -102,7 +102,7 @@ __global__ void lstm_fwd_kernel(const ssc_lstm_fwd_desc d) {
     sw[g] = d.sent ? d.wcol[(size_t)n * d.ldwcol] : 0.f;
   }
   const float sv = d.sent ? d.sent[b] : 0.f;
-  const float cp = d.c_prev ? d.c_prev[(size_t)b * d.ld_cprev + j] : 0.f;
+  const float cp = d.c_prev ? d.c_prev[(size_t)(d.c_prev_rows ? d.c_prev_rows[b] : b) * d.ld_cprev + j] : 0.f;
   float pre[4] = {0.f, 0.f, 0.f, 0.f};
   // split-K slabs: summed in index order per gate (a `v += load` loop with a dynamic trip count would serialise one
   // memory latency per slab), U loads per gate in flight.  U follows the slab count: the decode step hands ONE slab (the gate
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_img_kernel(const ssc_lstm_fwd_de
       for (int g = 0; g < 4; ++g) t2[g] = d.slabs2[r2 * H4 + g * H + jc];
     }
     const float sv = d.sent ? d.sent[bc] : 0.f;
-    const float cp = d.c_prev ? d.c_prev[(size_t)bc * d.ld_cprev + jc] : 0.f;
+    const float cp = d.c_prev ? d.c_prev[(size_t)(d.c_prev_rows ? d.c_prev_rows[bc] : bc) * d.ld_cprev + jc] : 0.f;
     __syncthreads();   // (the previous chunk's alpha rows have been consumed; first pass: sP's writers)
     for (int idx = tid; idx < TR * R; idx += 512) {
       const int row = idx / R, r = idx - row * R, ab = img * rpi + c0 + row;
@@ -404,8 +404,8 @@ __global__ __launch_bounds__(512) void lstm_fwd_img_kernel(const ssc_lstm_fwd_de
 // The VALU form above spent ~100 of its 190 us at C4 (5000 rows, R = 36) on LDS reads for the contraction (5 reads per 4 FMAs).
 // (A first matrix-core form held the table tile in 36 registers per lane, one wave per image: ~200 registers, two waves per SIMD,
 // 96 us; with the next chunk's operands prefetched by hand 114 us.)
-// MODE 0: one slab read by row index, no second slab; MODE 1: + a second slab read through slab2_rows (the sibling-dedup decode
-// step); MODE 2: every option of the descriptor.  Modes 0 and 1 have NO conditional loads: hipcc turns `p ? *p : 0` into a branch
+// MODE 0: one slab read by row index, no second slab; MODE 1: + a second slab read through slab2_rows and the previous cell state
+// through c_prev_rows (the sibling-dedup decode step); MODE 2: every option of the descriptor.  Modes 0 and 1 have NO conditional loads: hipcc turns `p ? *p : 0` into a branch
 // with s_waitcnt vmcnt(0) at the join, which serialises the loads of a lane (the first forms of this kernel: 120-135 us).
 template <int KS, int MODE>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(KS <= 17 && MODE < 2 ? 4 : 2, 8))) void lstm_fwd_img_mfma_kernel(
@@ -445,7 +445,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(KS <= 17 &&
       if (MODE == 2) o.pre[g] = d.nslab > 0 ? *reinterpret_cast<const ssc_f32x4v*>(d.slabs + o.r1 * H4 + n) : ssc_f32x4v{0.f, 0.f, 0.f, 0.f};
       else o.pre[g] = *reinterpret_cast<const ssc_f32x4v*>(d.slabs + o.r1 * H4 + n);
     }
-    if (MODE == 2) o.cp = d.c_prev ? *reinterpret_cast<const ssc_f32x4v*>(d.c_prev + (size_t)o.bc * d.ld_cprev + uc) : ssc_f32x4v{0.f, 0.f, 0.f, 0.f};
+    if (MODE == 2)
+      o.cp = d.c_prev ? *reinterpret_cast<const ssc_f32x4v*>(d.c_prev + (size_t)(d.c_prev_rows ? d.c_prev_rows[o.bc] : o.bc) * d.ld_cprev + uc)
+                      : ssc_f32x4v{0.f, 0.f, 0.f, 0.f};
+    else if (MODE == 1) o.cp = *reinterpret_cast<const ssc_f32x4v*>(d.c_prev + (size_t)d.c_prev_rows[o.bc] * d.ld_cprev + uc);
     else o.cp = *reinterpret_cast<const ssc_f32x4v*>(d.c_prev + (size_t)o.bc * d.ld_cprev + uc);
     const float* ap = alpha + (size_t)o.bc * ldalpha;
     o.sv = sentp[o.bc];
@@ -1263,7 +1266,7 @@ extern "C" int ssc_lstm_fwd_img(const ssc_lstm_fwd_desc* d, const float* alpha, 
     // (mode 2: split-K slabs beyond the first, per-token / per-image rows, saved gates, a missing state or slab - the decode step
     // uses none of them)
     const bool rare = d->nslab != 1 || d->nslab2 > 1 || d->add0 || d->add1 || d->gates_out || d->slab_rows || !d->c_prev ||
-                      (d->nslab2 == 1 && !d->slab2_rows);
+                      (d->nslab2 == 1 && !(d->slab2_rows && d->c_prev_rows)) || (d->nslab2 == 0 && d->c_prev_rows);
     const int mode = rare ? 2 : d->nslab2 == 1 ? 1 : 0;
 #define SSC_IMG_LAUNCH(KS)                                                                                                           \
   do {                                                                                                                             \

@@ -82,6 +82,9 @@ class DecodeEngine:
         # "_parent" (B, S*beam) int64: set by cbs_search after a beam re-ordering - row g descends from beam parent[g] of its group;
         # beams with the same parent hold identical states (ssc_decode_step_desc.parent: their shared products are formed once)
         parent = states.get("_parent")
+        # "_ungathered": the states are the previous call's outputs in ITS row order (cbs_search left out the re-ordering by
+        # back-pointer because ungathered_ok() said this call reads them through the parent lists)
+        ungathered = bool(states.get("_ungathered", False))
         st = {k: v.contiguous() for k, v in states.items() if not k.startswith("_")}
         tokens = tokens.to(torch.int64).contiguous()
         eps = eps.to(self.device, torch.float32).contiguous()
@@ -95,6 +98,12 @@ class DecodeEngine:
         new = {k: torch.empty_like(st[k]) for k in ("h1", "c1", "h_decoder", "c_decoder")}
         alpha = torch.empty(G, ctx.R, dtype=torch.float32, device=self.device)
         lp = torch.empty(G, d.V, dtype=torch.float32, device=self.device) if want_log_probs else None
+        att_table = self._att_table_mode(ctx, G, rpi)
+        has_parent = parent is not None and parent.numel() == G
+        group = parent.shape[-1] if has_parent else 0
+        if ungathered and not (has_parent and emb_table is None and
+                               self.lib._raw_ssc_decode_ungathered_ok(C.byref(self._cfg), ctx.nimg, G, group, att_table)):
+            raise ValueError("un-gathered states handed to a decode step that cannot read them through parent lists")
         desc = _lib.DecodeStepDesc(G, ctx.R, rpi, ctx.feats.data_ptr(), ctx.buf.data_ptr(), tokens.data_ptr(),
                                    sent.data_ptr() if sent is not None else None, eps.data_ptr(),
                                    st["h1"].data_ptr(), st["c1"].data_ptr(), st["h_decoder"].data_ptr(),
@@ -102,9 +111,7 @@ class DecodeEngine:
                                    new["h_decoder"].data_ptr(), new["c_decoder"].data_ptr(), alpha.data_ptr(),
                                    lp.data_ptr() if lp is not None else None, 1 if raw_logits else 0,
                                    1 if emb_table is not None else 0,
-                                   parent.data_ptr() if parent is not None and parent.numel() == G else None,
-                                   parent.shape[-1] if parent is not None and parent.numel() == G else 0,
-                                   self._att_table_mode(ctx, G, rpi))
+                                   parent.data_ptr() if has_parent else None, group, att_table, 1 if ungathered else 0)
         p = self._params()
         if emb_table is not None:  # rows of `emb_table` are the token embeddings themselves (UpDownCell.forward API)
             p.emb = emb_table.data_ptr()
@@ -114,6 +121,15 @@ class DecodeEngine:
         out_states = dict(st)
         out_states.update(new)
         return lp, out_states, alpha
+
+    def ungathered_ok(self, ctx: ImageContext, G: int, group: int) -> bool:
+        """May a step of G rows in groups of `group` beams over `ctx` take its previous states in the previous step's row order
+        (states["_ungathered"], with the back-pointers in states["_parent"])?  For cbs_search(ungathered_ok=...)."""
+        if G % ctx.nimg != 0:
+            return False
+        # (same decision as step(): the table must be in use; it has been formed by the time a search re-orders beams)
+        att = 0 if (ctx.R > 128 or G < self.ATT_TABLE_MIN_ROWS or G // ctx.nimg < self.ATT_TABLE_MIN_ROWS_PER_IMAGE) else 1
+        return bool(self.lib._raw_ssc_decode_ungathered_ok(C.byref(self._cfg), ctx.nimg, G, group, att))
 
 
     def _step_from_embedding(self, ctx, token_embedding, states, sentiment, eps):
@@ -128,12 +144,16 @@ DecodeEngine.step_from_embedding = DecodeEngine._step_from_embedding
 
 def cbs_search(start_predictions: torch.Tensor, start_state, step: Callable, fsm: torch.Tensor, end_index: int,
                max_steps: int, beam_size: int, per_node_beam_size: int, early_stop: bool = True,
-               early_stop_every: int = 1, raw_logits: bool = False):
+               early_stop_every: int = 1, raw_logits: bool = False,
+               ungathered_ok: Optional[Callable[[int, int], bool]] = None):
     """Constrained beam search with on-device bookkeeping (ssc_beam_first / ssc_beam_step / ssc_gather_rows /
     ssc_beam_backtrace).  `step(tokens (G,), state) -> (log_probs (G,V), state, ...)` as in cbs.py:127,170.
     Returns (predictions (B,S,beam,steps) int64, log_probs (B,S,beam)).
     raw_logits: `step` returns un-normalised logits; the selection kernels normalise each row themselves (bit-identical
-    selections and log-probs)."""
+    selections and log-probs).
+    ungathered_ok(G, group) -> bool: the step function reads its previous states through the back-pointers itself
+    (DecodeEngine.ungathered_ok): the states then stay in the previous step's row order, with state["_parent"] = back-pointers and
+    state["_ungathered"] = True, and the re-ordering of cbs.py:236-250 (one gather per state tensor and step) is not done here."""
     lib = _lib.load()
     beam_first = lib.ssc_beam_first_logits if raw_logits else lib.ssc_beam_first
     beam_step = lib.ssc_beam_step_logits if raw_logits else lib.ssc_beam_step
@@ -182,14 +202,22 @@ def cbs_search(start_predictions: torch.Tensor, start_state, step: Callable, fsm
                           _lib.ptr(sval), _lib.ptr(sidx), st())
         last_lp = new_lp
         new_state = {}
+        # a step function that reads its previous states through the parent list (DecodeEngine.step at large G: `ungathered_ok`)
+        # gets them as they are - the re-ordering of cbs.py:236-250 then happens inside its kernels' row lists
+        leave = ungathered_ok is not None and SB > 1 and bool(ungathered_ok(B * SB, SB))
         for k, v in state.items():  # cbs.py:236-250
             if k.startswith("_"):
+                continue
+            if leave:
+                new_state[k] = v
                 continue
             v2 = v.reshape(B * SB, -1).contiguous()
             dst = torch.empty_like(v2)
             lib.ssc_gather_rows(_lib.ptr(v2), v2.stride(0), _lib.ptr(backs[t - 1]), B, SB, v2.size(1), _lib.ptr(dst), st())
             new_state[k] = dst.view_as(v)
         new_state["_parent"] = backs[t - 1]   # for the step function: which rows of a group now hold the same states
+        if leave:
+            new_state["_ungathered"] = True
         state = new_state
         nsteps += 1
     allp = torch.empty(B, SB, nsteps, dtype=torch.int64, device=dev)

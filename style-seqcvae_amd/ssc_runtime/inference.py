@@ -51,7 +51,8 @@ def diverse_decode(dec: DecodeEngine, feats: torch.Tensor, sentiment: Optional[t
 
     start = torch.full((B,), boundary_index, dtype=torch.long, device=dev)
     beams, lps = cbs_search(start, None, step, fsm, boundary_index, max_steps, beam, per_node or (beam // 2) or beam,
-                            early_stop=early_stop, early_stop_every=4, raw_logits=_RAW)
+                            early_stop=early_stop, early_stop_every=4, raw_logits=_RAW,
+                            ungathered_ok=lambda G, group: dec.ungathered_ok(ctx, G, group))
     if trivial or fsm.size(1) == 1:
         best = beams[:, 0, 0, :]
     else:

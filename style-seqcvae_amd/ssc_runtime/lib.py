@@ -39,7 +39,7 @@ class LstmFwdDesc(C.Structure):
                 ("b_ih", vp), ("b_hh", vp), ("sent", vp), ("wcol", vp), ("ldwcol", C.c_int), ("c_prev", vp),
                 ("ld_cprev", C.c_int), ("gates_out", vp), ("c_out", vp), ("ld_cout", C.c_int), ("h_out", vp),
                 ("ld_hout", C.c_int), ("add0_rows", vp), ("slab_rows", vp), ("slabs2", vp), ("nslab2", C.c_int),
-                ("slab2_stride", C.c_size_t), ("slab2_rows", vp)]
+                ("slab2_stride", C.c_size_t), ("slab2_rows", vp), ("c_prev_rows", vp)]
 
 
 class LstmBwdDesc(C.Structure):
@@ -107,7 +107,8 @@ class DecodeStepDesc(C.Structure):
     _fields_ = [("G", C.c_int), ("R", C.c_int), ("rows_per_image", C.c_int), ("feats", vp), ("imgbuf", vp),
                 ("tokens", vp), ("sentiment", vp), ("eps", vp), ("h1", vp), ("c1", vp), ("hd", vp), ("cd", vp),
                 ("h1_out", vp), ("c1_out", vp), ("hd_out", vp), ("cd_out", vp), ("alpha", vp), ("log_probs", vp),
-                ("raw_logits", C.c_int), ("emb_override", C.c_int), ("parent", vp), ("group", C.c_int), ("att_table", C.c_int)]
+                ("raw_logits", C.c_int), ("emb_override", C.c_int), ("parent", vp), ("group", C.c_int), ("att_table", C.c_int),
+                ("ungathered", C.c_int)]
 
 
 # name -> (restype, argtypes).  Every symbol include/ssc.h declares is listed; tests check they all resolve.
@@ -166,6 +167,7 @@ SYMBOLS = {
     "ssc_decode_prepare": (_i, [C.POINTER(ModelCfg), C.POINTER(Params), vp, _i, _i, vp, _sz, vp]),
     "ssc_decode_step_workspace_bytes": (_sz, [C.POINTER(ModelCfg), _i, _i]),
     "ssc_decode_step": (_i, [C.POINTER(ModelCfg), C.POINTER(Params), C.POINTER(DecodeStepDesc), vp, _sz, vp]),
+    "ssc_decode_ungathered_ok": (_i, [C.POINTER(ModelCfg), _i, _i, _i, _i]),
     "ssc_beam_first": (_i, [vp, _i, vp, _i, _i, _i, _i, vp, vp, vp]),
     "ssc_beam_step": (_i, [vp, _i, vp, vp, vp, _i, _i, _i, _i, _i, _i, vp, vp, vp, vp, vp, vp]),
     "ssc_beam_first_logits": (_i, [vp, _i, vp, _i, _i, _i, _i, vp, vp, vp]),

@@ -522,3 +522,54 @@ def test_sibling_dedup_and_table_paths_leave_the_search_unchanged():
     assert maxdiff(outs[0][0], outs[1][0]) < 2e-5 and maxdiff(outs[0][2], outs[1][2]) < 1e-6
     for k in ("h1", "c1", "h_decoder", "c_decoder"):
         assert maxdiff(outs[0][1][k], outs[1][1][k]) < 2e-6, k
+    # the same step from the states in the PREVIOUS step's row order (no re-ordering by the caller: "_ungathered"): every reader
+    # goes through the parent lists - the very same numbers
+    assert dec.ungathered_ok(ctx, G, 5) and not dec.ungathered_ok(ctx, G, 1)
+    s_in = {k: v.reshape(G, H).contiguous() for k, v in base.items()}
+    s_in["_parent"] = parent
+    s_in["_ungathered"] = True
+    lp, so, al = dec.step(ctx, tok, s_in, sent_rows, eps[1])
+    assert torch.equal(lp, outs[0][0]) and torch.equal(al, outs[0][2])
+    for k in ("h1", "c1", "h_decoder", "c_decoder"):
+        assert torch.equal(so[k], outs[0][1][k]), k
+    # ... and a step that cannot read them that way refuses them
+    lib.ssc_debug_set(b"dec_dedup", 0)
+    try:
+        with pytest.raises(ValueError):
+            dec.step(ctx, tok, s_in, sent_rows, eps[1])
+    finally:
+        lib.ssc_debug_set(b"dec_dedup", 1)
+
+
+def test_search_without_state_reordering_equals_search_with_it():
+    """cbs_search leaves the states in the previous step's row order when the step function reads them through the parent lists
+    (DecodeEngine.step at >= 512 rows); ssc_debug_set("dec_ungathered", 0) restores the four ssc_gather_rows per step: identical
+    beams."""
+    from ssc_runtime import lib as L
+    from ssc_runtime.inference import diverse_decode
+    from ssc_runtime.vocab import Vocabulary
+    from var_updown.models import UpDownCaptioner
+    lib = L.load()
+    V, F, E, H, A, Z, R = 300, 48, 40, 64, 24, 8, 7
+    torch.manual_seed(11)
+    m = UpDownCaptioner(Vocabulary.synthetic(V), image_feature_size=F, embedding_size=E, hidden_size=H,
+                        attention_projection_size=A, max_caption_length=8, beam_size=5, z_space=Z, prior_std=1.0,
+                        simple_vae=False, latent_embedding="glove", sentiment_vae=1, senti_prior_multip=0.5,
+                        device=torch.device("cuda")).to("cuda")
+    m.eval()
+    m._engine()
+    dec = m._dec
+    g = torch.Generator().manual_seed(5)
+    nimg, ns, beam = 9, 17, 5
+    feats = torch.randn(nimg, R, F, generator=g).cuda()
+    senti = torch.randint(-1, 2, (nimg,), generator=g).float().cuda()
+    B = nimg * ns
+    eps = [torch.randn(B, Z, generator=g).cuda()] + [torch.randn(B * beam, Z, generator=g).cuda() for _ in range(9)]
+    res = []
+    for on in (1, 0):
+        lib.ssc_debug_set(b"dec_ungathered", on)
+        try:
+            res.append(diverse_decode(dec, feats, senti, ns, beam, 8, 1, eps_steps=[e.clone() for e in eps], early_stop=False)[0].clone())
+        finally:
+            lib.ssc_debug_set(b"dec_ungathered", 1)
+    assert torch.equal(res[0], res[1])
