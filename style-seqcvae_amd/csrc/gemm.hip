@@ -2311,6 +2311,7 @@ extern "C" int ssc_set_gemm_mode(int mode) {
 
 // ---- include/ssc_debug.h -----------------------------------------------------------------------------------------
 extern int ssc_g_dec_att_table, ssc_g_dec_dedup, ssc_g_beam_reg, ssc_g_dec_ungathered;   // decode.hip
+extern int ssc_g_img_mfma;   // pointwise.hip
 namespace {
 struct DebugKey { const char* name; int* var; };
 const DebugKey g_debug_keys[] = {
@@ -2330,6 +2331,7 @@ const DebugKey g_debug_keys[] = {
     {"tile_gm", &g_tile_gm},         // tile rows per group of the tile order (8; 0 = row-major)   (SSC_TILE_GM)
     {"dec_dedup", &ssc_g_dec_dedup},           // decode: parent-state products on the distinct parents of a beam group (1 | 0)   (SSC_DEC_DEDUP)
     {"beam_reg", &ssc_g_beam_reg},             // decode: beam selection with the vocabulary row in registers (1 | 0)              (SSC_BEAM_REG)
+    {"img_mfma", &ssc_g_img_mfma},             // decode: the image cell's table contraction on the fp32 matrix cores (1 | 0 = VALU form)   (SSC_IMG_MFMA)
     {"dec_ungathered", &ssc_g_dec_ungathered}, // decode: states left in the previous step's row order, read through the parent lists (1 | 0)   (SSC_DEC_UNGATHERED)
     {"dec_att_table", &ssc_g_dec_att_table},   // decode: attended-feature term of the decoder gates from a per-image table (1 | 0)   (SSC_DEC_ATT_TABLE)
     {"big_min_m", &g_big_min_m},     // rows from which a product with N >= 512 takes 128x128 tiles (65; 512 = the behaviour until late in round 2)   (SSC_BIG_MIN_M)

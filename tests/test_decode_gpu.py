@@ -573,3 +573,79 @@ def test_search_without_state_reordering_equals_search_with_it():
         finally:
             lib.ssc_debug_set(b"dec_ungathered", 1)
     assert torch.equal(res[0], res[1])
+
+
+@pytest.mark.parametrize("nimg,rpi,R,H,variant", [
+    (3, 37, 36, 72, "dedup"),      # KS = 10, a ragged last 16-row chunk, a ragged last unit block (72 = 4 x 16 + 8)
+    (2, 16, 50, 64, "dedup"),      # KS = 17
+    (2, 20, 100, 48, "plain"),     # KS = 33 (84 KB of LDS)
+    (4, 19, 36, 64, "plain"),
+    (2, 33, 36, 64, "general"),    # every option of the descriptor (mode 2)
+    (2, 18, 9, 50, "general"),     # H % 4 != 0: the VALU form
+    (3, 21, 36, 64, "valu"),       # the VALU form forced by its switch
+])
+def test_image_cell_kernel_equals_float64(nimg, rpi, R, H, variant):
+    """ssc_lstm_fwd_img - the decoder cell with the attended-feature term contracted from the per-image table
+    (updown_cell.py:156-158,211-229) - against a float64 evaluation: the matrix-core kernel in its three modes (plain; sibling
+    dedup = second slab through slab2_rows + previous cell state through c_prev_rows; every option), every k-step count
+    (R <= 38 / 66 / 128), ragged rows and units, the sentiment column, and the VALU form."""
+    import ctypes as C
+    from ssc_runtime import lib as L
+    lib = L.load()
+    dev_ = "cuda"
+    G, H4 = nimg * rpi, 4 * H
+    g = torch.Generator().manual_seed(nimg * 1000 + R * 10 + H)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(dev_)
+    slabs, P = rnd(2, G, H4) * 0.3, rnd(nimg, R, H4) * 0.3
+    alpha = torch.softmax(rnd(G, R), dim=1).contiguous()
+    cprev, b_ih, b_hh, wcol = rnd(G, H), rnd(H4) * 0.1, rnd(H4) * 0.1, rnd(H4) * 0.2
+    sent = torch.randint(-1, 2, (G,), generator=g).float().to(dev_)
+    c_out, h_out = torch.empty(G, H, device=dev_), torch.empty(G, H, device=dev_)
+    f = L.LstmFwdDesc()
+    f.B, f.H = G, H
+    f.slabs, f.nslab, f.slab_stride = slabs.data_ptr(), 1, G * H4
+    f.b_ih, f.b_hh = b_ih.data_ptr(), b_hh.data_ptr()
+    f.sent, f.wcol, f.ldwcol = sent.data_ptr(), wcol.data_ptr(), 1
+    f.c_prev, f.ld_cprev = cprev.data_ptr(), H
+    f.c_out, f.ld_cout, f.h_out, f.ld_hout = c_out.data_ptr(), H, h_out.data_ptr(), H
+    pre = slabs[0].double() + b_ih.double() + b_hh.double() + sent.double()[:, None] * wcol.double() \
+        + torch.bmm(alpha.double().view(nimg, rpi, R), P.double()).view(G, H4)
+    cp = cprev.double()
+    keep = []
+    if variant == "dedup":
+        nu = max(G // 3, 1)
+        slabs2 = rnd(nu, H4) * 0.3
+        slot = torch.randint(0, nu, (G,), generator=g).int().to(dev_)
+        prow = torch.randint(0, G, (G,), generator=g).int().to(dev_)
+        f.slabs2, f.nslab2, f.slab2_stride, f.slab2_rows, f.c_prev_rows = slabs2.data_ptr(), 1, G * H4, slot.data_ptr(), prow.data_ptr()
+        pre = pre + slabs2.double()[slot.long()]
+        cp = cprev.double()[prow.long()]
+        keep += [slabs2, slot, prow]
+    elif variant == "general":
+        f.nslab = 2                                                # a second split-K slab
+        add0 = rnd(7, H4) * 0.2                                    # a per-token table, rows by index
+        rows0 = torch.randint(0, 7, (G,), generator=g).to(dev_)
+        add1 = rnd(nimg, H4) * 0.2                                 # a per-image row
+        gates = torch.empty(G, H4, device=dev_)
+        srow = torch.randint(0, G, (G,), generator=g).int().to(dev_)
+        f.add0, f.ld_add0, f.add0_rows = add0.data_ptr(), H4, rows0.data_ptr()
+        f.add1, f.ld_add1, f.rows_per_add1 = add1.data_ptr(), H4, rpi
+        f.gates_out, f.slab_rows = gates.data_ptr(), srow.data_ptr()
+        pre = pre - slabs[0].double() + slabs[0].double()[srow.long()] + slabs[1].double()[srow.long()] \
+            + add0.double()[rows0] + add1.double().repeat_interleave(rpi, 0)
+        keep += [add0, rows0, add1, gates, srow]
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    if variant == "valu":
+        lib.ssc_debug_set(b"img_mfma", 0)
+    try:
+        lib.ssc_lstm_fwd_img(C.byref(f), L.ptr(alpha), R, L.ptr(P), R, rpi, st)
+        torch.cuda.synchronize()
+    finally:
+        lib.ssc_debug_set(b"img_mfma", 1)
+    i, fg, gg, o = pre.view(G, 4, H).unbind(1)
+    c = torch.sigmoid(fg) * cp + torch.sigmoid(i) * torch.tanh(gg)
+    h = torch.sigmoid(o) * torch.tanh(c)
+    assert maxdiff(c_out, c) < 2e-6 and maxdiff(h_out, h) < 2e-6
+    if variant == "general":
+        act = torch.stack([torch.sigmoid(i), torch.sigmoid(fg), torch.tanh(gg), torch.sigmoid(o)], 1).reshape(G, H4)
+        assert maxdiff(gates, act) < 2e-6
