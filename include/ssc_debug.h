@@ -42,7 +42,13 @@ int ssc_prof_loop_ms(float* fwd_loop_ms, float* bwd_loop_ms);
  *   "tile_gm"     tile rows per group of the XCD-aware tile order (8; 0 = row-major)               (SSC_TILE_GM)
  *   "big_min_m"   rows from which a product with N >= 512 takes 128x128 tiles (65); below 512 rows always in the
  *                 wave-specialised form                                                            (SSC_BIG_MIN_M)
- * Returns SSC_EINVAL for an unknown key. */
+ *   decode (ssc_decode_step and the beam kernels; every form gives the same captions):
+ *   "dec_att_table"  attended-feature term of the decoder gates from the per-image table (1)      (SSC_DEC_ATT_TABLE)
+ *   "dec_dedup"      products fed only by the parent's states on the distinct parents (1)         (SSC_DEC_DEDUP)
+ *   "dec_ungathered" ssc_decode_ungathered_ok() may say yes: states read through the parent lists (1)   (SSC_DEC_UNGATHERED)
+ *   "img_mfma"       table contraction of ssc_lstm_fwd_img on the fp32 matrix cores (1 | 0 = VALU form)  (SSC_IMG_MFMA)
+ *   "beam_reg"       beam selection with the vocabulary row in registers for V <= 10240 (1)       (SSC_BEAM_REG)
+ * The environment variables are honoured only with SSC_DEBUG=1.  Returns SSC_EINVAL for an unknown key. */
 int ssc_debug_set(const char* key, int value);
 int ssc_debug_get(const char* key, int* value);
 
