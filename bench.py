@@ -384,10 +384,29 @@ def main():
         ex = eng.dp_exposure_ms()
         t = torch.tensor([sum(ex) / max(1, len(ex)), max(ex) if ex else 0.0], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dp_exposure = {"allreduce_exposed_ms_per_step_mean": float(t[0]), "allreduce_exposed_ms_per_step_max": float(t[1]),
+        # the replicas must still be bit-identical (same reduced gradients, same update on every rank), and no bounded wait of the
+        # direct exchange may have given up: a number measured on diverged replicas would be worthless
+        chk = eng.params.flat.sum(dtype=torch.float64).reshape(1)
+        lohi = torch.cat([chk, -chk])
+        dist.all_reduce(lohi, op=dist.ReduceOp.MAX)
+        identical = bool((lohi[0] == -lohi[1]).item())
+        timeouts = False
+        if eng._xgmi is not None and (eng.dp_choice or {}).get("algo") == "xgmi":
+            try:
+                eng._xgmi.check()
+            except Exception:   # noqa: BLE001
+                timeouts = True
+            flag = torch.tensor([1.0 if timeouts else 0.0], device=device, dtype=torch.float64)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            timeouts = bool(flag.item() > 0)
+        if rank == 0 and (not identical or timeouts):
+            print(f"[bench] DATA-PARALLEL RUN INVALID: replicas identical = {identical}, direct-exchange timeouts = {timeouts}",
+                  file=sys.stderr, flush=True)
+        dp_exposure = {"replicas_identical": identical, "direct_exchange_timeouts": timeouts,
+                       "allreduce_exposed_ms_per_step_mean": float(t[0]), "allreduce_exposed_ms_per_step_max": float(t[1]),
                        "bytes_per_step": int(eng.grads.flat.numel() * 4), "exchange": eng.dp_choice or {"algo": "rccl", "why": "requested"},
-                       "scheme": "4 ranges (output head behind the BPTT loop, then the three weight-gradient groups), async behind the "
-                       "backward phases (engine.backward_overlapped)"}
+                       "scheme": "5 ranges (output head behind the BPTT loop, then embedding, decoder LSTM, encoder LSTM + fc heads, attention "
+                       "LSTM + attention), each exchanged behind its backward phase (engine.backward_overlapped)"}
         if rank == 0:
             print("data-parallel exchange:", json.dumps(dp_exposure), file=sys.stderr, flush=True)
     loss_probe = None if args.timed_only else eng.forward(*batches[0])[0].mean().item()
