@@ -583,6 +583,7 @@ def test_search_without_state_reordering_equals_search_with_it():
     (2, 33, 36, 64, "general"),    # every option of the descriptor (mode 2)
     (2, 18, 9, 50, "general"),     # H % 4 != 0: the VALU form
     (3, 21, 36, 64, "valu"),       # the VALU form forced by its switch
+    (50, 100, 36, 1200, "dedup"),  # C4's decode step at full size: 5000 rows, 75 unit blocks
 ])
 def test_image_cell_kernel_equals_float64(nimg, rpi, R, H, variant):
     """ssc_lstm_fwd_img - the decoder cell with the attended-feature term contracted from the per-image table
