@@ -285,6 +285,47 @@ def decode_fixture(UpDownCaptioner, name, dims, sv, B=2, R=5, beam=5):
     print(name, "lp0[0,:3]", lp0[0, :3].numpy())
 
 
+def decode_large_fixture(UpDownCaptioner, name="g15_decode_large", dims=(300, 40, 48, 32, 64, 16, 6), sv=1, nimg=8, groups=14, beam=5,
+                         R=7):
+    """One eval-mode ``_decode_step`` (updown_captioner.py:371-455) at a LARGE call: nimg images x groups x beam rows = 560 rows
+    whose recurrent states look like those a beam search hands over after a re-ordering (cbs.py:236-250): the `beam` rows of a
+    group hold the states of the parents the back-pointers name, so several rows of a group share their states.  The build's
+    large-call decode paths (per-token gate table, per-image attended-feature table, products over the distinct parents, states
+    read through the parent lists) are pinned against THIS, the reference's own step on the re-ordered states."""
+    V, E, H, A, F, Z, L = dims
+    model = build_reference_model(UpDownCaptioner, dims, sv, multip=0.5)
+    model.eval()
+    g = torch.Generator().manual_seed(1515)
+    feats = torch.randn(nimg, R, F, generator=g)
+    feats[3, R - 2:] = 0
+    senti = torch.tensor([[1.0]] * nimg)  # equal per-row sentiment: the tile-order quirk (:418-424) is then invisible
+    prior_mean = senti.repeat(1, Z) * 0.5 if sv == 1 else torch.zeros(nimg, Z)
+    prior_var = torch.ones(nimg, Z)
+    G = nimg * groups * beam
+    NG = nimg * groups
+    tok = torch.randint(1, V, (G,), generator=g)
+    keys = ("h1", "c1", "h_encoder", "c_encoder", "h_decoder", "c_decoder")
+    base = {k: torch.randn(NG, beam, H, generator=g) * 0.3 for k in keys}    # the previous step's outputs, in ITS row order
+    parent = torch.randint(0, beam, (NG, beam), generator=g)                 # back-pointers of the beam step in between
+    parent[0] = torch.tensor([0, 0, 0, 0, 0])                                # a group with one parent ...
+    parent[1] = torch.arange(beam)                                           # ... and one with five
+    st_in = {k: v.gather(1, parent.view(NG, beam, 1).expand(NG, beam, H)).reshape(G, H).contiguous() for k, v in base.items()}
+    eps = torch.randn(G, Z, generator=g)
+    data = state_dict_np(model)
+    with torch.no_grad(), EpsInjector([eps]):
+        lp, st, _, _, al = model._decode_step(feats.clone(), None, tok, {k: v.clone() for k, v in st_in.items()}, senti, None,
+                                              prior_mean, prior_var)
+    data.update({"in/feats": feats.numpy(), "in/sentiment": senti.numpy(), "in/tok": tok.numpy(), "in/eps": eps.numpy(),
+                 "in/parent": parent.numpy(), "out/lp": lp.numpy(), "out/alpha": al.numpy()})
+    for k in keys:
+        data["in/base/" + k] = base[k].reshape(G, H).numpy()
+    for k in st:
+        data["out/st/" + k] = st[k].numpy()
+    data["cfg"] = np.array(repr(oracle_cfg(dims, sv, multip=0.5)))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **data)
+    print(name, "lp[0,:3]", lp[0, :3].numpy(), "distinct parents", sum(len(set(r.tolist())) for r in parent), "of", G)
+
+
 def full_size_inputs(seed, B, R=36, F=2048, L=20, V=10000, Z=128, unk=False):
     """Inputs of the full-size fixtures, regenerated from the seed on both sides (make_golden.py here, tests/test_train_gpu.py
     on the GPU box): BASELINE.md 4 distributions; `unk` plants @@UNKNOWN@@ (id 0) inside some captions."""
@@ -748,6 +789,8 @@ def main():
     UpDownCaptioner = import_reference()
     if "--only-sv2" in sys.argv:
         return sv2_train_fixture()
+    if "--only-decode-large" in sys.argv:
+        return decode_large_fixture(UpDownCaptioner)
     filter_fixture()
     if "--only-filter" in sys.argv:
         return
@@ -769,6 +812,7 @@ def main():
     train_fixture(UpDownCaptioner, "g4b_train_simple", toy, sv=1, simple_vae=True)
     decode_fixture(UpDownCaptioner, "g5_decode_sv1", toy, sv=1)
     decode_fixture(UpDownCaptioner, "g5b_decode_sv0", toy, sv=0)
+    decode_large_fixture(UpDownCaptioner)
     sgd_fixture(UpDownCaptioner, "g6_sgd", toy, sv=1)
     # odd sizes: nothing a multiple of 4/16/64 (kernel tail paths)
     train_fixture(UpDownCaptioner, "g7_train_odd", (131, 37, 50, 27, 70, 13, 5), sv=1, B=5, R=7)

@@ -102,6 +102,51 @@ def test_eval_decode_step_matches_reference(name):
     assert pm.shape == (ins["tok0"].numel(), cfg.z_space) and plv.shape == pm.shape
 
 
+def test_large_call_decode_step_matches_reference_on_reordered_states():
+    """g15_decode_large: the reference's `_decode_step` at 8 images x 14 groups x beam 5 = 560 rows on states re-ordered by
+    back-pointers (cbs.py:236-250).  At this size the build's step takes its large-call paths - per-token gate table, per-image
+    attended-feature table contracted on the matrix cores, products over the distinct parents of each beam group - and is handed
+    the states (a) re-ordered, with the back-pointers as `_parent`, (b) NOT re-ordered (`_ungathered`: read through the parent
+    lists), (c) re-ordered without back-pointers (no sharing): all three equal the reference's result."""
+    d, cfgd = load("g15_decode_large")
+    cfg = oracle.OracleConfig(**cfgd)
+    m = build_model(cfg, group(d, "param/"))
+    m.eval()
+    m._engine()
+    dec = m._dec
+    ins = group(d, "in/")
+    feats = dev(ins["feats"])
+    nimg = feats.size(0)
+    G = ins["tok"].numel()
+    parent = dev(ins["parent"])                       # (groups, beam)
+    NG, beam = parent.shape
+    base = {k: dev(v) for k, v in group(d, "in/base/").items()}
+    H = base["h1"].size(1)
+    gathered = {k: v.view(NG, beam, H).gather(1, parent.view(NG, beam, 1).expand(NG, beam, H)).reshape(G, H).contiguous()
+                for k, v in base.items()}
+    sent_rows = dev(ins["sentiment"]).view(nimg, 1).expand(nimg, G // nimg).reshape(G).contiguous()
+    tok, eps = dev(ins["tok"]), dev(ins["eps"])
+    ctx = dec.prepare(feats)
+    assert dec.ungathered_ok(ctx, G, beam)            # the large-call paths are really in use at this size
+    want_st = group(d, "out/st/")
+
+    def check(states):
+        lp, st, al = dec.step(ctx, tok, states, sent_rows, eps)
+        assert maxdiff(lp, torch.from_numpy(d["out/lp"])) < TOL
+        assert maxdiff(al, torch.from_numpy(d["out/alpha"])) < TOL
+        for k in ("h1", "c1", "h_decoder", "c_decoder"):
+            assert maxdiff(st[k], want_st[k]) < TOL, k
+
+    a = dict(gathered)
+    a["_parent"] = parent
+    check(a)
+    b = dict(base)
+    b["_parent"] = parent
+    b["_ungathered"] = True
+    check(b)
+    check(dict(gathered))
+
+
 def test_tied_module_and_cpu_call_fails_loudly():
     d, cfgd = load("g3_train_tied")
     cfg = oracle.OracleConfig(**cfgd)
