@@ -403,7 +403,6 @@ struct ThreadPtrs {
 // WM x WN MFMA tiles (32x32 each) per wave; block tile (64*WM) x (64*WN); PF = k-steps prefetched in registers.
 template <bool A_KC, bool B_KC, int WM, int WN, int PF, bool VEC>
 __global__ __launch_bounds__(256) void gemm_kernel(const KArgs a) {
-  ssc_touch_args(a);
   constexpr int RA = 64 * WM, RB = 64 * WN;
   constexpr int TA = RA * KC_LD, TB = RB * KC_LD;  // floats per LDS buffer (KC image is the larger one)
   __shared__ __attribute__((aligned(16))) float lds[2 * TA + 2 * TB];
@@ -603,7 +602,6 @@ __device__ __forceinline__ void split4(const f32x4& v, u32x2& hi, u32x2& mid, u3
 // workgroup is bound by, so more resident waves per SIMD matter more than the extra barrier.
 template <int PF, int WN, int NBUF>
 __global__ __launch_bounds__(256) void gemm_x3_kernel(const KArgs a) {
-  ssc_touch_args(a);
   constexpr int RB = 64 * WN;
   constexpr int PLA = 64 * PL_ROW_B, PLB = RB * PL_ROW_B;   // bytes per plane
   constexpr int STAGE_B = 3 * PLA + 3 * PLB;
@@ -792,7 +790,6 @@ constexpr int X3B_MC_ROW_B = 320;
 
 template <bool A_KC, bool B_KC, bool KG>
 __global__ __launch_bounds__(256, 2) void gemm_x3b_kernel(const KArgs a) {
-  ssc_touch_args(a);
   constexpr int PLN = X3B_PLANE;
   __shared__ __attribute__((aligned(16))) unsigned char lds[6 * PLN];
   const int tid = threadIdx.x;
@@ -1552,7 +1549,6 @@ __global__ __launch_bounds__(256 + 64 * NPW) void gemm_x3w_kernel(const KGroup g
 #pragma unroll
   for (int i = 1; i < SSC_GROUP_MAX; ++i)
     if (i < g.n && w >= g.first[i]) p = i;   // workgroup-uniform
-  ssc_touch_args(g.a[p]);   // (ssc_common.h: the body reads its fields through dependent scalar loads)
   const int local = w - g.first[p];
   const int gx = g.gx[p], gy = g.gy[p], gz = g.gz[p];
   const int x = local % gx, yz = local / gx;

@@ -85,7 +85,6 @@ __global__ void embed_scatter_kernel(float* __restrict__ dt, int ldt, const int6
 // LSTM pointwise forward / backward
 // ---------------------------------------------------------------------------------------------
 __global__ void lstm_fwd_kernel(const ssc_lstm_fwd_desc d) {
-  ssc_touch_args(d);
   int j = blockIdx.x * blockDim.x + threadIdx.x;
   int b = blockIdx.y;
   if (j >= d.H) return;
@@ -168,7 +167,6 @@ __global__ void lstm_fwd_kernel(const ssc_lstm_fwd_desc d) {
 typedef float ssc_f32x4v __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(512, 2) void lstm_fwd_z_kernel(const ssc_lstm_fwd_desc d, const float* __restrict__ z, int ldz,
                                                             const float* __restrict__ wz, int ldwz, int Z) {
-  ssc_touch_args(d);
   constexpr int TB = 32, TJ = 16, KT = 128, LD = KT + 4, NT = 512;   // k-tile of 128 (one pass for Z <= 128); rows padded by 4 floats
   __shared__ __attribute__((aligned(16))) float sz[TB * LD];       // z[b0 + r, k]
   __shared__ __attribute__((aligned(16))) float sw[4 * TJ * LD];   // wz[g*H + j0 + jj, k], row = g*16 + jj
@@ -303,7 +301,6 @@ constexpr int IMG_MAXR = 128;
 // per workgroup: 64-byte half lines whose other half a neighbouring workgroup fetched again later - 198 us for ~300 MB).
 __global__ __launch_bounds__(512) void lstm_fwd_img_kernel(const ssc_lstm_fwd_desc d, const float* __restrict__ alpha, int ldalpha,
                                                            const float* __restrict__ P, int R, int rpi, int cpw) {
-  ssc_touch_args(d);
   constexpr int TJ = 32, TR = 16, PW = 4 * TJ;   // units, rows per chunk, table tile width (4 gates x TJ)
   // dynamic LDS sized by R (R = 36: 20.7 KB)
   extern __shared__ float img_lds[];
@@ -413,7 +410,6 @@ __global__ __launch_bounds__(512) void lstm_fwd_img_kernel(const ssc_lstm_fwd_de
 template <int KS, int MODE>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(MODE == 2 ? 2 : KS <= 10 ? 4 : KS <= 17 ? 3 : 2, 8))) void lstm_fwd_img_mfma_kernel(
     const ssc_lstm_fwd_desc d, const float* __restrict__ alpha, int ldalpha, const float* __restrict__ P, int R, int rpi, int cpw) {
-  ssc_touch_args(d);
   constexpr int LDP = 80, NW = 8;
   constexpr bool RARE = MODE == 2;
   extern __shared__ float img_lds[];   // [4 * KS][LDP], rows >= R + 2 zero
@@ -556,7 +552,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
 // (exact-fp32 16x16x4 MFMA, K = 16) and the consumer (latent head) sums the cdiv(H,16) partial slabs in index order.
 __global__ __launch_bounds__(512, 2) void lstm_fwd_p_kernel(const ssc_lstm_fwd_desc d, const float* __restrict__ wp, int ldwp,
                                                             int NP, float* __restrict__ pout) {
-  ssc_touch_args(d);
   constexpr int TB = 32, TJ = 16, LD = TJ + 4, NT = 512, NPMAX = 256;
   __shared__ __attribute__((aligned(16))) float sh[TB * LD];      // h[b0 + r, j0 + k]
   __shared__ __attribute__((aligned(16))) float sw[NPMAX * LD];   // wp[n, j0 + k]
@@ -653,7 +648,6 @@ __global__ __launch_bounds__(512, 2) void lstm_fwd_p_kernel(const ssc_lstm_fwd_d
 }
 
 __global__ void lstm_bwd_kernel(const ssc_lstm_bwd_desc d) {
-  ssc_touch_args(d);
   int j = blockIdx.x * blockDim.x + threadIdx.x;
   int b = blockIdx.y;
   if (j >= d.H) return;
@@ -707,7 +701,6 @@ __global__ void lstm_bwd_kernel(const ssc_lstm_bwd_desc d) {
 template <int KMAX>   // 256 | 768: bounds the staged registers (KMAX / 16 + KMAX / 32 floats per thread)
 __global__ __launch_bounds__(512, 2) void lstm_bwd_x_kernel(const ssc_lstm_bwd_desc d, const float* __restrict__ x, int ldx,
                                                             const float* __restrict__ w, int ldw, int K) {
-  ssc_touch_args(d);
   constexpr int TB = 32, TJ = 16, NT = 512;
   extern __shared__ __attribute__((aligned(16))) float bwdx_lds[];
   const int KP = (K + 63) & ~63;       // four quarters of whole 16-wide chunks
@@ -814,7 +807,6 @@ __global__ __launch_bounds__(512, 2) void lstm_bwd_x_kernel(const ssc_lstm_bwd_d
 // latent head
 // ---------------------------------------------------------------------------------------------
 __global__ void latent_fwd_kernel(const ssc_latent_fwd_desc d) {
-  ssc_touch_args(d);
   int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   int lane = threadIdx.x & 63;
   if (b >= d.B) return;
@@ -871,7 +863,6 @@ __global__ void latent_prior_sample_kernel(const float* __restrict__ eps, int ld
 // row; the slab list is split into 256 / (64 ceil(Z/64)) contiguous parts that are summed in parallel (each in index order) and
 // combined in part order - fixed summation order, four times the loads in flight of the wave-per-row form.  Z <= 256.
 __global__ __launch_bounds__(256) void latent_fwd_wide_kernel(const ssc_latent_fwd_desc d) {
-  ssc_touch_args(d);
   __shared__ float pm_[4][64], pl_[4][64], kl_[4];
   const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int Z = d.Z;
@@ -931,7 +922,6 @@ __global__ __launch_bounds__(256) void latent_fwd_wide_kernel(const ssc_latent_f
 }
 
 __global__ void latent_bwd_kernel(const ssc_latent_bwd_desc d) {
-  ssc_touch_args(d);
   int b = blockIdx.y;
   int z = blockIdx.x * blockDim.x + threadIdx.x;
   if (z >= d.Z) return;

@@ -69,20 +69,6 @@ __device__ __forceinline__ float ssc_tanh_fast(float x) {
   return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
-// Touch every 64-byte line of a by-value kernel argument struct in ONE batch of independent scalar loads.  A kernel reads such a
-// struct field by field, often through dependent steps (a member index, a segment, a pointer, then its target), and every first
-// touch of a line of a launch's fresh kernarg buffer is a scalar-cache miss; with all lines requested up front the later loads hit
-// (gemm_x3w_kernel: first operand loads issued 1.35 instead of 2.10 us after kernel entry, -0.5 % per train step).
-template <class T>
-__device__ __forceinline__ void ssc_touch_args(const T& a) {
-  const unsigned* kp = reinterpret_cast<const unsigned*>(&a);
-  unsigned touch = 0;
-#pragma unroll
-  for (int i = 0; i < (int)(sizeof(T) / 64); ++i) touch ^= kp[16 * i];
-  touch ^= kp[sizeof(T) / 4 - 1];
-  asm volatile("" ::"s"(touch));
-}
-
 // internal cross-TU entry points (not part of the C ABI)
 int ssc_gemm_slabs(const ssc_gemm_desc* d, int splits, float* slabs, hipStream_t st);  // partial slabs only
 int ssc_attn_fwd_qslabs(const float* qslabs, int nslab, size_t slab_stride, float* q_out, int ldqo, const float* pv,
