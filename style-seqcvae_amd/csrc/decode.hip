@@ -495,7 +495,7 @@ extern "C" int ssc_decode_ungathered_ok(const ssc_model_cfg* cfg, int nimg, int 
   // the conditions under which ssc_decode_step reads every previous state through its row lists (`dedup` there, and the table)
   if (group != 0 && (group < 2 || G % group != 0)) return 0;   // (group 0: asked before the group size is known)
   return ssc_g_dec_ungathered && att_table != 0 && ssc_g_dec_att_table != 0 &&
-         nimg >= DEC_TOKEN_TABLE_MIN_IMAGES && G >= 512 && ssc_g_dec_dedup;
+         nimg >= DEC_TOKEN_TABLE_MIN_IMAGES && G >= 512 && ssc_g_dec_dedup && cfg->H % 4 == 0;
 }
 
 extern "C" int ssc_decode_step(const ssc_model_cfg* cfg, const ssc_params* p, const ssc_decode_step_desc* d, void* workspace,
@@ -526,7 +526,8 @@ extern "C" int ssc_decode_step(const ssc_model_cfg* cfg, const ssc_params* p, co
   // Beams that share their parent: the products fed only by the previous step's h1 / hd run on the distinct parents
   // (ssc_decode_step_desc.parent).  Used where the token's gate term is not part of the product (token table) and the rows are
   // many enough for the 128x128 kernels with device-side row lists.
-  const bool dedup = d->parent && d->group > 1 && G % d->group == 0 && il.token_table && !d->emb_override && G >= 512 && ssc_g_dec_dedup;
+  const bool dedup = d->parent && d->group > 1 && G % d->group == 0 && il.token_table && !d->emb_override && G >= 512 && ssc_g_dec_dedup &&
+                     H % 4 == 0;   // (16-byte operand rows: the products over the row lists are then ONE launch, one slab)
   const int* ucount = nullptr; const int* urows = nullptr; const int* slot = nullptr; const int* prow = nullptr;
   // un-gathered states: every reader of h1 / c1 / hd / cd must go through the row lists
   if (d->ungathered && !(dedup && att_table)) return SSC_EINVAL;

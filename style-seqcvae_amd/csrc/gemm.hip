@@ -2049,6 +2049,9 @@ int ssc_gemm_slabs_auto(const ssc_gemm_desc* d, float* slabs, size_t cap_floats,
     int ksteps = 0;
     for (int i = 0; i < np[g]; ++i) ksteps += ssc_cdiv(part[g].seg[i].K, BK);
     int splits = ssc_gemm_auto_splits(d->M, d->N, ksteps);
+    // a product over a device-side row list leaves ONE compact slab (its consumers index it by slot; a decode step of 512-800
+    // rows is a grid below one round of workgroups, which the split heuristic would otherwise cut along K)
+    if (d->m_count || d->a_rows || d->c_rows) splits = 1;
     while (splits > 1 && (size_t)(total + splits) * mn > cap_floats) --splits;
     if ((size_t)(total + splits) * mn > cap_floats) return SSC_EWORKSPACE;
     int per = ssc_cdiv(ksteps, splits);

@@ -650,3 +650,44 @@ def test_image_cell_kernel_equals_float64(nimg, rpi, R, H, variant):
     if variant == "general":
         act = torch.stack([torch.sigmoid(i), torch.sigmoid(fg), torch.tanh(gg), torch.sigmoid(o)], 1).reshape(G, H4)
         assert maxdiff(gates, act) < 2e-6
+
+
+def test_full_size_large_call_decode_step_matches_oracle():
+    """C4's model size (V = 10000, E / H / A = 1000 / 1200 / 768, 36 x 2048 regions, Z = 128) at a call large enough for every
+    large-call path (8 images x 14 groups x beam 5 = 560 rows: per-token gate table, per-image attended-feature table on the
+    matrix cores, products over the distinct parents, states read through the parent lists): one step from states re-ordered by
+    back-pointers against the CPU oracle (itself pinned to the reference at this call shape by g15_decode_large) - log-probs,
+    states and attention weights within 1e-4."""
+    cfg = oracle.OracleConfig(vocab_size=10000, image_feature_size=2048, embedding_size=1000, hidden_size=1200,
+                              attention_projection_size=768, z_space=128, max_caption_length=20, sentiment_vae=1,
+                              senti_prior_multip=0.5, beam_size=5)
+    params = oracle.init_params(cfg, seed=4)
+    g = torch.Generator().manual_seed(8)
+    nimg, groups, beam, R, H, Z, V = 8, 14, 5, 36, 1200, 128, 10000
+    NG, G = nimg * groups, nimg * groups * beam
+    feats = torch.randn(nimg, R, 2048, generator=g)
+    senti = torch.tensor([[1.0], [-1.0], [0.0], [1.0], [1.0], [0.0], [-1.0], [1.0]])
+    tok = torch.randint(1, V, (G,), generator=g)
+    keys = ("h1", "c1", "h_encoder", "c_encoder", "h_decoder", "c_decoder")
+    base = {k: torch.randn(NG, beam, H, generator=g) * 0.3 for k in keys}
+    parent = torch.randint(0, beam, (NG, beam), generator=g)
+    st_in = {k: v.gather(1, parent.view(NG, beam, 1).expand(NG, beam, H)).reshape(G, H).contiguous() for k, v in base.items()}
+    eps = torch.randn(G, Z, generator=g)
+    pm, pv = oracle.prior_from_sentiment(cfg, senti, nimg, feats)
+    rep = G // nimg
+    ex = lambda t: t.unsqueeze(1).expand(nimg, rep, *t.shape[1:]).reshape(G, *t.shape[1:])
+    with torch.no_grad():
+        want_lp, want_st, _, _, want_al = oracle.decode_step(params, cfg, ex(feats), tok, st_in, False, ex(senti), ex(pm), ex(pv), eps)
+    m = build_model(cfg, params)
+    m.eval()
+    m._engine()
+    dec = m._dec
+    ctx = dec.prepare(dev(feats))
+    assert dec.ungathered_ok(ctx, G, beam)
+    states = {k: dev(v.reshape(G, H)) for k, v in base.items()}
+    states["_parent"] = dev(parent)
+    states["_ungathered"] = True
+    lp, st, al = dec.step(ctx, dev(tok), states, dev(ex(senti).reshape(G)), dev(eps))
+    assert maxdiff(lp, want_lp) < 1e-4 and maxdiff(al, want_al) < 1e-5
+    for k in ("h1", "c1", "h_decoder", "c_decoder"):
+        assert maxdiff(st[k], want_st[k]) < 1e-4, k
