@@ -652,7 +652,8 @@ def test_image_cell_kernel_equals_float64(nimg, rpi, R, H, variant):
         assert maxdiff(gates, act) < 2e-6
 
 
-def test_full_size_large_call_decode_step_matches_oracle():
+@pytest.mark.parametrize("nimg,groups,beam", [(8, 14, 5), (8, 13, 5), (10, 12, 5), (26, 4, 5), (40, 3, 5), (8, 40, 3), (16, 4, 5)])
+def test_full_size_large_call_decode_step_matches_oracle(nimg, groups, beam):
     """C4's model size (V = 10000, E / H / A = 1000 / 1200 / 768, 36 x 2048 regions, Z = 128) at a call large enough for every
     large-call path (8 images x 14 groups x beam 5 = 560 rows: per-token gate table, per-image attended-feature table on the
     matrix cores, products over the distinct parents, states read through the parent lists): one step from states re-ordered by
@@ -662,11 +663,11 @@ def test_full_size_large_call_decode_step_matches_oracle():
                               attention_projection_size=768, z_space=128, max_caption_length=20, sentiment_vae=1,
                               senti_prior_multip=0.5, beam_size=5)
     params = oracle.init_params(cfg, seed=4)
-    g = torch.Generator().manual_seed(8)
-    nimg, groups, beam, R, H, Z, V = 8, 14, 5, 36, 1200, 128, 10000
+    g = torch.Generator().manual_seed(8 + nimg)
+    R, H, Z, V = 36, 1200, 128, 10000
     NG, G = nimg * groups, nimg * groups * beam
     feats = torch.randn(nimg, R, 2048, generator=g)
-    senti = torch.tensor([[1.0], [-1.0], [0.0], [1.0], [1.0], [0.0], [-1.0], [1.0]])
+    senti = torch.randint(-1, 2, (nimg, 1), generator=g).float()
     tok = torch.randint(1, V, (G,), generator=g)
     keys = ("h1", "c1", "h_encoder", "c_encoder", "h_decoder", "c_decoder")
     base = {k: torch.randn(NG, beam, H, generator=g) * 0.3 for k in keys}
@@ -683,10 +684,16 @@ def test_full_size_large_call_decode_step_matches_oracle():
     m._engine()
     dec = m._dec
     ctx = dec.prepare(dev(feats))
-    assert dec.ungathered_ok(ctx, G, beam)
-    states = {k: dev(v.reshape(G, H)) for k, v in base.items()}
+    # the call shapes straddle the thresholds of the large-call paths: 512 rows per step, 16 rows per image, 8 images per call
+    # ((8, 14, 5) = 560 and (8, 13, 5) = 520 rows are grids below one round of workgroups at this width; (40, 3, 5) shares parents
+    # without the table; (16, 4, 5) = 320 rows takes none of them)
+    if dec.ungathered_ok(ctx, G, beam):
+        states = {k: dev(v.reshape(G, H)) for k, v in base.items()}
+        states["_ungathered"] = True
+    else:
+        states = {k: dev(v) for k, v in st_in.items()}
+    assert dec.ungathered_ok(ctx, G, beam) == (G >= 512 and groups * beam >= 16)
     states["_parent"] = dev(parent)
-    states["_ungathered"] = True
     lp, st, al = dec.step(ctx, dev(tok), states, dev(ex(senti).reshape(G)), dev(eps))
     assert maxdiff(lp, want_lp) < 1e-4 and maxdiff(al, want_al) < 1e-5
     for k in ("h1", "c1", "h_decoder", "c_decoder"):
