@@ -125,6 +125,14 @@ def test_train_sv2_matches_oracle_medium():
     # (V = 777), tied head (E = 300: frozen table, Linear + Tanh projection) here, and a large untied one
     (1, 6, 7, dict(V=451, E=300, H=64, A=48, F=128, Z=16, L=6)),
     (1, 64, 6, dict(V=2003, E=128, H=256, A=128, F=256, Z=32, L=5)),
+    # FULL width (C2's model: what the kernel-form and split-K decisions of the launchers see in production), short captions to
+    # keep the CPU oracle at seconds: minibatches on either side of the 64-row and 128-row tile boundaries and the yaml's 150
+    (1, 65, 36, dict(V=10000, E=1000, H=1200, A=768, F=2048, Z=128, L=3)),
+    (1, 130, 36, dict(V=10000, E=1000, H=1200, A=768, F=2048, Z=128, L=3)),
+    (0, 150, 36, dict(V=10000, E=1000, H=1200, A=768, F=2048, Z=128, L=3)),
+    (1, 33, 36, dict(V=10000, E=1000, H=1200, A=768, F=2048, Z=128, L=4)),
+    # BASELINE configs[4] (C5) at FULL width: B = 128 per GPU, 100 regions, V = 30000 (captions cut to 3 tokens for the CPU oracle)
+    (1, 128, 100, dict(V=30000, E=1000, H=1200, A=768, F=2048, Z=128, L=3)),
 ])
 def test_train_matches_oracle_medium(sv, B, R, dims):
     cfg = oracle.OracleConfig(vocab_size=dims["V"], image_feature_size=dims["F"], embedding_size=dims["E"],
