@@ -652,19 +652,21 @@ def test_image_cell_kernel_equals_float64(nimg, rpi, R, H, variant):
         assert maxdiff(gates, act) < 2e-6
 
 
-@pytest.mark.parametrize("nimg,groups,beam", [(8, 14, 5), (8, 13, 5), (10, 12, 5), (26, 4, 5), (40, 3, 5), (8, 40, 3), (16, 4, 5)])
-def test_full_size_large_call_decode_step_matches_oracle(nimg, groups, beam):
+@pytest.mark.parametrize("nimg,groups,beam,sv,R", [(8, 14, 5, 1, 36), (8, 13, 5, 1, 36), (10, 12, 5, 0, 36), (26, 4, 5, 1, 36),
+                                                   (40, 3, 5, 1, 36), (8, 40, 3, 1, 36), (16, 4, 5, 1, 36), (9, 14, 5, 0, 36),
+                                                   (8, 14, 5, 1, 50), (8, 14, 5, 1, 100), (8, 14, 5, 1, 27)])
+def test_full_size_large_call_decode_step_matches_oracle(nimg, groups, beam, sv, R):
     """C4's model size (V = 10000, E / H / A = 1000 / 1200 / 768, 36 x 2048 regions, Z = 128) at a call large enough for every
     large-call path (8 images x 14 groups x beam 5 = 560 rows: per-token gate table, per-image attended-feature table on the
     matrix cores, products over the distinct parents, states read through the parent lists): one step from states re-ordered by
     back-pointers against the CPU oracle (itself pinned to the reference at this call shape by g15_decode_large) - log-probs,
     states and attention weights within 1e-4."""
     cfg = oracle.OracleConfig(vocab_size=10000, image_feature_size=2048, embedding_size=1000, hidden_size=1200,
-                              attention_projection_size=768, z_space=128, max_caption_length=20, sentiment_vae=1,
+                              attention_projection_size=768, z_space=128, max_caption_length=20, sentiment_vae=sv,
                               senti_prior_multip=0.5, beam_size=5)
     params = oracle.init_params(cfg, seed=4)
     g = torch.Generator().manual_seed(8 + nimg)
-    R, H, Z, V = 36, 1200, 128, 10000
+    H, Z, V = 1200, 128, 10000   # (R = 50 / 100: the image cell's 17 / 33 k-step forms; 27: a partial last k-step)
     NG, G = nimg * groups, nimg * groups * beam
     feats = torch.randn(nimg, R, 2048, generator=g)
     senti = torch.randint(-1, 2, (nimg, 1), generator=g).float()

@@ -131,6 +131,8 @@ def test_train_sv2_matches_oracle_medium():
     (1, 130, 36, dict(V=10000, E=1000, H=1200, A=768, F=2048, Z=128, L=3)),
     (0, 150, 36, dict(V=10000, E=1000, H=1200, A=768, F=2048, Z=128, L=3)),
     (1, 33, 36, dict(V=10000, E=1000, H=1200, A=768, F=2048, Z=128, L=4)),
+    (1, 1, 36, dict(V=10000, E=1000, H=1200, A=768, F=2048, Z=128, L=4)),
+    (0, 2, 9, dict(V=10000, E=1000, H=1200, A=768, F=2048, Z=128, L=3)),
     # BASELINE configs[4] (C5) at FULL width: B = 128 per GPU, 100 regions, V = 30000 (captions cut to 3 tokens for the CPU oracle)
     (1, 128, 100, dict(V=30000, E=1000, H=1200, A=768, F=2048, Z=128, L=3)),
 ])
