@@ -201,6 +201,7 @@ def measure_decode(model, c, rank, world, device, images, warmup):
     was_training = model.training
     model.eval()
     dec = model._dec
+    dec.weights_frozen = os.environ.get("SSC_BENCH_NO_REUSE") != "1"   # an inference run: the parameters do not change between the calls (what scripts/inference.py sets; the variable is the A/B switch)
     chunk = 50                       # images per beam-search call: 50 x 20 samples x 5 beams = 5000 rows
     per_rank = images // world
     n_chunks = max(1, per_rank // chunk)
@@ -239,6 +240,8 @@ def measure_decode(model, c, rank, world, device, images, warmup):
             el, tokens, rows_steps = float(tmax[0]), float(t[1]), float(t[2])
         results[early] = (el, tokens, rows_steps)
     droof = decode_roofline(dec, feats[0], senti, c) if rank == 0 else None
+    dec.weights_frozen = False       # (the train leg that may follow changes the weights)
+    dec._last_ctx = None
     if was_training:
         model.train()
     if rank != 0:

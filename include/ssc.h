@@ -404,6 +404,11 @@ int ssc_xgmi_allreduce(const ssc_xgmi_comm* c, size_t lo, size_t hi, unsigned se
 size_t ssc_decode_image_bytes(const ssc_model_cfg* cfg, int nimg, int R);
 int ssc_decode_prepare(const ssc_model_cfg* cfg, const ssc_params* p, const float* feats, int nimg, int R, void* imgbuf,
                        size_t imgbuf_bytes, void* stream);
+/* The same; `prev_imgbuf` (optional) is the image buffer of an EARLIER context (prev_nimg images, prev_R regions) prepared with
+ * the SAME parameter values - the caller's promise: weights fixed over an inference run -; what depends on the weights alone (the
+ * per-token gate table, V x 4H) is copied from it instead of being formed again. */
+int ssc_decode_prepare_from(const ssc_model_cfg* cfg, const ssc_params* p, const float* feats, int nimg, int R, void* imgbuf,
+                            size_t imgbuf_bytes, const void* prev_imgbuf, int prev_nimg, int prev_R, void* stream);
 
 typedef struct {
   int G, R, rows_per_image;

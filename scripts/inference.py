@@ -77,6 +77,7 @@ def main():
         model.load_state_dict(torch.load(_A.checkpoint_path, map_location=device, weights_only=True)["model"])
     model.eval()
     model._engine()
+    model._dec.weights_frozen = True   # the checkpoint's weights stay as they are for the whole run: weight-only tables are formed once
     n_z = max(1, _C.MODEL.N_Z_SAMPLES)
     beam = _C.MODEL.BEAM_SIZE
     boundary = vocabulary.get_token_index("@@BOUNDARY@@")

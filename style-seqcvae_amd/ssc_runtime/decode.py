@@ -33,6 +33,12 @@ class DecodeEngine:
         self._params = params_struct_fn
         self._ws = None
         self._ws_key = None
+        # weights_frozen: the caller's promise that the parameters do not change between prepare() calls (an inference run over a
+        # loaded checkpoint: scripts/inference.py, bench.py's decode leg).  What ssc_decode_prepare derives from the weights alone
+        # (the per-token gate table) is then taken over from the previous image context instead of being formed per call.
+        # Default off: the drop-in module's eval calls may be interleaved with training steps.
+        self.weights_frozen = False
+        self._last_ctx = None
 
     def prepare(self, feats: torch.Tensor) -> ImageContext:
         assert feats.is_cuda and feats.dtype == torch.float32 and feats.dim() == 3 and feats.size(2) == self.dims.F
@@ -41,9 +47,14 @@ class DecodeEngine:
         nbytes = self.lib.ssc_decode_image_bytes(C.byref(self._cfg), nimg, R)
         buf = torch.empty(nbytes // 4 + 64, dtype=torch.float32, device=self.device)
         p = self._params()
-        self.lib.ssc_decode_prepare(C.byref(self._cfg), C.byref(p), _lib.ptr(feats), nimg, R, _lib.ptr(buf), buf.numel() * 4,
-                                    _lib.stream_ptr())
-        return ImageContext(feats, buf)
+        prev = self._last_ctx if self.weights_frozen else None
+        self.lib.ssc_decode_prepare_from(C.byref(self._cfg), C.byref(p), _lib.ptr(feats), nimg, R, _lib.ptr(buf), buf.numel() * 4,
+                                         _lib.ptr(prev.buf) if prev is not None else None, prev.nimg if prev is not None else 0,
+                                         prev.R if prev is not None else 0, _lib.stream_ptr())
+        ctx = ImageContext(feats, buf)
+        # (kept alive by this reference: the copy above is stream-ordered before anything that could overwrite the old buffer)
+        self._last_ctx = ctx if self.weights_frozen else None
+        return ctx
 
     # The attended-feature term of the decoder gates from a per-image table (ssc_decode_step_desc.att_table): worth its one-off
     # product per image context once a step has a few hundred rows that share their image sixteen or more at a time (C4: 5000

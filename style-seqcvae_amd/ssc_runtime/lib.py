@@ -165,6 +165,7 @@ SYMBOLS = {
     "ssc_xgmi_allreduce": (_i, [C.POINTER(XgmiComm), _sz, _sz, C.c_uint, C.c_uint, vp, vp]),
     "ssc_decode_image_bytes": (_sz, [C.POINTER(ModelCfg), _i, _i]),
     "ssc_decode_prepare": (_i, [C.POINTER(ModelCfg), C.POINTER(Params), vp, _i, _i, vp, _sz, vp]),
+    "ssc_decode_prepare_from": (_i, [C.POINTER(ModelCfg), C.POINTER(Params), vp, _i, _i, vp, _sz, vp, _i, _i, vp]),
     "ssc_decode_step_workspace_bytes": (_sz, [C.POINTER(ModelCfg), _i, _i]),
     "ssc_decode_step": (_i, [C.POINTER(ModelCfg), C.POINTER(Params), C.POINTER(DecodeStepDesc), vp, _sz, vp]),
     "ssc_decode_ungathered_ok": (_i, [C.POINTER(ModelCfg), _i, _i, _i, _i]),

@@ -700,3 +700,39 @@ def test_full_size_large_call_decode_step_matches_oracle(nimg, groups, beam, sv,
     assert maxdiff(lp, want_lp) < 1e-4 and maxdiff(al, want_al) < 1e-5
     for k in ("h1", "c1", "h_decoder", "c_decoder"):
         assert maxdiff(st[k], want_st[k]) < 1e-4, k
+
+
+def test_weight_only_tables_are_taken_over_between_image_contexts():
+    """DecodeEngine.weights_frozen: the per-token gate table of ssc_decode_prepare depends on the weights alone and is copied from
+    the previous image context (ssc_decode_prepare_from) - a step on a context prepared that way is bit-equal to one on a context
+    prepared from scratch, for a different image count and region count than the context the table came from."""
+    from ssc_runtime.vocab import Vocabulary
+    from var_updown.models import UpDownCaptioner
+    V, F, E, H, A, Z = 300, 64, 40, 48, 24, 8
+    torch.manual_seed(5)
+    m = UpDownCaptioner(Vocabulary.synthetic(V), image_feature_size=F, embedding_size=E, hidden_size=H,
+                        attention_projection_size=A, max_caption_length=8, beam_size=3, z_space=Z, prior_std=1.0,
+                        simple_vae=False, latent_embedding="glove", sentiment_vae=1, senti_prior_multip=0.5,
+                        device=torch.device("cuda")).to("cuda")
+    m.eval()
+    m._engine()
+    dec = m._dec
+    g = torch.Generator().manual_seed(6)
+    feats_a = torch.randn(12, 7, F, generator=g).cuda()
+    feats_b = torch.randn(9, 5, F, generator=g).cuda()
+    G = 9 * 6
+    tok = torch.randint(0, V, (G,), generator=g).cuda()
+    sent = torch.randint(-1, 2, (G,), generator=g).float().cuda()
+    eps = torch.randn(G, Z, generator=g).cuda()
+    fresh = dec.step(dec.prepare(feats_b), tok, None, sent, eps)
+    dec.weights_frozen = True
+    try:
+        dec.prepare(feats_a)                        # leaves its table behind
+        assert dec._last_ctx is not None
+        reused = dec.step(dec.prepare(feats_b), tok, None, sent, eps)
+    finally:
+        dec.weights_frozen = False
+        dec._last_ctx = None
+    assert torch.equal(fresh[0], reused[0]) and torch.equal(fresh[2], reused[2])
+    for k in ("h1", "c1", "h_decoder", "c_decoder"):
+        assert torch.equal(fresh[1][k], reused[1][k]), k
