@@ -736,3 +736,42 @@ def test_weight_only_tables_are_taken_over_between_image_contexts():
     assert torch.equal(fresh[0], reused[0]) and torch.equal(fresh[2], reused[2])
     for k in ("h1", "c1", "h_decoder", "c_decoder"):
         assert torch.equal(fresh[1][k], reused[1][k]), k
+
+
+def test_large_call_paths_with_a_multi_state_machine_leave_the_search_unchanged():
+    """The large-call decode paths under constrained beam search with S = 3 machine states: groups of S x beam = 15 rows
+    (back-pointers range over the whole group), 8 images x 5 samples x 15 = 600 rows per step - against the same search with the
+    parent sharing, the attended-feature table and the un-gathered states switched off: identical beams for every state."""
+    from ssc_runtime import lib as L
+    from ssc_runtime.inference import diverse_decode
+    from ssc_runtime.vocab import Vocabulary
+    from var_updown.models import UpDownCaptioner
+    lib = L.load()
+    V, F, E, H, A, Z, R = 350, 64, 40, 64, 24, 8, 6
+    torch.manual_seed(13)
+    m = UpDownCaptioner(Vocabulary.synthetic(V), image_feature_size=F, embedding_size=E, hidden_size=H,
+                        attention_projection_size=A, max_caption_length=7, beam_size=5, z_space=Z, prior_std=1.0,
+                        simple_vae=False, latent_embedding="glove", sentiment_vae=1, senti_prior_multip=0.5,
+                        device=torch.device("cuda")).to("cuda")
+    m.eval()
+    m._engine()
+    dec = m._dec
+    g = torch.Generator().manual_seed(4)
+    nimg, ns, beam, S = 8, 5, 5, 3
+    B = nimg * ns
+    feats = torch.randn(nimg, R, F, generator=g).cuda()
+    senti = torch.randint(-1, 2, (nimg,), generator=g).float().cuda()
+    fsm = make_fsm(B, S, V, seed=77).cuda()
+    ncons = torch.ones(B, dtype=torch.long)
+    eps = [torch.randn(B, Z, generator=g).cuda()] + [torch.randn(B * S * beam, Z, generator=g).cuda() for _ in range(8)]
+    outs = []
+    for on in (1, 0):
+        for key in (b"dec_dedup", b"dec_att_table", b"dec_ungathered"):
+            lib.ssc_debug_set(key, on)
+        try:
+            outs.append(diverse_decode(dec, feats, senti, ns, beam, 7, 1, fsm=fsm, num_constraints=ncons, min_constraints_to_satisfy=1,
+                                       eps_steps=[e.clone() for e in eps], early_stop=False)[0].clone())
+        finally:
+            for key in (b"dec_dedup", b"dec_att_table", b"dec_ungathered"):
+                lib.ssc_debug_set(key, 1)
+    assert torch.equal(outs[0], outs[1])
