@@ -6,14 +6,13 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "style-seqcvae_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: E402
 
-import oracle  # noqa: E402  (parameter initialisation only)
-from gpuutil import engine_from  # noqa: E402
 from ssc_runtime import lib as L  # noqa: E402
+from ssc_runtime.vocab import Vocabulary  # noqa: E402
+from var_updown.models import UpDownCaptioner  # noqa: E402
 
 
 def main():
@@ -29,10 +28,12 @@ def main():
         Z = pick([128, 128, 150, 64])
         L_ = pick([1, 2, 3, 5, 8])
         sv = pick([1, 1, 0])
-        cfg = oracle.OracleConfig(vocab_size=V, image_feature_size=2048, embedding_size=1000, hidden_size=1200,
-                                  attention_projection_size=768, z_space=Z, max_caption_length=L_, sentiment_vae=sv,
-                                  senti_prior_multip=0.5)
-        params = oracle.init_params(cfg, seed=3)
+        torch.manual_seed(3)
+        model = UpDownCaptioner(Vocabulary.synthetic(V), image_feature_size=2048, embedding_size=1000, hidden_size=1200,
+                                attention_projection_size=768, max_caption_length=L_, beam_size=5, z_space=Z, prior_std=1.0,
+                                simple_vae=False, latent_embedding="glove", sentiment_vae=sv, senti_prior_multip=0.5,
+                                device=torch.device("cuda")).to("cuda")
+        model.train()
         B = pick([1, 2, 7, 31, 32, 33, 63, 64, 65, 96, 127, 128, 129, 150, 192, 200, 256])
         R = pick([5, 36, 36, 64, 100])
         T = L_ + 1
@@ -49,12 +50,11 @@ def main():
         for mode in (1, 0):
             lib.ssc_set_gemm_mode(mode)
             try:
-                eng = engine_from(cfg, params)
+                eng = model._engine()
                 loss, kld = eng.forward(feats.cuda(), caps.cuda(), senti.cuda(), eps.cuda())
                 eng.backward(torch.full((B,), 1.0 / B, device="cuda"), torch.full((B,), 1.0 / (B * 750.0), device="cuda"))
                 torch.cuda.synchronize()
                 res.append((loss.clone(), kld.clone(), {k: v.clone() for k, v in eng.grad_dict().items()}))
-                del eng
             finally:
                 lib.ssc_set_gemm_mode(1)
         dl = float((res[0][0] - res[1][0]).abs().max()) / (float(res[1][0].abs().max()) + 1.0)
