@@ -775,3 +775,54 @@ def test_large_call_paths_with_a_multi_state_machine_leave_the_search_unchanged(
             for key in (b"dec_dedup", b"dec_att_table", b"dec_ungathered"):
                 lib.ssc_debug_set(key, 1)
     assert torch.equal(outs[0], outs[1])
+
+
+def _random_cbs_cases():
+    g = torch.Generator().manual_seed(20261005)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+    pick = lambda xs: xs[ri(0, len(xs) - 1)]
+    cases = []
+    for V in (64, 1000, 5000, 10000, 10240, 10241, 12000, 300, 2500, 7777):   # <= 10240: row in registers; above: LDS-staged
+        S = pick([1, 2, 3])
+        beam = pick([1, 2, 3, 5])
+        cases.append((ri(1, 3), S, V, beam, pick([1, 2, min(5, max(1, beam))]), pick([0.15, 0.5, 0.9]), ri(4, 9)))
+    return cases
+
+
+@pytest.mark.parametrize("B,S,V,beam,per_node,density,steps", _random_cbs_cases())
+def test_cbs_search_random_configs_match_oracle(B, S, V, beam, per_node, density, steps):
+    """Seeded random search configurations (vocabulary sizes on both sides of the selection kernels' 10240-entry register form,
+    machine states, beam / per-node widths, mask densities, step counts) against the oracle's search (pinned to the reference's
+    cbs.py by g12_cbs).  The step function is evaluated on the CPU for BOTH sides, so the log-probs are the same bits and every
+    difference would be the bookkeeping's: masked top-k per target state, merge, back-pointers, state re-ordering, forced ends."""
+    g = torch.Generator().manual_seed(V * 31 + S * 7 + beam)
+    U = torch.randn(V, 12, generator=g)
+    W = torch.randn(12, V, generator=g) * 1.5
+    drift = torch.randn(5, V, generator=g) * 0.5
+    endb = 2.5 if density > 0.4 else 0.5
+    fsm = (torch.rand(B, S, S, V, generator=g) < density).to(torch.uint8)
+    fsm[:, :, :, 1] = 1          # the end token is always allowed
+    fsm[:, :, :, 2:6] = 1        # and a few others, so that no state is left without a finite candidate
+
+    def step_cpu(tokens, state):
+        G = tokens.numel()
+        cnt = torch.zeros(G, 1) if state is None else state["cnt"]
+        acc = torch.zeros(G, 2) if state is None else state["acc"]
+        logits = U[tokens] @ W + drift[cnt.long().view(-1) % 5] + acc.sum(1, keepdim=True) * 0.02
+        logits[:, 1] += endb
+        new = {"cnt": cnt + 1, "acc": (acc + tokens.view(-1, 1).float() * torch.tensor([[1.0, 0.5]])) % 3.0}
+        return torch.log_softmax(logits, dim=1), new
+
+    def step_gpu(tokens, state):
+        st = None if state is None else {k: v.cpu() for k, v in state.items() if not k.startswith("_")}
+        lp, new = step_cpu(tokens.cpu(), st)
+        return lp.cuda(), {k: v.cuda() for k, v in new.items()}
+
+    start = torch.full((B,), 1, dtype=torch.long)
+    want_p, want_lp = oracle.cbs_search(start, None, step_cpu, fsm, end_index=1, max_steps=steps, beam_size=beam,
+                                        per_node_beam_size=per_node)
+    got_p, got_lp = cbs_search(start.cuda(), None, step_gpu, fsm.cuda(), 1, steps, beam, per_node)
+    assert got_p.shape == want_p.shape
+    finite = torch.isfinite(want_lp) & (want_lp > -1e19)
+    assert torch.equal(got_p.cpu()[finite], want_p[finite])
+    assert maxdiff(got_lp.cpu()[finite], want_lp[finite]) < 1e-5
