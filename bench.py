@@ -193,8 +193,10 @@ def decode_roofline(dec, feats, senti, c):
 
 def measure_decode(model, c, rank, world, device, images, warmup):
     """BASELINE.json configs[3] (C4): beam 5 (per-node 2) x 20 latent samples per image, 36x2048 features, max 20
-    steps, trivial one-state FSM, images sharded over ranks (no collective).  A "step" = one chunk of 50 images
-    (5000 rows per beam-search call).  Returns the result dict on rank 0 (None elsewhere)."""
+    steps, trivial one-state FSM, images sharded over ranks (no collective).  A "step" = one chunk of 100 images
+    (10000 rows per beam-search call: how many images share a call is the harness's choice - the reference decodes one image at
+    a time, inference.py:95; from 100 images on the rate is flat, 50 cost 4 %: 5000 rows leave the last 128-row tile row of
+    every product 94 % empty and a thirteenth, a third full, round of workgroups).  Returns the result dict on rank 0 (None elsewhere)."""
     import torch.distributed as dist
     from ssc_runtime.inference import count_tokens, diverse_decode
 
@@ -202,7 +204,8 @@ def measure_decode(model, c, rank, world, device, images, warmup):
     model.eval()
     dec = model._dec
     dec.weights_frozen = os.environ.get("SSC_BENCH_NO_REUSE") != "1"   # an inference run: the parameters do not change between the calls (what scripts/inference.py sets; the variable is the A/B switch)
-    chunk = 50                       # images per beam-search call: 50 x 20 samples x 5 beams = 5000 rows
+    chunk = int(os.environ.get("SSC_BENCH_DECODE_CHUNK", "100"))   # images per beam-search call: 100 x 20 samples x 5 beams = 10000 rows (the variable is the A/B switch)
+    chunk = max(1, min(chunk, images // world))
     per_rank = images // world
     n_chunks = max(1, per_rank // chunk)
     g = torch.Generator().manual_seed(4321 + rank)

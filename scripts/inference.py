@@ -33,7 +33,7 @@ parser.add_argument("--infer-tensors", default="")
 parser.add_argument("--synthetic", type=int, default=0)
 parser.add_argument("--vocab-size", type=int, default=10000)
 parser.add_argument("--num-boxes", type=int, default=36)
-parser.add_argument("--images-per-call", type=int, default=50)
+parser.add_argument("--images-per-call", type=int, default=100)
 parser.add_argument("--sentiment", type=float, default=None, help="override the per-image sentiment (-1, 0, 1)")
 parser.add_argument("--constraints-json", default="",
                     help='constrained beam search: {"<image_id>": ["dog", "fire hydrant", ...]} - up to DATA.CBS.MAX_GIVEN_CONSTRAINTS '
