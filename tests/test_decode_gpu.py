@@ -826,3 +826,27 @@ def test_cbs_search_random_configs_match_oracle(B, S, V, beam, per_node, density
     finite = torch.isfinite(want_lp) & (want_lp > -1e19)
     assert torch.equal(got_p.cpu()[finite], want_p[finite])
     assert maxdiff(got_lp.cpu()[finite], want_lp[finite]) < 1e-5
+
+
+@pytest.mark.parametrize("every", [2, 4, 7])
+def test_lagging_early_stop_check_gives_the_output_of_the_per_step_check(every):
+    """cbs_search(early_stop_every = n > 1) asks the device every n steps whether every beam has ended and reads the answer
+    without waiting (pinned flag behind an event), so it may run a few surplus steps; their all-END columns are trimmed: the same
+    predictions, log-probs and number of columns as the per-step check of cbs.py:167."""
+    B, V, beam, steps = 5, 200, 3, 16
+    g = torch.Generator().manual_seed(31)
+    table = (torch.randn(V, V, generator=g) * 1.5)
+    table[:, 1] += 6.0          # the end token wins quickly: every beam has ended after a few steps
+    table = table.cuda()
+
+    def step(tokens, state):
+        return torch.log_softmax(table[tokens], dim=1), {"h": torch.zeros(tokens.numel(), 2, device="cuda")}
+
+    start = torch.full((B,), 1, dtype=torch.long, device="cuda")
+    a, alp = cbs_search(start, None, step, None, 1, steps, beam, 2, early_stop=True, early_stop_every=1)
+    assert a.shape[-1] < steps          # it did stop early
+    torch.cuda.synchronize()
+    b, blp = cbs_search(start, None, step, None, 1, steps, beam, 2, early_stop=True, early_stop_every=every)
+    assert a.shape == b.shape and torch.equal(a, b) and torch.equal(alp, blp)
+    c, clp = cbs_search(start, None, step, None, 1, steps, beam, 2, early_stop=False)
+    assert c.shape[-1] == steps and torch.equal(c[..., :a.shape[-1]], a) and torch.equal(clp, alp)
