@@ -28,6 +28,7 @@ struct ImgLayout {
 // of the beam's last token (ssc_lstm_fwd_desc.add0_rows), instead of a K = E segment of the gate product in every step
 // (5000 x 4800 x 1000 per step at C4: 0.25 ms x 20 steps).  Below it (a handful of rows per step) the segment is cheaper.
 constexpr int DEC_TOKEN_TABLE_MIN_IMAGES = 8;
+constexpr int DEDUP_MAX_ROWS = 56 * 1024;   // the parent sharing keeps one byte per row in the LDS of one workgroup
 }  // namespace
 int ssc_g_beam_reg = ssc_env_int("SSC_BEAM_REG", 1);   // 0: the LDS-staged selection kernel for every vocabulary size
 int ssc_g_dec_dedup = ssc_env_int("SSC_DEC_DEDUP", 1);   // ssc_debug_set("dec_dedup"): products fed only by the parent's states run on distinct parents
@@ -399,16 +400,21 @@ __global__ void gather_rows_kernel(const float* __restrict__ src, int ld, const 
 // order): prow[g] = (g - g % group) + parent[g] and the representative rows are the classes' parent rows; else prow[g] = g.
 __global__ __launch_bounds__(1024) void dedup_rows_kernel(const int64_t* __restrict__ parent, int n, int group, int* __restrict__ out,
                                                           int ungathered) {
+  // the back-pointers go to LDS once (one byte each: group <= 255, checked by the caller; n <= DEDUP_MAX_ROWS) - every later look
+  // at a neighbour's parent is an LDS read instead of a dependent global load (38 us -> ~8 us at 10000 rows)
+  extern __shared__ unsigned char sp[];
   __shared__ int part[1024];
   const int tid = threadIdx.x;
   int* urows = out + 4;
   int* slot = out + 4 + n;
   int* prow = out + 4 + 2 * n;
+  for (int g = tid; g < n; g += 1024) sp[g] = (unsigned char)parent[g];
+  __syncthreads();
   auto first_of = [&](int g) -> int {   // the first row of g's group with the same parent
     const int g0 = g - g % group;
-    const int64_t pg = parent[g];
+    const unsigned char pg = sp[g];
     for (int k = g0; k < g; ++k)
-      if (parent[k] == pg) return k;
+      if (sp[k] == pg) return k;
     return g;
   };
   const int per = (n + 1023) / 1024;
@@ -425,7 +431,7 @@ __global__ __launch_bounds__(1024) void dedup_rows_kernel(const int64_t* __restr
   }
   int pos = part[tid] - cnt;
   for (int g = lo; g < hi; ++g)
-    if (first_of(g) == g) { urows[pos] = ungathered ? g - g % group + (int)parent[g] : g; slot[g] = pos; ++pos; }
+    if (first_of(g) == g) { urows[pos] = ungathered ? g - g % group + (int)sp[g] : g; slot[g] = pos; ++pos; }
   if (tid == 1023) out[0] = part[1023];
   for (int i = part[1023] + tid; i < n; i += 1024) urows[i] = 0;   // entries past the count are never used; keep them in range
   __syncthreads();
@@ -435,7 +441,7 @@ __global__ __launch_bounds__(1024) void dedup_rows_kernel(const int64_t* __restr
   for (int g = lo; g < hi; ++g) {
     const int f = first_of(g);
     if (f != g) slot[g] = slot[f];
-    prow[g] = ungathered ? g - g % group + (int)parent[g] : g;
+    prow[g] = ungathered ? g - g % group + (int)sp[g] : g;
   }
 }
 
@@ -512,7 +518,7 @@ extern "C" int ssc_decode_ungathered_ok(const ssc_model_cfg* cfg, int nimg, int 
   // the conditions under which ssc_decode_step reads every previous state through its row lists (`dedup` there, and the table)
   if (group != 0 && (group < 2 || G % group != 0)) return 0;   // (group 0: asked before the group size is known)
   return ssc_g_dec_ungathered && att_table != 0 && ssc_g_dec_att_table != 0 &&
-         nimg >= DEC_TOKEN_TABLE_MIN_IMAGES && G >= 512 && ssc_g_dec_dedup && cfg->H % 4 == 0;
+         nimg >= DEC_TOKEN_TABLE_MIN_IMAGES && G >= 512 && G <= DEDUP_MAX_ROWS && group <= 255 && ssc_g_dec_dedup && cfg->H % 4 == 0;
 }
 
 extern "C" int ssc_decode_step(const ssc_model_cfg* cfg, const ssc_params* p, const ssc_decode_step_desc* d, void* workspace,
@@ -543,14 +549,14 @@ extern "C" int ssc_decode_step(const ssc_model_cfg* cfg, const ssc_params* p, co
   // Beams that share their parent: the products fed only by the previous step's h1 / hd run on the distinct parents
   // (ssc_decode_step_desc.parent).  Used where the token's gate term is not part of the product (token table) and the rows are
   // many enough for the 128x128 kernels with device-side row lists.
-  const bool dedup = d->parent && d->group > 1 && G % d->group == 0 && il.token_table && !d->emb_override && G >= 512 && ssc_g_dec_dedup &&
-                     H % 4 == 0;   // (16-byte operand rows: the products over the row lists are then ONE launch, one slab)
+  const bool dedup = d->parent && d->group > 1 && d->group <= 255 && G <= DEDUP_MAX_ROWS && G % d->group == 0 && il.token_table &&
+                     !d->emb_override && G >= 512 && ssc_g_dec_dedup && H % 4 == 0;   // (16-byte operand rows: the products over the row lists are then ONE launch, one slab)
   const int* ucount = nullptr; const int* urows = nullptr; const int* slot = nullptr; const int* prow = nullptr;
   // un-gathered states: every reader of h1 / c1 / hd / cd must go through the row lists
   if (d->ungathered && !(dedup && att_table)) return SSC_EINVAL;
   if (dedup) {
     int* dd = reinterpret_cast<int*>(W + l.dedup);
-    SSC_LAUNCH(dedup_rows_kernel, dim3(1), dim3(1024), 0, st, d->parent, G, d->group, dd, d->ungathered ? 1 : 0);
+    SSC_LAUNCH(dedup_rows_kernel, dim3(1), dim3(1024), (size_t)((G + 15) & ~15), st, d->parent, G, d->group, dd, d->ungathered ? 1 : 0);
     SSC_CHECK_LAUNCH();
     ucount = dd; urows = dd + 4; slot = dd + 4 + G; prow = dd + 4 + 2 * G;
   }
