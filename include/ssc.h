@@ -36,7 +36,7 @@ extern "C" {
 
 #define SSC_MAX_SEG 6
 
-int ssc_version(void);              /* ABI version (this header: 3) */
+int ssc_version(void);              /* ABI version (this header: 4) */
 int ssc_last_hip_error(void);       /* last hipError_t observed by this thread */
 const char* ssc_arch(void);         /* "gfx950" */
 
@@ -477,6 +477,70 @@ int ssc_gather_rows(const float* src, int ld, const int64_t* backptr, int B, int
 /* back-trace (cbs.py:252-277): preds (steps,B,SB) int64, backptrs (steps-1,B,SB) int64 -> out (B,SB,steps). */
 int ssc_beam_backtrace(const int64_t* preds, const int64_t* backptrs, int steps, int B, int SB, int64_t* out,
                        void* stream);
+
+
+/* ------------------------------------------------------------------------------------------------
+ * Compiled finite-state machines for constrained beam search.
+ * The reference keeps a machine as a dense adjacency tensor fsm[from, to, token] (uint8, (S,S,V):
+ * updown-baseline/updown/utils/constraints.py:328-478) and its search scans every row's V log-probs and V mask
+ * bytes once per TARGET state (cbs.py:157-250: `for i in range(num_fsm_states)` masked_fill + topk).
+ * The machines the reference builds send almost every token of a from-state to ONE target set (the self-loop
+ * of a main state, the reset state of a sub-state); only the word forms of the constraint words differ.
+ * ssc_fsm_compile turns each (machine, from-state) into
+ *     default target set (bit i = state i) | <= E exception tokens, ascending, each with its target set |
+ *     an "is exception" bitmap over V | the P smallest non-exception tokens,
+ * and ssc_beam_step_fsm makes ONE scan per row - the top per_node non-exception tokens - and then selects, per
+ * target state, among those, the exception tokens and the -1e20 fill.  The result is the dense kernels' bit for
+ * bit (same order: value descending, token ascending).  A from-state that is not "default + <= E exceptions" is
+ * flagged and its rows take the dense per-target scans inside the same launch.  S <= 32.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  int M;   /* machines */
+  int S;   /* states per machine (<= 32) */
+  int V;   /* vocabulary */
+  int E;   /* exception capacity per (machine, from-state) */
+  int P;   /* fill tokens kept per (machine, from-state): >= the per_node of every later ssc_beam_step_fsm */
+} ssc_fsm_dims;
+size_t ssc_fsm_tables_bytes(const ssc_fsm_dims* d);
+/* fsm (M,S,S,V) uint8 -> tables (device, ssc_fsm_tables_bytes) */
+int ssc_fsm_compile(const uint8_t* fsm, const ssc_fsm_dims* d, void* tables, size_t tables_bytes, void* stream);
+
+/* One descriptor for both search steps.  Batch entry b uses machine mach[b] (NULL: machine b), so the N_Z latent
+ * samples of an image share its machine instead of carrying a copy each. */
+typedef struct {
+  const float* scores; int ld;   /* first: (B,V); step: (B*S*beam, V); log-probs, or un-normalised logits with raw_logits = 1 */
+  int raw_logits;
+  const uint8_t* fsm;            /* dense (M,S,S,V); NULL only for the trivial machine (S = 1, every transition allowed) */
+  const void* tables;            /* from ssc_fsm_compile, or NULL: dense scans */
+  ssc_fsm_dims dims;             /* of `tables` / `fsm` (M, S, V used when tables is NULL) */
+  const int* mach;               /* (B) or NULL */
+  int B, beam, per_node, end_index;
+  const int64_t* last_pred;      /* step: (B, S*beam) previous predictions */
+  const float* last_lp;          /* step: (B, S, beam) running log-probs */
+  int64_t* pred; float* lp_out;  /* (B, S*beam), (B, S, beam) */
+  int64_t* backptr;              /* step: (B, S*beam) */
+  float* scratch_val; int64_t* scratch_idx;   /* step: B*S*S*beam*per_node each */
+  int skip_dead;                 /* step: a row whose running log-prob is <= -1e19 (no finite beam: only -1e20 fills led to it) is
+                                  * scored as if all its log-probs were 0 and its `scores` row is NOT read.  Every log-prob of the
+                                  * search and every beam with a finite log-prob stay bit-identical (x + (-1e20) == -1e20 in fp32);
+                                  * only the token ids of beams that are themselves <= -1e19 can differ.  Lets the caller skip the
+                                  * decode step for such rows (ssc_decode_step_desc.live_*) */
+  /* early stop without a host round trip (cbs.py:167 asks `(last_predictions == end).all()` before every step):
+   * ctl = device int32[2 + 2*max_steps], zero-filled by the caller before the first step except ctl[0] = max_steps;
+   * step t (1-based index of the column it writes, first = 0) counts the beams that have not ended, and the last workgroup of
+   * the step to finish sets ctl[0] = min(ctl[0], t + 1) when there are none and writes t + 1 to *host_flag (a device-visible
+   * pointer to pinned host memory, optional).  A step that finds ctl[0] <= t (the search had already stopped) emits END at +0
+   * for every beam with the identity back-pointer, so that surplus steps queued by a host that polls *host_flag late change
+   * nothing: columns [0, ctl[0]) of the back-trace ARE the reference's output. */
+  int* ctl; int step_index; int max_steps; int* host_flag;
+} ssc_beam_desc;
+int ssc_beam_first_fsm(const ssc_beam_desc* d, void* stream);
+int ssc_beam_step_fsm(const ssc_beam_desc* d, void* stream);
+/* back-trace with the step count taken from ctl[0] on the device: out (B,SB,max_steps); columns >= ctl[0] are filled with end_index */
+int ssc_beam_backtrace_ctl(const int64_t* preds, const int64_t* backptrs, const int* ctl, int max_steps, int B, int SB,
+                           int end_index, int64_t* out, void* stream);
+/* device-visible address of a pinned (hipHostMalloc / torch pin_memory) host word, for ssc_beam_desc.host_flag */
+int ssc_host_device_ptr(void* host_ptr, void** device_ptr);
 
 #ifdef __cplusplus
 }

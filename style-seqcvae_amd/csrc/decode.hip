@@ -11,6 +11,7 @@
 #include <initializer_list>
 
 #include "ssc_common.h"
+#include "beam_common.h"
 
 namespace {
 
@@ -126,48 +127,9 @@ int gemm_slabs(hipStream_t st, float* ws, size_t ws_floats, std::initializer_lis
 // beam-search kernels.  Selection order: value descending, index ascending ("k-pass selection":
 // pass k finds the best candidate strictly after the previous pick in that order).
 // ---------------------------------------------------------------------------------------------------
-struct Cand {
-  float v;
-  int i;
-};
-__device__ __forceinline__ bool better(float v, int i, const Cand& o) {  // (v,i) ranks before o
-  return (v > o.v) || (v == o.v && i < o.i);
-}
-__device__ __forceinline__ Cand wave_best(Cand c) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    Cand t;
-    t.v = __shfl_xor(c.v, o, 64);
-    t.i = __shfl_xor(c.i, o, 64);
-    if (t.i >= 0 && (c.i < 0 || better(t.v, t.i, c))) c = t;
-  }
-  return c;
-}
-__device__ __forceinline__ Cand block_best(Cand c, Cand* sh) {
-  int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  c = wave_best(c);
-  __syncthreads();
-  if (lane == 0) sh[wv] = c;
-  __syncthreads();
-  Cand r = sh[0];
-  for (int k = 1; k < nw; ++k)
-    if (sh[k].i >= 0 && (r.i < 0 || better(sh[k].v, sh[k].i, r))) r = sh[k];
-  return r;
-}
-
 // NORM: `lp` holds un-normalised logits; the row's log-sum-exp is taken here with exactly the arithmetic of
 // log_softmax_kernel (256 threads, strided partial maxima / sums, block_reduce order), so lp[v] - lse is bit-identical to
 // what ssc_log_softmax would have stored.  The row is staged in LDS when it fits (`staged`), so HBM sees it once.
-__device__ __forceinline__ float dec_block_reduce(float v, float* sh, bool is_max) {
-  int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  v = is_max ? ssc_wave_max(v) : ssc_wave_sum(v);
-  __syncthreads();
-  if (lane == 0) sh[wv] = v;
-  __syncthreads();
-  float r = sh[0];
-  for (int i = 1; i < nw; ++i) r = is_max ? fmaxf(r, sh[i]) : r + sh[i];
-  return r;
-}
 template <bool NORM>
 __device__ __forceinline__ const float* row_prepare(const float* __restrict__ row, int V, bool staged, float* srow, float* shr,
                                                     float& lse) {
@@ -201,15 +163,16 @@ __device__ __forceinline__ const float* row_prepare(const float* __restrict__ ro
 // first step: per (b, s): top-`beam` over v of (fsm[b,0,s,v] ? lp[b,v] : -inf)       cbs.py:127-145
 template <bool NORM>
 __global__ __launch_bounds__(256) void beam_first_kernel(const float* __restrict__ lp, int ldlp,
-                                                         const uint8_t* __restrict__ fsm, int S, int V, int beam,
-                                                         int64_t* __restrict__ pred, float* __restrict__ lp_out, int staged) {
+                                                         const uint8_t* __restrict__ fsm, const int* __restrict__ mach, int S,
+                                                         int V, int beam, int64_t* __restrict__ pred,
+                                                         float* __restrict__ lp_out, int staged) {
   extern __shared__ float srow[];
   __shared__ Cand sh[4];
   __shared__ float shr[16];
   int b = blockIdx.x / S, s = blockIdx.x % S;
   float lse;
   const float* row = row_prepare<NORM>(lp + (size_t)b * ldlp, V, staged != 0, srow, shr, lse);
-  const uint8_t* m = fsm ? fsm + (((size_t)b * S + 0) * S + s) * V : nullptr;   // nullptr: the trivial one-state machine
+  const uint8_t* m = fsm ? fsm + (((size_t)(mach ? mach[b] : b) * S + 0) * S + s) * V : nullptr;   // nullptr: the trivial one-state machine
   Cand prev{INFINITY, -1};
   for (int k = 0; k < beam; ++k) {
     Cand best{-INFINITY, -1};
@@ -230,7 +193,7 @@ __global__ __launch_bounds__(256) void beam_first_kernel(const float* __restrict
 // later steps, part A: per (source row g=(b,s,k), target state i): masked top-`per_node`     cbs.py:177-209
 template <bool NORM>
 __global__ __launch_bounds__(256) void beam_row_topk_kernel(const float* __restrict__ lp, int ldlp,
-                                                            const uint8_t* __restrict__ fsm,
+                                                            const uint8_t* __restrict__ fsm, const int* __restrict__ mach,
                                                             const int64_t* __restrict__ last_pred, int S, int V, int beam,
                                                             int per_node, int end_index, float* __restrict__ sval,
                                                             int64_t* __restrict__ sidx, int staged) {
@@ -239,7 +202,7 @@ __global__ __launch_bounds__(256) void beam_row_topk_kernel(const float* __restr
   __shared__ float shr[16];
   int g = blockIdx.x, i = blockIdx.y;
   int b = g / (S * beam), s = (g / beam) % S, k = g % beam;
-  const uint8_t* m = fsm ? fsm + (((size_t)b * S + s) * S + i) * V : nullptr;
+  const uint8_t* m = fsm ? fsm + (((size_t)(mach ? mach[b] : b) * S + s) * S + i) * V : nullptr;
   bool ended = last_pred[g] == end_index;   // workgroup-uniform; an ended beam never looks at its row
   float lse = 0.f;
   const float* row = lp + (size_t)g * ldlp;
@@ -273,7 +236,7 @@ __global__ __launch_bounds__(256) void beam_row_topk_kernel(const float* __restr
 constexpr int BEAM_REG_NV = 40;
 template <bool NORM>
 __global__ __launch_bounds__(256) void beam_row_topk_reg_kernel(const float* __restrict__ lp, int ldlp,
-                                                                const uint8_t* __restrict__ fsm,
+                                                                const uint8_t* __restrict__ fsm, const int* __restrict__ mach,
                                                                 const int64_t* __restrict__ last_pred, int S, int V, int beam,
                                                                 int per_node, int end_index, float* __restrict__ sval,
                                                                 int64_t* __restrict__ sidx) {
@@ -281,7 +244,7 @@ __global__ __launch_bounds__(256) void beam_row_topk_reg_kernel(const float* __r
   __shared__ float shr[16];
   const int g = blockIdx.x, i = blockIdx.y, t = threadIdx.x;
   const int b = g / (S * beam), s = (g / beam) % S, k = g % beam;
-  const uint8_t* m = fsm ? fsm + (((size_t)b * S + s) * S + i) * V : nullptr;
+  const uint8_t* m = fsm ? fsm + (((size_t)(mach ? mach[b] : b) * S + s) * S + i) * V : nullptr;
   const bool ended = last_pred[g] == end_index;   // workgroup-uniform; an ended beam never looks at its row
   const float* row = lp + (size_t)g * ldlp;
   float x[BEAM_REG_NV];
@@ -333,36 +296,6 @@ __global__ __launch_bounds__(256) void beam_row_topk_reg_kernel(const float* __r
     if (t == 0) {
       sval[base + n] = best.v;
       sidx[base + n] = best.i;
-    }
-    prev = best;
-  }
-}
-
-// part B: per (b, target state i): top-`beam` over the S*beam*per_node summed candidates      cbs.py:210-234
-__global__ __launch_bounds__(64) void beam_merge_kernel(const float* __restrict__ sval, const int64_t* __restrict__ sidx,
-                                                        const float* __restrict__ last_lp, int S, int beam, int per_node,
-                                                        int64_t* __restrict__ pred, float* __restrict__ lp_out,
-                                                        int64_t* __restrict__ backptr) {
-  int b = blockIdx.x / S, i = blockIdx.x % S;
-  int lane = threadIdx.x;
-  int ncand = S * beam * per_node;
-  const float* sv = sval + (size_t)blockIdx.x * ncand;
-  const int64_t* si = sidx + (size_t)blockIdx.x * ncand;
-  const float* ll = last_lp + (size_t)b * S * beam;
-  Cand prev{INFINITY, -1};
-  for (int k = 0; k < beam; ++k) {
-    Cand best{-INFINITY, -1};
-    for (int cidx = lane; cidx < ncand; cidx += 64) {
-      float x = sv[cidx] + ll[cidx / per_node];
-      bool after_prev = (prev.i < 0) || (x < prev.v) || (x == prev.v && cidx > prev.i);
-      if (after_prev && (best.i < 0 || better(x, cidx, best))) best = Cand{x, cidx};
-    }
-    best = wave_best(best);
-    if (lane == 0) {
-      size_t o = (size_t)blockIdx.x * beam + k;
-      pred[o] = si[best.i];
-      lp_out[o] = best.v;
-      backptr[o] = best.i / per_node;
     }
     prev = best;
   }
@@ -641,15 +574,44 @@ extern "C" int ssc_decode_step(const ssc_model_cfg* cfg, const ssc_params* p, co
 
 namespace {
 constexpr size_t BEAM_STAGE_MAX = 64 * 1024;   // a vocabulary row is staged in LDS up to this size
-int beam_first_impl(bool norm, const float* lp, int ldlp, const uint8_t* fsm, int B, int S, int V, int beam, int64_t* pred,
-                    float* lp_out, hipStream_t st) {
+}  // namespace
+// first step (dense scans: once per search); mach (B) or NULL: the machine of batch entry b
+int ssc_beam_first_dense(bool norm, const float* lp, int ldlp, const uint8_t* fsm, const int* mach, int B, int S, int V, int beam,
+                         int64_t* pred, float* lp_out, hipStream_t st) {
   if (!lp || (!fsm && S != 1) || !pred || !lp_out || B <= 0 || S <= 0 || V <= 0 || beam <= 0 || beam > V || ldlp < V) return SSC_EINVAL;
   const int staged = norm && (size_t)V * sizeof(float) <= BEAM_STAGE_MAX;
   const size_t lds = staged ? (size_t)V * sizeof(float) : 0;
-  if (norm) SSC_LAUNCH(beam_first_kernel<true>, dim3(B * S), dim3(256), lds, st, lp, ldlp, fsm, S, V, beam, pred, lp_out, staged);
-  else SSC_LAUNCH(beam_first_kernel<false>, dim3(B * S), dim3(256), 0, st, lp, ldlp, fsm, S, V, beam, pred, lp_out, 0);
+  if (norm) SSC_LAUNCH(beam_first_kernel<true>, dim3(B * S), dim3(256), lds, st, lp, ldlp, fsm, mach, S, V, beam, pred, lp_out, staged);
+  else SSC_LAUNCH(beam_first_kernel<false>, dim3(B * S), dim3(256), 0, st, lp, ldlp, fsm, mach, S, V, beam, pred, lp_out, 0);
   SSC_CHECK_LAUNCH();
   return SSC_OK;
+}
+// later steps, part A with the dense machine: one masked scan per (row, target state)
+int ssc_beam_rows_dense(bool norm, const float* lp, int ldlp, const uint8_t* fsm, const int* mach, const int64_t* last_pred, int B,
+                        int S, int V, int beam, int per_node, int end_index, float* scratch_val, int64_t* scratch_idx,
+                        hipStream_t st) {
+  const int staged = norm && (size_t)V * sizeof(float) <= BEAM_STAGE_MAX;
+  const size_t lds = staged ? (size_t)V * sizeof(float) : 0;
+  if (V <= 256 * BEAM_REG_NV && ssc_g_beam_reg) {
+    if (norm)
+      SSC_LAUNCH(beam_row_topk_reg_kernel<true>, dim3(B * S * beam, S), dim3(256), 0, st, lp, ldlp, fsm, mach, last_pred, S, V, beam,
+                 per_node, end_index, scratch_val, scratch_idx);
+    else
+      SSC_LAUNCH(beam_row_topk_reg_kernel<false>, dim3(B * S * beam, S), dim3(256), 0, st, lp, ldlp, fsm, mach, last_pred, S, V, beam,
+                 per_node, end_index, scratch_val, scratch_idx);
+  } else if (norm)
+    SSC_LAUNCH(beam_row_topk_kernel<true>, dim3(B * S * beam, S), dim3(256), lds, st, lp, ldlp, fsm, mach, last_pred, S, V, beam,
+                       per_node, end_index, scratch_val, scratch_idx, staged);
+  else
+    SSC_LAUNCH(beam_row_topk_kernel<false>, dim3(B * S * beam, S), dim3(256), 0, st, lp, ldlp, fsm, mach, last_pred, S, V, beam,
+                       per_node, end_index, scratch_val, scratch_idx, 0);
+  SSC_CHECK_LAUNCH();
+  return SSC_OK;
+}
+namespace {
+int beam_first_impl(bool norm, const float* lp, int ldlp, const uint8_t* fsm, int B, int S, int V, int beam, int64_t* pred,
+                    float* lp_out, hipStream_t st) {
+  return ssc_beam_first_dense(norm, lp, ldlp, fsm, nullptr, B, S, V, beam, pred, lp_out, st);
 }
 int beam_step_impl(bool norm, const float* lp, int ldlp, const uint8_t* fsm, const int64_t* last_pred, const float* last_lp, int B,
                    int S, int V, int beam, int per_node, int end_index, int64_t* pred, float* lp_out, int64_t* backptr,
@@ -658,26 +620,9 @@ int beam_step_impl(bool norm, const float* lp, int ldlp, const uint8_t* fsm, con
   if (B <= 0 || S <= 0 || V <= 0 || beam <= 0 || per_node <= 0 || per_node > V || ldlp < V || end_index < 0 ||
       end_index >= V || beam > S * beam * per_node)
     return SSC_EINVAL;
-  const int staged = norm && (size_t)V * sizeof(float) <= BEAM_STAGE_MAX;
-  const size_t lds = staged ? (size_t)V * sizeof(float) : 0;
-  if (V <= 256 * BEAM_REG_NV && ssc_g_beam_reg) {
-    if (norm)
-      SSC_LAUNCH(beam_row_topk_reg_kernel<true>, dim3(B * S * beam, S), dim3(256), 0, st, lp, ldlp, fsm, last_pred, S, V, beam,
-                 per_node, end_index, scratch_val, scratch_idx);
-    else
-      SSC_LAUNCH(beam_row_topk_reg_kernel<false>, dim3(B * S * beam, S), dim3(256), 0, st, lp, ldlp, fsm, last_pred, S, V, beam,
-                 per_node, end_index, scratch_val, scratch_idx);
-  } else if (norm)
-    SSC_LAUNCH(beam_row_topk_kernel<true>, dim3(B * S * beam, S), dim3(256), lds, st, lp, ldlp, fsm, last_pred, S, V, beam,
-                       per_node, end_index, scratch_val, scratch_idx, staged);
-  else
-    SSC_LAUNCH(beam_row_topk_kernel<false>, dim3(B * S * beam, S), dim3(256), 0, st, lp, ldlp, fsm, last_pred, S, V, beam,
-                       per_node, end_index, scratch_val, scratch_idx, 0);
-  SSC_CHECK_LAUNCH();
-  SSC_LAUNCH(beam_merge_kernel, dim3(B * S), dim3(64), 0, st, scratch_val, scratch_idx, last_lp, S, beam, per_node,
-                     pred, lp_out, backptr);
-  SSC_CHECK_LAUNCH();
-  return SSC_OK;
+  SSC_TRY(ssc_beam_rows_dense(norm, lp, ldlp, fsm, nullptr, last_pred, B, S, V, beam, per_node, end_index, scratch_val, scratch_idx, st));
+  return ssc_beam_merge(scratch_val, scratch_idx, last_lp, B, S, beam, per_node, pred, lp_out, backptr, end_index, nullptr, 0, 0,
+                        nullptr, st);
 }
 }  // namespace
 

@@ -7,7 +7,7 @@
 
 thread_local int ssc_tls_hip_error = 0;
 
-extern "C" int ssc_version(void) { return 3; }
+extern "C" int ssc_version(void) { return 4; }
 extern "C" int ssc_last_hip_error(void) { return ssc_tls_hip_error; }
 extern "C" const char* ssc_arch(void) { return "gfx950"; }
 

@@ -85,3 +85,13 @@ int ssc_gemm_dw_group(const ssc_gemm_desc* const* d, int n, hipStream_t st);
 // C (+)= sum of split-K slabs (M x N, ld N) in index order (+ bias)
 int ssc_reduce_slabs(const float* slabs, int nslab, size_t stride, int M, int N, float* C, int ldc, const float* bias,
                      int accumulate, hipStream_t st);
+
+// beam-search stages shared by decode.hip and fsm.hip
+int ssc_beam_first_dense(bool norm, const float* lp, int ldlp, const uint8_t* fsm, const int* mach, int B, int S, int V, int beam,
+                         int64_t* pred, float* lp_out, hipStream_t st);
+int ssc_beam_rows_dense(bool norm, const float* lp, int ldlp, const uint8_t* fsm, const int* mach, const int64_t* last_pred, int B,
+                        int S, int V, int beam, int per_node, int end_index, float* scratch_val, int64_t* scratch_idx,
+                        hipStream_t st);
+int ssc_beam_merge(const float* sval, const int64_t* sidx, const float* last_lp, int B, int S, int beam, int per_node,
+                   int64_t* pred, float* lp_out, int64_t* backptr, int end_index, int* ctl, int step_index, int max_steps,
+                   int* host_flag, hipStream_t st);

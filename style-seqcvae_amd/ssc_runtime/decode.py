@@ -153,41 +153,114 @@ class DecodeEngine:
 DecodeEngine.step_from_embedding = DecodeEngine._step_from_embedding
 
 
-def cbs_search(start_predictions: torch.Tensor, start_state, step: Callable, fsm: torch.Tensor, end_index: int,
+class CompiledFsm:
+    """Machines in the compiled form of ssc_fsm_compile (include/ssc.h): per (machine, from-state) a default target set plus a
+    short list of exception tokens.  `fsm` (M,S,S,V) uint8 on the device stays referenced: a from-state that does not fit the
+    form (more than `max_exceptions` tokens off the default) is flagged on the device and takes the dense scans.
+    fill: how many of the smallest non-exception tokens are kept per from-state (>= per-node beam size of the search)."""
+
+    def __init__(self, fsm: torch.Tensor, max_exceptions: int = 512, fill: int = 8):
+        assert fsm.is_cuda and fsm.dtype == torch.uint8 and fsm.dim() == 4 and fsm.size(1) == fsm.size(2) <= 32, fsm.shape
+        self.fsm = fsm.contiguous()
+        M, S, _, V = self.fsm.shape
+        lib = _lib.load()
+        self.dims = _lib.FsmDims(M, S, V, int(max_exceptions), int(fill))
+        nbytes = lib.ssc_fsm_tables_bytes(C.byref(self.dims))
+        if nbytes == 0:
+            raise ValueError(f"ssc_fsm_tables_bytes: bad dims {fsm.shape}, E={max_exceptions}, P={fill}")
+        self.tables = torch.empty(nbytes // 4, dtype=torch.int32, device=fsm.device)
+        lib.ssc_fsm_compile(_lib.ptr(self.fsm), C.byref(self.dims), _lib.ptr(self.tables), nbytes, _lib.stream_ptr())
+
+    def sparse_states(self) -> torch.Tensor:
+        """(M, S) bool: which from-states took the compiled form (diagnostic; one device read)."""
+        ms = self.dims.M * self.dims.S
+        return self.tables[:ms].view(self.dims.M, self.dims.S) != 0
+
+
+_HOST_FLAGS = []   # pinned words for the early-stop flag, recycled (allocating pinned memory is slow)
+
+
+def _host_flag():
+    """-> (pinned int32 tensor [1] holding 0, its device-visible address)."""
+    lib = _lib.load()
+    t = _HOST_FLAGS.pop() if _HOST_FLAGS else torch.zeros(1, dtype=torch.int32).pin_memory()
+    t.zero_()
+    dp = C.c_void_p()
+    if lib._raw_ssc_host_device_ptr(C.c_void_p(t.data_ptr()), C.byref(dp)) != 0:
+        return t, None
+    return t, dp
+
+
+def cbs_search(start_predictions: torch.Tensor, start_state, step: Callable, fsm: Optional[torch.Tensor], end_index: int,
                max_steps: int, beam_size: int, per_node_beam_size: int, early_stop: bool = True,
-               early_stop_every: int = 1, raw_logits: bool = False,
-               ungathered_ok: Optional[Callable[[int, int], bool]] = None):
-    """Constrained beam search with on-device bookkeeping (ssc_beam_first / ssc_beam_step / ssc_gather_rows /
-    ssc_beam_backtrace).  `step(tokens (G,), state) -> (log_probs (G,V), state, ...)` as in cbs.py:127,170.
+               early_stop_every: int = 4, raw_logits: bool = False,
+               ungathered_ok: Optional[Callable[[int, int], bool]] = None, compiled: Optional[CompiledFsm] = None,
+               mach: Optional[torch.Tensor] = None, skip_dead: bool = False, compile_fsm: bool = True):
+    """Constrained beam search with on-device bookkeeping (ssc_beam_first_fsm / ssc_beam_step_fsm / ssc_gather_rows /
+    ssc_beam_backtrace_ctl).  `step(tokens (G,), state) -> (log_probs (G,V), state, ...)` as in cbs.py:127,170.
     Returns (predictions (B,S,beam,steps) int64, log_probs (B,S,beam)).
+    fsm: (M,S,S,V) uint8 on the device, or None = the trivial one-state machine; batch entry b runs machine mach[b] (int32 (B);
+    None: M = B, machine b).  compiled: the machines' compiled form (made here from `fsm` when S > 1 unless compile_fsm=False,
+    which keeps the dense per-target scans): one scan per row instead of S, bit-identical selections.
     raw_logits: `step` returns un-normalised logits; the selection kernels normalise each row themselves (bit-identical
     selections and log-probs).
+    early_stop: cbs.py:167 stops as soon as every beam has ended - a host sync per step in the reference.  Here the device itself
+    notes the step after which all beams had ended (ssc_beam_desc.ctl) and turns every later step into a no-op, the host polls a
+    pinned flag the device writes and merely stops QUEUEING steps once it sees it; the columns the reference would have produced
+    are cut out at the end.  Same output for every machine, no host round trip.  early_stop_every <= 1: ask (and wait) after
+    every step, as the reference does.
+    skip_dead: ssc_beam_desc.skip_dead (rows without a finite beam are not scored from their logits; needs the compiled form).
     ungathered_ok(G, group) -> bool: the step function reads its previous states through the back-pointers itself
     (DecodeEngine.ungathered_ok): the states then stay in the previous step's row order, with state["_parent"] = back-pointers and
     state["_ungathered"] = True, and the re-ordering of cbs.py:236-250 (one gather per state tensor and step) is not done here."""
     lib = _lib.load()
-    beam_first = lib.ssc_beam_first_logits if raw_logits else lib.ssc_beam_first
-    beam_step = lib.ssc_beam_step_logits if raw_logits else lib.ssc_beam_step
     st = _lib.stream_ptr
     dev = start_predictions.device
+    B = start_predictions.numel()
+    if compiled is not None and fsm is None:
+        fsm = compiled.fsm
     if fsm is None:   # the trivial one-state machine (every transition allowed): no mask is read on the device
-        B, S, V = start_predictions.numel(), 1, None
+        M, S, V = B, 1, None
     else:
-        B, S, _, V = fsm.shape
+        M, S, _, V = fsm.shape
         assert fsm.is_cuda and fsm.dtype == torch.uint8
         fsm = fsm.contiguous()
+        assert mach is not None or M == B, (M, B)
+        if compiled is None and compile_fsm and S > 1:
+            compiled = CompiledFsm(fsm, fill=max(8, per_node_beam_size))
+    if mach is not None:
+        mach = mach.to(dev, torch.int32).contiguous()
+        assert mach.numel() == B
+    assert not skip_dead or compiled is not None
     SB = S * beam_size
     preds = torch.empty(max_steps, B, SB, dtype=torch.int64, device=dev)
     backs = torch.empty(max(max_steps - 1, 1), B, SB, dtype=torch.int64, device=dev)
     last_lp = torch.empty(B, S, beam_size, dtype=torch.float32, device=dev)
+    ctl = flag = flag_dev = None
+    if early_stop:
+        ctl = torch.zeros(2 + 2 * max_steps, dtype=torch.int32, device=dev)
+        ctl[0] = max_steps
+        flag, flag_dev = _host_flag()
     out = step(start_predictions, start_state)
     lp0, state = out[0], out[1]
     lp0 = lp0.contiguous()
     if V is None:
         V = lp0.shape[1]
     assert lp0.shape == (B, V), lp0.shape
-    beam_first(_lib.ptr(lp0), lp0.stride(0), _lib.ptr(fsm), B, S, V, beam_size, _lib.ptr(preds[0]), _lib.ptr(last_lp),
-                       st())
+    d = _lib.BeamDesc()
+    d.raw_logits = 1 if raw_logits else 0
+    d.fsm = _lib.ptr(fsm)
+    d.tables = _lib.ptr(compiled.tables) if compiled is not None else None
+    d.dims = compiled.dims if compiled is not None else _lib.FsmDims(M, S, V, 0, 1)
+    d.mach = _lib.ptr(mach)
+    d.B, d.beam, d.per_node, d.end_index = B, beam_size, per_node_beam_size, end_index
+    d.skip_dead = 1 if skip_dead else 0
+    d.ctl = _lib.ptr(ctl)
+    d.max_steps = max_steps
+    d.host_flag = flag_dev if ctl is not None else None
+    d.scores, d.ld = _lib.ptr(lp0), lp0.stride(0)
+    d.pred, d.lp_out = _lib.ptr(preds[0]), _lib.ptr(last_lp)
+    lib.ssc_beam_first_fsm(C.byref(d), st())
     # enlarge states to (B*S*beam, *) batch-major (cbs.py:10-17,152-155)
     def enlarge(t):
         _, *rest = t.shape
@@ -197,35 +270,24 @@ def cbs_search(start_predictions: torch.Tensor, start_state, step: Callable, fsm
     state["_parent"] = torch.zeros(B, SB, dtype=torch.int64, device=dev)   # every beam of a group descends from the one start row
     sval = torch.empty(B * S * SB * per_node_beam_size, dtype=torch.float32, device=dev)
     sidx = torch.empty(B * S * SB * per_node_beam_size, dtype=torch.int64, device=dev)
-    nsteps = 1
-    pending = None   # (event, pinned host flag) of the last "have all beams ended?" question put to the device
+    d.scratch_val, d.scratch_idx = _lib.ptr(sval), _lib.ptr(sidx)
     for t in range(1, max_steps):
         last = preds[t - 1].reshape(B * SB)
-        # cbs.py:167 stops as soon as every beam has ended (a host sync per step in the reference).  Steps taken after
-        # that point change nothing (ended beams re-emit END at log-prob +0) and the surplus columns are trimmed below, so the
-        # question is put every `early_stop_every` steps and ANSWERED WITHOUT WAITING: the flag travels to pinned host memory
-        # behind an event and is read once the event has completed - the host never drains the queue it is filling (a blocking
-        # check every 4 steps left the GPU idle for 12 % of a 100-image call).  Same output, a few surplus steps at most.
-        if early_stop and early_stop_every <= 1:
-            if bool((last == end_index).all()):
-                break
-        elif early_stop:
-            if pending is not None and pending[0].query():
-                if bool(pending[1][0]):
+        if ctl is not None:
+            if early_stop_every <= 1:
+                if int(ctl[0]) <= t:   # (waits for the device, like the reference's `.all()`)
                     break
-                pending = None
-            if pending is None and (t - 1) % early_stop_every == 0:
-                host = torch.empty(1, dtype=torch.bool, pin_memory=True)
-                host.copy_((last == end_index).all().reshape(1), non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record()
-                pending = (ev, host)
+            elif int(flag[0]) != 0:    # a plain read of pinned host memory: nothing is queued, nothing waited for
+                break
+        state["_last_lp"] = last_lp   # (for step functions that skip rows without a finite beam)
         out = step(last, state)
         lp, state = out[0].contiguous(), out[1]
         new_lp = torch.empty_like(last_lp)
-        beam_step(_lib.ptr(lp), lp.stride(0), _lib.ptr(fsm), _lib.ptr(last), _lib.ptr(last_lp), B, S, V, beam_size,
-                          per_node_beam_size, end_index, _lib.ptr(preds[t]), _lib.ptr(new_lp), _lib.ptr(backs[t - 1]),
-                          _lib.ptr(sval), _lib.ptr(sidx), st())
+        d.scores, d.ld = _lib.ptr(lp), lp.stride(0)
+        d.last_pred, d.last_lp = _lib.ptr(last), _lib.ptr(last_lp)
+        d.pred, d.lp_out, d.backptr = _lib.ptr(preds[t]), _lib.ptr(new_lp), _lib.ptr(backs[t - 1])
+        d.step_index = t
+        lib.ssc_beam_step_fsm(C.byref(d), st())
         last_lp = new_lp
         new_state = {}
         # a step function that reads its previous states through the parent list (DecodeEngine.step at large G: `ungathered_ok`)
@@ -245,15 +307,13 @@ def cbs_search(start_predictions: torch.Tensor, start_state, step: Callable, fsm
         if leave:
             new_state["_ungathered"] = True
         state = new_state
-        nsteps += 1
-    allp = torch.empty(B, SB, nsteps, dtype=torch.int64, device=dev)
-    lib.ssc_beam_backtrace(_lib.ptr(preds), _lib.ptr(backs), nsteps, B, SB, _lib.ptr(allp), st())
-    if early_stop and early_stop_every > 1 and nsteps > 1:
-        # trim trailing all-END columns beyond the first one (what a per-step check would never have produced)
-        all_end = (allp == end_index).all(dim=0).all(dim=0)            # (nsteps,)
-        keep = nsteps
-        while keep > 1 and bool(all_end[keep - 1]) and bool(all_end[keep - 2]):
-            keep -= 1
-        allp = allp[:, :, :keep].contiguous()
-        nsteps = keep
-    return allp.view(B, S, beam_size, nsteps), last_lp
+    if ctl is None:
+        allp = torch.empty(B, SB, max_steps, dtype=torch.int64, device=dev)
+        lib.ssc_beam_backtrace(_lib.ptr(preds), _lib.ptr(backs), max_steps, B, SB, _lib.ptr(allp), st())
+        return allp.view(B, S, beam_size, max_steps), last_lp
+    # a search the host stopped queueing at step t has written columns [0, t) and ctl[0] <= t; one that ran out has ctl[0] <= max_steps
+    allp = torch.empty(B, SB, max_steps, dtype=torch.int64, device=dev)
+    lib.ssc_beam_backtrace_ctl(_lib.ptr(preds), _lib.ptr(backs), _lib.ptr(ctl), max_steps, B, SB, end_index, _lib.ptr(allp), st())
+    nsteps = int(ctl[0])   # (the one wait of the search: its result is about to be read anyway)
+    _HOST_FLAGS.append(flag)
+    return allp[:, :, :nsteps].contiguous().view(B, S, beam_size, nsteps), last_lp

@@ -23,8 +23,10 @@ def diverse_decode(dec: DecodeEngine, feats: torch.Tensor, sentiment: Optional[t
                    num_constraints: Optional[torch.Tensor] = None, min_constraints_to_satisfy: int = 0,
                    eps_steps: Optional[List[torch.Tensor]] = None, early_stop: bool = True, per_node: Optional[int] = None):
     """feats (nimg,R,F), sentiment (nimg,) or None -> predictions (nimg, n_samples, steps) int64 on device.
-    fsm: (nimg*n_samples, S, S, V) uint8 or None (trivial one-state machine, what MAX_GIVEN_CONSTRAINTS: 0 produces).
-    eps_steps: optional explicit noise per step call [(rows_k, Z)]; default: device RNG."""
+    fsm: None (trivial one-state machine, what MAX_GIVEN_CONSTRAINTS: 0 produces), or (nimg, S, S, V) uint8 - ONE machine per
+    image, shared by its n_samples latent samples through an index list -, or (nimg*n_samples, S, S, V) (a copy per sample).
+    eps_steps: optional explicit noise per step call [(rows_k, Z)]; default: a generator of this call's own, seeded by ONE draw
+    from the global CPU generator - the global random state a call consumes does not depend on how many steps it ran."""
     dev = feats.device
     nimg = feats.size(0)
     d = dec.dims
@@ -35,6 +37,17 @@ def diverse_decode(dec: DecodeEngine, feats: torch.Tensor, sentiment: Optional[t
         num_constraints = torch.zeros(B, dtype=torch.long)
     sent_b = sentiment.reshape(nimg, 1).expand(nimg, n_samples).reshape(B) if sentiment is not None else None
     calls = {"k": 0}
+    mach = None
+    if not trivial and fsm.size(0) != B:
+        assert fsm.size(0) == nimg, (fsm.shape, nimg, n_samples)
+        mach = torch.arange(nimg, dtype=torch.int32, device=dev).repeat_interleave(n_samples)
+    gen = None
+    if eps_steps is None:
+        # The search may queue a few steps beyond the one after which every beam had ended (the early-stop flag is polled, not
+        # waited for): their noise must not come out of the global generator, or the captions of the NEXT call would depend on
+        # host / device timing.
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(int(torch.randint(0, 2 ** 62, (1,)).item()))
 
     def step(tokens, state):
         G = tokens.numel()
@@ -42,7 +55,7 @@ def diverse_decode(dec: DecodeEngine, feats: torch.Tensor, sentiment: Optional[t
         if eps_steps is not None:
             eps = eps_steps[calls["k"]]
         else:
-            eps = torch.randn(G, d.Z, device=dev)
+            eps = torch.randn(G, d.Z, device=dev, generator=gen)
         calls["k"] += 1
         lp, st, alpha = dec.step(ctx, tokens, state, sent_rows, eps, raw_logits=_RAW)
         # the eval cell never touches the encoder-LSTM states (updown_cell.py:200-203): do not carry (and re-order by
@@ -52,7 +65,7 @@ def diverse_decode(dec: DecodeEngine, feats: torch.Tensor, sentiment: Optional[t
     start = torch.full((B,), boundary_index, dtype=torch.long, device=dev)
     beams, lps = cbs_search(start, None, step, fsm, boundary_index, max_steps, beam, per_node or (beam // 2) or beam,
                             early_stop=early_stop, early_stop_every=4, raw_logits=_RAW,
-                            ungathered_ok=lambda G, group: dec.ungathered_ok(ctx, G, group))
+                            ungathered_ok=lambda G, group: dec.ungathered_ok(ctx, G, group), mach=mach)
     if trivial or fsm.size(1) == 1:
         best = beams[:, 0, 0, :]
     else:

@@ -111,6 +111,18 @@ class DecodeStepDesc(C.Structure):
                 ("ungathered", C.c_int)]
 
 
+class FsmDims(C.Structure):
+    _fields_ = [("M", C.c_int), ("S", C.c_int), ("V", C.c_int), ("E", C.c_int), ("P", C.c_int)]
+
+
+class BeamDesc(C.Structure):
+    _fields_ = [("scores", vp), ("ld", C.c_int), ("raw_logits", C.c_int), ("fsm", vp), ("tables", vp), ("dims", FsmDims),
+                ("mach", vp), ("B", C.c_int), ("beam", C.c_int), ("per_node", C.c_int), ("end_index", C.c_int),
+                ("last_pred", vp), ("last_lp", vp), ("pred", vp), ("lp_out", vp), ("backptr", vp), ("scratch_val", vp),
+                ("scratch_idx", vp), ("skip_dead", C.c_int), ("ctl", vp), ("step_index", C.c_int), ("max_steps", C.c_int),
+                ("host_flag", vp)]
+
+
 # name -> (restype, argtypes).  Every symbol include/ssc.h declares is listed; tests check they all resolve.
 _i, _f, _sz = C.c_int, C.c_float, C.c_size_t
 SYMBOLS = {
@@ -175,6 +187,12 @@ SYMBOLS = {
     "ssc_beam_step_logits": (_i, [vp, _i, vp, vp, vp, _i, _i, _i, _i, _i, _i, vp, vp, vp, vp, vp, vp]),
     "ssc_gather_rows": (_i, [vp, _i, vp, _i, _i, _i, vp, vp]),
     "ssc_beam_backtrace": (_i, [vp, vp, _i, _i, _i, vp, vp]),
+    "ssc_fsm_tables_bytes": (_sz, [C.POINTER(FsmDims)]),
+    "ssc_fsm_compile": (_i, [vp, C.POINTER(FsmDims), vp, _sz, vp]),
+    "ssc_beam_first_fsm": (_i, [C.POINTER(BeamDesc), vp]),
+    "ssc_beam_step_fsm": (_i, [C.POINTER(BeamDesc), vp]),
+    "ssc_beam_backtrace_ctl": (_i, [vp, vp, vp, _i, _i, _i, _i, vp, vp]),
+    "ssc_host_device_ptr": (_i, [vp, C.POINTER(vp)]),
 }
 
 # include/ssc_debug.h (diagnostics / profiling / tuning switches: not part of the product ABI)

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(cdll, n), f"{n} declared in include/ssc.h but not exported"
         assert n in L.SYMBOLS, f"{n} missing from the ctypes table"
     assert sorted(L.SYMBOLS) == names
-    assert lib.ssc_version() == 3 and lib.ssc_arch() == b"gfx950"
+    assert lib.ssc_version() == 4 and lib.ssc_arch() == b"gfx950"
     # diagnostics / profiling / tuning switches live in their own header, outside the product ABI
     dbg = header_symbols("ssc_debug.h")
     assert sorted(L.DEBUG_SYMBOLS) == dbg and not set(dbg) & set(names)

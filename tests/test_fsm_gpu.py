@@ -1,0 +1,246 @@
+"""GPU: compiled finite-state machines (ssc_fsm_compile / ssc_beam_step_fsm) against the dense per-target scans
+the reference's loop corresponds to (updown-baseline/updown/modules/cbs.py:157-250), which tests/test_decode_gpu.py pins to the
+reference's own results (g12_cbs).  Everything here is integer / bit-exact: the compiled form must give the dense form's
+selections token for token, log-prob for log-prob."""
+import pytest
+import torch
+
+import oracle
+from goldenlib import cbs_table_step, load_raw, unpack_fsm
+from ssc_runtime.decode import CompiledFsm, cbs_search
+
+pytestmark = pytest.mark.gpu
+
+
+def _builder(tmp_path, V, kmax=3, big_class=0):
+    """Vocabulary of V words that holds the constraint word forms, and the FSM builder over it.  big_class: a class with that many
+    word forms (the reference's attribute / sentiment classes have 100-280 forms, data/constraint_wordforms_attrib*.tsv)."""
+    from ssc_runtime.constraints import FiniteStateMachineBuilder
+    from ssc_runtime.vocab import Vocabulary
+    words = ["a", "the", "dog", "dogs", "cat", "cats", "fire", "hydrant", "hydrants", "red", "reddish", "on", "street", "sits", "salt",
+             "and", "pepper"]
+    lines = ["dog\tdog,dogs", "cat\tcat,cats", "fire\tfire", "hydrant\thydrant,hydrants", "red\tred,reddish,zzz-not-in-vocab",
+             "salt\tsalt", "and\tand", "pepper\tpepper,peppers-oov"]
+    fillers = [f"w{i}" for i in range(V - 2 - len(words))]
+    if big_class:
+        lines.append("attribute\t" + ",".join(fillers[5:5 + 3 * big_class:3]))
+    tsv = tmp_path / "wordforms.tsv"
+    tsv.write_text("\n".join(lines) + "\n")
+    vocab = Vocabulary(["@@UNKNOWN@@", "@@BOUNDARY@@"] + words + fillers)
+    assert vocab.get_vocab_size() == V
+    return vocab, FiniteStateMachineBuilder(vocab, str(tsv), None, max_given_constraints=kmax)
+
+
+def _machines(tmp_path, V, sets, big_class=0):
+    """(M, S, S, V) uint8: the machines of the constraint sets, padded to the largest state count (states an image does not use
+    have no transitions at all)."""
+    _, b = _builder(tmp_path, V, big_class=big_class)
+    built = [b.build(list(c)) for c in sets]
+    S = max(x[1] for x in built)
+    fsm = torch.zeros(len(sets), S, S, V, dtype=torch.uint8)
+    for i, (m, ns, _) in enumerate(built):
+        fsm[i, :ns, :ns] = m[:ns, :ns]
+    return fsm
+
+
+def _read_tables(c: CompiledFsm):
+    """The tables of ssc_fsm_compile as tensors, by the layout of csrc/fsm.hip::fsm_layout (64-word aligned regions)."""
+    d = c.dims
+    M, S, V, E, P = d.M, d.S, d.V, d.E, d.P
+    r = lambda x: (x + 63) // 64 * 64
+    NW = ((V + 255) // 256 + 31) // 32
+    t = c.tables.cpu()
+    o = 0
+    out = {}
+    for name, n in (("ok", M * S), ("dflt", M * S), ("nexc", M * S), ("etok", M * S * E), ("emask", M * S * E), ("fill", M * S * P),
+                    ("bits", M * S * 256 * NW)):
+        out[name] = t[o:o + n]
+        o += r(n)
+    assert o == t.numel()
+    out["NW"] = NW
+    return out
+
+
+SETS = [(), ("dog",), ("dog", "cat"), ("fire hydrant", "dog"), ("dog", "cat", "red"), ("dog", "cat", "fire hydrant"),
+        ("salt and pepper", "fire hydrant", "dog"), ("dog", "dog"), ("red",)]
+
+
+@pytest.mark.parametrize("V,E", [(60, 16), (10000, 512), (12345, 64)])
+def test_compiled_tables_describe_the_dense_machine(tmp_path, V, E):
+    """default target set + exception list + bitmap + fill tokens reproduce the dense adjacency exactly, for the machines the
+    builder makes (0-3 constraints, multi-word, repeated, out-of-vocabulary word forms landing on @@UNKNOWN@@)."""
+    fsm = _machines(tmp_path, V, SETS)
+    M, S = fsm.shape[:2]
+    c = CompiledFsm(fsm.cuda(), max_exceptions=E, fill=4)
+    t = _read_tables(c)
+    assert bool((t["ok"] == 1).all())                      # every from-state of these machines has the form
+    tmask = (fsm.long() << torch.arange(S).view(1, 1, S, 1)).sum(2)          # (M, S, V): target set of every (from-state, token)
+    for ms in range(M * S):
+        m, s = divmod(ms, S)
+        n = int(t["nexc"][ms])
+        tok = t["etok"][ms * E: ms * E + n].long()
+        assert bool((tok[1:] > tok[:-1]).all())            # ascending
+        want = tmask[m, s]
+        rebuilt = torch.full((V,), int(t["dflt"][ms]) & 0xFFFFFFFF, dtype=torch.long)
+        rebuilt[tok] = t["emask"][ms * E: ms * E + n].long() & 0xFFFFFFFF
+        assert torch.equal(rebuilt, want), (m, s)
+        is_exc = torch.zeros(V, dtype=torch.bool)
+        is_exc[tok] = True
+        nonexc = (~is_exc).nonzero().view(-1)[:4]
+        assert torch.equal(t["fill"][ms * 4: ms * 4 + nonexc.numel()].long(), nonexc)
+        bits = t["bits"][ms * 256 * t["NW"]: (ms + 1) * 256 * t["NW"]].view(256, t["NW"]).long() & 0xFFFFFFFF
+        v = torch.arange(V)
+        got = (bits[v % 256, (v // 256) // 32] >> ((v // 256) % 32)) & 1
+        assert torch.equal(got.bool(), is_exc)
+
+
+def _table_step(V, seed, end_bias=1.0):
+    g = torch.Generator().manual_seed(seed)
+    U = torch.randn(V, 10, generator=g).cuda()
+    W = (torch.randn(10, V, generator=g) * 1.5).cuda()
+    drift = (torch.randn(5, V, generator=g) * 0.5).cuda()
+
+    def step(tokens, state):
+        G = tokens.numel()
+        cnt = torch.zeros(G, 1, device="cuda") if state is None else state["cnt"]
+        acc = torch.zeros(G, 2, device="cuda") if state is None else state["acc"]
+        logits = U[tokens] @ W + drift[cnt.long().view(-1) % 5] + acc.sum(1, keepdim=True) * 0.02
+        logits[:, 1] += end_bias
+        new = {"cnt": cnt + 1, "acc": (acc + tokens.view(-1, 1).float() * torch.tensor([[1.0, 0.5]], device="cuda")) % 3.0}
+        return logits, new
+    return step
+
+
+def _search(fsm, step, B, beam, per_node, steps, mach=None, raw=True, **kw):
+    start = torch.full((B,), 1, dtype=torch.long, device="cuda")
+    if raw:
+        return cbs_search(start, None, step, fsm, 1, steps, beam, per_node, raw_logits=True, mach=mach, **kw)
+    lp_step = lambda tok, st: (lambda o: (torch.log_softmax(o[0], dim=1), o[1]))(step(tok, st))
+    return cbs_search(start, None, lp_step, fsm, 1, steps, beam, per_node, raw_logits=False, mach=mach, **kw)
+
+
+@pytest.mark.parametrize("V,beam,per_node,raw,big", [(60, 3, 1, True, 0), (2000, 5, 2, False, 0), (10000, 5, 2, True, 0),
+                                                      (10000, 3, 2, True, 150), (12345, 5, 2, True, 0), (12345, 4, 4, False, 40)])
+def test_compiled_search_equals_dense_search_on_built_machines(tmp_path, V, beam, per_node, raw, big):
+    """One scan per row (compiled form) against one scan per (row, target state) (dense form): predictions, log-probs and step
+    count bit-equal - including the beams that hold only -1e20 fills -, for machines with 0-3 constraints padded to 12+ states;
+    V on both sides of the register form (10240); word-form classes of 40 / 150 forms."""
+    sets = SETS + ([("attribute", "dog")] if big else [])
+    fsm = _machines(tmp_path, V, sets, big_class=big).cuda()
+    B = fsm.size(0)
+    step = _table_step(V, seed=V + beam)
+    a_p, a_lp = _search(fsm, step, B, beam, per_node, 9, raw=raw, compile_fsm=False)
+    b_p, b_lp = _search(fsm, step, B, beam, per_node, 9, raw=raw, compile_fsm=True)
+    assert a_p.shape == b_p.shape and torch.equal(a_p, b_p) and torch.equal(a_lp, b_lp)
+    assert bool((a_lp > -1e19).any()) and bool((a_lp <= -1e19).any())   # the case has both finite and fill-only beams
+
+
+@pytest.mark.parametrize("V,S,density,E", [(97, 4, 0.6, 512), (300, 3, 0.9, 8), (5000, 3, 0.5, 64), (10240, 2, 0.2, 0), (11000, 3, 0.97, 512)])
+def test_compiled_search_equals_dense_search_on_random_machines(V, S, density, E):
+    """Random dense adjacency: with a large exception capacity every token is an 'exception' of some default (the compiled path
+    with hundreds of candidates per target), with a small one the from-states are flagged and take the dense scans inside the
+    compiled launch - both must give the dense kernels' result bit for bit."""
+    g = torch.Generator().manual_seed(V + S)
+    B, beam, per_node = 3, 3, 2
+    fsm = (torch.rand(B, S, S, V, generator=g) < density).to(torch.uint8)
+    fsm[:, :, :, 1] = 1
+    fsm[:, :, :, 2:6] = 1
+    fsm = fsm.cuda()
+    step = _table_step(V, seed=V)
+    a_p, a_lp = _search(fsm, step, B, beam, per_node, 7, compile_fsm=False)
+    comp = CompiledFsm(fsm, max_exceptions=E, fill=8)
+    b_p, b_lp = _search(fsm, step, B, beam, per_node, 7, compiled=comp)
+    assert torch.equal(a_p, b_p) and torch.equal(a_lp, b_lp)
+    ok = comp.sparse_states()
+    if E == 0 or (E < 100 and V >= 300):
+        assert not bool(ok.any())        # really the in-launch dense scans
+    if E >= 512 and V <= 512:
+        assert bool(ok.all())
+
+
+def test_machines_are_shared_through_the_index_list(tmp_path):
+    """Batch entries that run the same machine (the N_Z latent samples of an image) name it by index instead of carrying a copy."""
+    V, beam, per_node = 3000, 5, 2
+    fsm = _machines(tmp_path, V, SETS[:5]).cuda()
+    M = fsm.size(0)
+    mach = torch.tensor([0, 0, 3, 1, 4, 4, 4, 2, 1], dtype=torch.int32)
+    step = _table_step(V, seed=5)
+    rep = fsm[mach.long()].contiguous()
+    a_p, a_lp = _search(rep, step, mach.numel(), beam, per_node, 8, compile_fsm=False)
+    for compile_fsm in (False, True):
+        b_p, b_lp = _search(fsm, step, mach.numel(), beam, per_node, 8, mach=mach.cuda(), compile_fsm=compile_fsm)
+        assert torch.equal(a_p, b_p) and torch.equal(a_lp, b_lp)
+    assert M < mach.numel()
+
+
+@pytest.mark.parametrize("V", [500, 10000])
+def test_rows_without_a_finite_beam_need_no_logits(tmp_path, V):
+    """skip_dead: a row whose running log-prob is <= -1e19 is scored as if its log-probs were all 0 and its logits are not read
+    (NaN-filled here to prove it).  Every log-prob of the search and every beam with a finite log-prob stay bit-identical."""
+    beam, per_node = 5, 2
+    fsm = _machines(tmp_path, V, SETS).cuda()
+    B, S = fsm.shape[:2]
+    step = _table_step(V, seed=3)
+    a_p, a_lp = _search(fsm, step, B, beam, per_node, 9, compile_fsm=True)
+
+    def poisoned(tokens, state):
+        logits, new = step(tokens, {k: v for k, v in state.items() if not k.startswith("_")} if state is not None else None)
+        if state is not None and "_last_lp" in state:
+            dead = (state["_last_lp"].reshape(-1) <= -1e19) & (tokens != 1)
+            logits = logits.clone()
+            logits[dead] = float("nan")
+        return logits, new
+    b_p, b_lp = _search(fsm, poisoned, B, beam, per_node, 9, compile_fsm=True, skip_dead=True)
+    assert a_p.shape == b_p.shape and torch.equal(a_lp, b_lp)
+    finite = a_lp > -1e19
+    assert torch.equal(a_p[finite], b_p[finite]) and bool(finite.any()) and bool((~finite).any())
+
+
+@pytest.mark.parametrize("every", [1, 3])
+def test_early_stop_on_the_device_with_substates(tmp_path, every):
+    """The stop condition of cbs.py:167 is noted by the device; steps queued after it are no-ops, so a host that sees the flag
+    late (or never: early_stop_every only chooses blocking / polling) returns the columns a per-step check returns.  Machines with
+    sub-states, whose END transition is NOT a self-loop (constraints.py:470-476): surplus steps would otherwise move beams."""
+    V, beam, per_node, steps = 400, 3, 2, 14
+    fsm = _machines(tmp_path, V, [("dog",), ("fire hydrant",), ("salt and pepper", "dog")]).cuda()
+    B = fsm.size(0)
+    step = _table_step(V, seed=11, end_bias=9.0)
+    start = torch.full((B,), 1, dtype=torch.long, device="cuda")
+    lp_step = lambda tok, st: (lambda o: (torch.log_softmax(o[0], dim=1), o[1]))(step(tok, st))
+    want_p, want_lp = oracle.cbs_search(start.cpu(), None, lambda tok, st: tuple(
+        x.cpu() if torch.is_tensor(x) else {k: v.cpu() for k, v in x.items()} for x in lp_step(
+            tok.cuda(), None if st is None else {k: v.cuda() for k, v in st.items()})), fsm.cpu(), end_index=1, max_steps=steps,
+        beam_size=beam, per_node_beam_size=per_node)
+    got_p, got_lp = cbs_search(start, None, lp_step, fsm, 1, steps, beam, per_node, early_stop_every=every)
+    full_p, full_lp = cbs_search(start, None, lp_step, fsm, 1, steps, beam, per_node, early_stop=False)
+    finite = want_lp > -1e19
+    assert got_p.shape == want_p.shape, (got_p.shape, want_p.shape)
+    assert torch.equal(got_p.cpu()[finite], want_p[finite])
+    assert float((got_lp.cpu()[finite] - want_lp[finite]).abs().max()) < 1e-5
+    if want_p.shape[-1] < steps:
+        # without the stop the beams move on (END out of a sub-state resets): the cut-out columns are not simply a prefix
+        assert full_p.shape[-1] == steps
+        torch.cuda.synchronize()
+
+
+_G12 = load_raw("g12_cbs")
+
+
+@pytest.mark.parametrize("ci", range(int(_G12["ncases"])))
+def test_compiled_search_equals_reference_fixture(ci):
+    """The compiled form against ConstrainedBeamSearch.search itself (cbs.py:59-277 run unmodified, g12_cbs), with a capacity that
+    keeps every from-state in the compiled form."""
+    key = f"search/case{ci}"
+    B, S, V, beam, per_node, steps = (int(x) for x in _G12[key + "/dims"])
+    table, drift = torch.from_numpy(_G12[key + "/table"]).cuda(), torch.from_numpy(_G12[key + "/drift"]).cuda()
+    fsm = unpack_fsm(_G12[key + "/fsm_bits"], B, S, V).cuda()
+    comp = CompiledFsm(fsm, max_exceptions=V, fill=8) if S > 1 else None
+    want_p, want_lp = torch.from_numpy(_G12[key + "/predictions"]), torch.from_numpy(_G12[key + "/log_probs"])
+    got_p, got_lp = cbs_search(torch.full((B,), 1, dtype=torch.long, device="cuda"), None, cbs_table_step(table, drift), fsm, 1, steps,
+                               beam, per_node, compiled=comp)
+    if comp is not None:
+        assert bool(comp.sparse_states().all())
+    assert got_p.shape == want_p.shape
+    finite = torch.isfinite(want_lp) & (want_lp > -1e19)
+    assert float((got_lp.cpu()[finite] - want_lp[finite]).abs().max()) < 1e-4
+    assert torch.equal(got_p.cpu()[finite], want_p[finite])
