@@ -263,8 +263,171 @@ def measure_decode(model, c, rank, world, device, images, warmup):
                                     "captions_per_s": n_chunks * chunk * world * 20 / el2}}
 
 
+def measure_decode_cbs(model, c, device, n_calls=3, warmup=2, legs="all"):
+    """SURVEY 8(f)-1 at C4's shapes: constrained beam search with k = 3 constraint classes per image (two word forms per word, every
+    fifth class a two-word phrase -> sub-states), beam 5 (per-node 2), N_Z = 20, 36x2048 features, max 20 steps, machines from
+    ssc_runtime.constraints.FiniteStateMachineBuilder (bit-identical to the reference builder, g9_fsm) - one machine per IMAGE,
+    compiled on the device (ssc_fsm_compile), rows without a finite beam skipped.  Images per call are chosen for <= 20000 rows
+    per step.  Beside the whole-call rate: the selection step (row kernel + merge) alone at the call's shape, compiled against
+    dense, with hipEvents on the launching stream - `selection.achieved` = algorithmic bytes (the logits once: G*V*4) / time."""
+    import ctypes as C
+    import tempfile
+    from ssc_runtime import lib as L
+    from ssc_runtime.constraints import FiniteStateMachineBuilder
+    from ssc_runtime.decode import CompiledFsm
+    from ssc_runtime.inference import count_tokens, diverse_decode
+    lib = L.load()
+    was_training = model.training
+    model.eval()
+    dec = model._dec
+    dec.weights_frozen = True
+    V, n_z, beam, per_node, kmax = c["V"], 20, 5, 2, 3
+    vocab = model._vocabulary
+    g = torch.Generator().manual_seed(777)
+    ncls = 300
+    lines = []
+    for j in range(ncls):   # class j: words w(100+4j) .. ; every fifth class is a two-word phrase
+        a, b2, c2, d2 = (f"w{100 + 4 * j + o}" for o in range(4))
+        lines.append(f"{a}\t{a},{b2}")
+        lines.append(f"{c2}\t{c2},{d2}")
+    with tempfile.TemporaryDirectory() as td:
+        tsv = os.path.join(td, "wordforms.tsv")
+        open(tsv, "w").write("\n".join(lines) + "\n")
+        builder = FiniteStateMachineBuilder(vocab, tsv, None, max_given_constraints=kmax)
+
+        def constraint(j):
+            a, c2 = f"w{100 + 4 * j}", f"w{100 + 4 * j + 2}"
+            return f"{a} {c2}" if j % 5 == 0 else a
+        nimg_pool = 64
+        picks = [torch.randperm(ncls, generator=g)[:kmax].tolist() for _ in range(nimg_pool)]
+        built = [builder.build([constraint(j) for j in pk]) for pk in picks]
+    S = max(b[1] for b in built)
+    nimg = max(1, 20000 // (n_z * S * beam))
+    built = built[:nimg] if nimg <= nimg_pool else built
+    nimg = len(built)
+    fsm = torch.zeros(nimg, S, S, V, dtype=torch.uint8)
+    for i, (m, ns, _) in enumerate(built):
+        fsm[i, :ns, :ns] = m[:ns, :ns]
+    fsm = fsm.to(device)
+    ncons = torch.full((nimg * n_z,), kmax, dtype=torch.long)
+    feats = [torch.randn(nimg, c["R"], c["F"], generator=g).to(device) for _ in range(2)]
+    senti = torch.ones(nimg, device=device)
+    comp = CompiledFsm(fsm, fill=8)
+    sparse_frac = float(comp.sparse_states().float().mean())
+
+    def run(compiled, skip, n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tokens = 0
+        for i in range(n):
+            pred, calls = diverse_decode(dec, feats[i % 2], senti, n_z, beam, c["L"], 1, fsm=fsm, num_constraints=ncons,
+                                         min_constraints_to_satisfy=kmax, compiled=compiled, skip_dead=skip, early_stop=True)
+            tokens += count_tokens(pred, 1)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, tokens, pred
+
+    run(comp, True, warmup)
+    el, tokens, pred = run(comp, True, n_calls)
+    if legs == "compiled":   # (what the rocprofv3 passes run: only the product path's launches in the tables)
+        return {"value": tokens / el, "unit": "tokens/s", "ms_per_call": el / n_calls * 1e3, "rows_per_step": nimg * n_z * S * beam}
+    # the same calls on the dense machine (one scan per row and target state, every row stepped): round 3's path
+    def dense_call(n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tk = 0
+        for i in range(n):
+            p2, _ = _dense_decode(dec, feats[i % 2], senti, n_z, beam, c["L"], fsm, ncons, kmax)
+            tk += count_tokens(p2, 1)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, tk
+    dense_call(1)
+    dense_n = max(1, n_calls // 2)
+    dense_el, dense_tokens = dense_call(dense_n)
+    # selection step alone at this shape
+    B, G = nimg * n_z, nimg * n_z * S * beam
+    logits = torch.randn(G, V, device=device)
+    last_pred = torch.randint(2, V, (B, S * beam), device=device)
+    last_lp = -torch.rand(B, S, beam, device=device) * 20
+    mach = torch.arange(nimg, dtype=torch.int32, device=device).repeat_interleave(n_z)
+    pred_o = torch.empty(B, S * beam, dtype=torch.int64, device=device)
+    lp_o = torch.empty(B, S, beam, device=device)
+    back = torch.empty(B, S * beam, dtype=torch.int64, device=device)
+    sval = torch.empty(B * S * S * beam * per_node, device=device)
+    sidx = torch.empty(B * S * S * beam * per_node, dtype=torch.int64, device=device)
+    d = L.BeamDesc()
+    d.scores, d.ld, d.raw_logits = L.ptr(logits), V, 1
+    d.fsm, d.mach = L.ptr(fsm), L.ptr(mach)
+    d.B, d.beam, d.per_node, d.end_index = B, beam, per_node, 1
+    d.last_pred, d.last_lp, d.pred, d.lp_out, d.backptr = L.ptr(last_pred), L.ptr(last_lp), L.ptr(pred_o), L.ptr(lp_o), L.ptr(back)
+    d.scratch_val, d.scratch_idx = L.ptr(sval), L.ptr(sidx)
+    sel = {}
+    for name, tables in (("compiled", comp), ("dense", None)):
+        d.tables = L.ptr(tables.tables) if tables is not None else None
+        d.dims = tables.dims if tables is not None else L.FsmDims(nimg, S, V, 0, 1)
+        for _ in range(2):
+            lib.ssc_beam_step_fsm(C.byref(d), L.stream_ptr())
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 5
+        e0.record()
+        for _ in range(reps):
+            lib.ssc_beam_step_fsm(C.byref(d), L.stream_ptr())
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / reps * 1e3
+        alg = G * V * 4.0                                           # the logits, once
+        moved = alg if tables is not None else S * G * V * 5.0       # dense: V floats + V mask bytes per (row, target state)
+        sel[name] = {"us_per_step": us, "algorithmic_bytes": alg, "achieved_GBps": alg / us / 1e3, "frac_of_8TBps": alg / us / 1e3 / HBM_PEAK_GBS,
+                     "bytes_scanned": moved}
+        if name == "compiled":
+            got = (pred_o.clone(), lp_o.clone(), back.clone())
+        else:
+            same = bool(torch.equal(got[0], pred_o) and torch.equal(got[1], lp_o) and torch.equal(got[2], back))
+    dec.weights_frozen = False
+    dec._last_ctx = None
+    if was_training:
+        model.train()
+    return {"metric": "constrained decode tokens/sec (k=3 constraints, beam 5 x 20 latent samples per image)", "value": tokens / el,
+            "unit": "tokens/s", "ms_per_call": el / n_calls * 1e3, "captions_per_s": n_calls * nimg * n_z / el,
+            "config": {"workload": "C4 shapes with constrained beam search: %d images per call x 20 samples x %d states x beam 5 = %d rows "
+                                   "per step, k = 3 constraint classes per image (one in five a two-word phrase), V = %d, max 20 steps, "
+                                   "random-init weights" % (nimg, S, G, V),
+                       "images_per_call": nimg, "states": S, "rows_per_step": G, "from_states_in_compiled_form": sparse_frac},
+            "dense_machine_same_shape": {"tokens_per_s": dense_tokens / dense_el, "ms_per_call": dense_el / dense_n * 1e3},
+            "selection": {"bound": "hbm", "kernel": "beam_row_fsm_kernel + beam_merge_kernel (one scan of the logits per row)",
+                          "peak": HBM_PEAK_GBS, "unit": "GB/s", **sel["compiled"],
+                          "dense": sel["dense"], "dense_equals_compiled": same}}
+
+
+def _dense_decode(dec, feats, senti, n_z, beam, L_, fsm, ncons, kmax):
+    """Round 3's constrained decode, kept for the A/B: the dense machine, one masked scan per (row, target state), every row stepped."""
+    from ssc_runtime.decode import cbs_search
+    from ssc_runtime.decoding import select_best_beam_simple_batched
+    dev = feats.device
+    nimg = feats.size(0)
+    B = nimg * n_z
+    ctx = dec.prepare(feats)
+    sent_b = senti.reshape(nimg, 1).expand(nimg, n_z).reshape(B)
+    mach = torch.arange(nimg, dtype=torch.int32, device=dev).repeat_interleave(n_z)
+    calls = {"k": 0}
+
+    def step(tokens, state):
+        G = tokens.numel()
+        eps = torch.randn(G, dec.dims.Z, device=dev)
+        calls["k"] += 1
+        lp, st, _ = dec.step(ctx, tokens, state, sent_b.view(B, 1).expand(B, G // B).reshape(G), eps, raw_logits=True)
+        return lp, {k: v for k, v in st.items() if k not in ("h_encoder", "c_encoder")}
+    start = torch.full((B,), 1, dtype=torch.long, device=dev)
+    beams, lps = cbs_search(start, None, step, fsm, 1, L_, beam, 2, early_stop=True, raw_logits=True,
+                            ungathered_ok=lambda G, group: dec.ungathered_ok(ctx, G, group), mach=mach, compile_fsm=False)
+    best, _ = select_best_beam_simple_batched(beams, lps, ncons, kmax)
+    return best.view(nimg, n_z, -1), calls["k"]
+
+
 def bench_decode(args, model, eng, c, rank, world, device):
     import torch.distributed as dist
+    if args.mode == "decode-cbs":
+        print(json.dumps(measure_decode_cbs(model, c, device, legs=args.cbs_legs)), flush=True)
+        return
     res = measure_decode(model, c, rank, world, device, args.images, args.warmup)
     if rank == 0:
         print(json.dumps(res), flush=True)
@@ -280,9 +443,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", type=int, default=C2["B"])
-    ap.add_argument("--mode", default="train", choices=["train", "decode"],
+    ap.add_argument("--mode", default="train", choices=["train", "decode", "decode-cbs"],
                     help="train: headline captions/sec (default); decode: C4 diverse-decode tokens/sec")
     ap.add_argument("--images", type=int, default=1000, help="decode mode: synthetic images in total")
+    ap.add_argument("--cbs-legs", default="all", choices=["all", "compiled"],
+                    help="decode-cbs mode: all = compiled machines, the dense A/B and the selection step alone; compiled = the product path only")
     ap.add_argument("--dump-gemm", default="", help="write the per-shape GEMM timing table (roofline leg) to this file")
     ap.add_argument("--no-decode", action="store_true", help="skip the short decode leg of the default run")
     ap.add_argument("--dp-algo", default="auto", choices=["auto", "rccl", "xgmi"],
@@ -338,7 +503,7 @@ def main():
                             senti_prior_multip=0.5, device=device).to(device)
     eng = model._engine()  # flat parameter / gradient store + fused kernels; the module's parameters are views of it
     eng.dp_algo = args.dp_algo
-    if args.mode == "decode":
+    if args.mode in ("decode", "decode-cbs"):
         return bench_decode(args, model, eng, c, rank, world, device)
     # decode leg of the headline metric (BASELINE.json: "captions/sec (train step) + decode tokens/sec"): C4 itself
     # (1000 images per rank = 20 beam-search calls of 5000 rows), reported in the same JSON line.  It runs FIRST, on the
@@ -347,6 +512,9 @@ def main():
     dres = None
     if not args.timed_only and not args.no_decode:
         dres = measure_decode(model, c, rank, world, device, 1000 * world, 5)   # C4: 1000 images per GPU (>= 5 calls and >= 2 s of warm-up: the leg runs first, on a GPU coming out of idle)
+    cbs_res = None
+    if rank == 0 and world == 1 and not args.timed_only and not args.no_decode:
+        cbs_res = measure_decode_cbs(model, c, device)
     batches = [synth_batch(1234 + rank + 100 * i, c["B"], c["R"], c["F"], c["L"], c["V"], c["Z"], device) for i in range(4)]
     total_iters = 70000
 
@@ -568,6 +736,8 @@ def main():
         result["decode_tokens_per_s"] = dres["value"]
         result["decode"] = {k: dres[k] for k in ("metric", "value", "unit", "steps", "ms_per_step", "config", "roofline", "captions_per_s",
                                                  "row_steps_per_s", "early_stop_disabled")}
+    if rank == 0 and cbs_res is not None:
+        result["decode_cbs"] = cbs_res
     if rank == 0 and not args.timed_only:
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(c)

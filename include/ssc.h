@@ -441,6 +441,12 @@ typedef struct {
                               * (g - g % group) + parent[g].  Every reader goes through the row lists the parent sharing builds
                               * anyway, so the four (G,H) gathers per step go away.  Only where ssc_decode_ungathered_ok() says
                               * so (parent sharing and the attended-feature table both in use); SSC_EINVAL otherwise */
+  const float* row_lp;       /* optional (G): the running log-prob of every row's beam.  A row with row_lp <= -1e19 (no finite beam: what
+                              * ssc_beam_desc.skip_dead scores without its logits) or whose token is end_index (an ended beam re-emits
+                              * END whatever its logits are, cbs.py:177-181) is SKIPPED: no product is formed for it, its outputs
+                              * (states, alpha, log_probs row) are unspecified.  Honoured where parent sharing and the attended-feature
+                              * table are in use (untied head); elsewhere every row is computed */
+  int end_index;             /* used with row_lp */
 } ssc_decode_step_desc;
 /* 1 if a step of G rows in groups of `group` (0: group size not known yet - any divisor of G above 1 will do) over an image context of
  * nimg images with this att_table mode can take un-gathered states */

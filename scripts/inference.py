@@ -101,25 +101,37 @@ def main():
             constraints = {int(k): v for k, v in json.load(open(_A.constraints_json)).items()}
         builder = FiniteStateMachineBuilder(vocabulary, _A.wordforms_tsv, None, max_given_constraints=kmax,
                                             max_words_per_constraint=_C.DATA.CBS.MAX_WORDS_PER_CONSTRAINT)
-        per_call = min(per_call, 4)   # (B, S, S, V) uint8 per (image, sample): keep the machines of one call within ~1 GB
+        # (one machine per IMAGE, shared by its N_Z samples and compiled on the device - ssc_fsm_compile -: a call is sized by its rows)
+    ROW_BUDGET = 40000   # rows (image, sample, state, beam) per decode step of a constrained call
     with torch.no_grad():
-        for lo in range(0, len(data), per_call):
-            feats = data.feats[lo: lo + per_call].to(device)
-            senti = data.senti[lo: lo + per_call, 0].to(device)
+        lo = 0
+        while lo < len(data):
+            built = None
+            n_here = min(per_call, len(data) - lo)
+            if builder is not None:
+                # one machine per image, padded to the chunk's largest state count: the states an image does not use have no
+                # incoming transition and never hold a finite beam (their rows are skipped: diverse_decode(skip_dead=True));
+                # the chunk ends where its rows per step would exceed the budget
+                built, S = [], 0
+                for i in range(n_here):
+                    m = builder.build([c for c in constraints.get(int(data.image_id[lo + i]), [])][:kmax])
+                    if built and (len(built) + 1) * n_z * max(S, m[1]) * beam > ROW_BUDGET:
+                        break
+                    built.append(m)
+                    S = max(S, m[1])
+                n_here = len(built)
+            feats = data.feats[lo: lo + n_here].to(device)
+            senti = data.senti[lo: lo + n_here, 0].to(device)
             if _A.sentiment is not None:
                 senti = torch.full_like(senti, _A.sentiment)
             fsm = ncons = None
-            if builder is not None:
-                # one machine per image (shared by its N_Z samples), padded to the chunk's largest state count: the states an
-                # image does not use have no incoming transition and never hold a finite beam
-                built = [builder.build([c for c in constraints.get(int(data.image_id[lo + i]), [])][:kmax]) for i in range(feats.size(0))]
-                S = max(b[1] for b in built)
+            if built is not None:
                 V = vocabulary.get_vocab_size()
-                fsm = torch.zeros(feats.size(0), n_z, S, S, V, dtype=torch.uint8)
+                fsm = torch.zeros(n_here, S, S, V, dtype=torch.uint8)
                 for i, (m, ns, _) in enumerate(built):
-                    fsm[i, :, :ns, :ns] = m[:ns, :ns]
-                fsm = fsm.view(-1, S, S, V).to(device)
-                ncons = torch.tensor([len(constraints.get(int(data.image_id[lo + i]), [])[:kmax]) for i in range(feats.size(0))]
+                    fsm[i, :ns, :ns] = m[:ns, :ns]
+                fsm = fsm.to(device)
+                ncons = torch.tensor([len(constraints.get(int(data.image_id[lo + i]), [])[:kmax]) for i in range(n_here)]
                                      ).repeat_interleave(n_z)
             pred, _ = diverse_decode(model._dec, feats, senti, n_z, beam, _C.DATA.MAX_CAPTION_LENGTH, boundary, fsm=fsm,
                                      num_constraints=ncons, min_constraints_to_satisfy=_C.MODEL.MIN_CONSTRAINTS_TO_SATISFY)
@@ -133,6 +145,7 @@ def main():
                 image_id = int(data.image_id[lo + i])
                 for k in range(n_z):
                     predictions.append({"image_id": image_id, "caption": " ".join(words[i, k, : n_keep[i, k]])})
+            lo += n_here
     json.dump(predictions, open(_A.output_path, "w", encoding="utf-8"))
     print(f"wrote {len(predictions)} captions to {_A.output_path}")
 

@@ -8,6 +8,7 @@
 // feats.repeat(...) for every beam row on every step, so both of its lru-caches miss and avg / pv are
 // recomputed per step; here per-image terms are computed once (ssc_decode_prepare) and rows index
 // their image (row g -> image g / rows_per_image, batch-major).
+#include <algorithm>
 #include <initializer_list>
 
 #include "ssc_common.h"
@@ -29,7 +30,7 @@ struct ImgLayout {
 // of the beam's last token (ssc_lstm_fwd_desc.add0_rows), instead of a K = E segment of the gate product in every step
 // (5000 x 4800 x 1000 per step at C4: 0.25 ms x 20 steps).  Below it (a handful of rows per step) the segment is cheaper.
 constexpr int DEC_TOKEN_TABLE_MIN_IMAGES = 8;
-constexpr int DEDUP_MAX_ROWS = 56 * 1024;   // the parent sharing keeps one byte per row in the LDS of one workgroup
+constexpr int DEDUP_MAX_ROWS = 1 << 20;   // rows of one decode step that go through the parent / live-row lists
 }  // namespace
 int ssc_g_beam_reg = ssc_env_int("SSC_BEAM_REG", 1);   // 0: the LDS-staged selection kernel for every vocabulary size
 int ssc_g_dec_dedup = ssc_env_int("SSC_DEC_DEDUP", 1);   // ssc_debug_set("dec_dedup"): products fed only by the parent's states run on distinct parents
@@ -67,7 +68,8 @@ ImgLayout img_layout(const ssc_model_cfg* c, int nimg, int R) {
 
 struct StepLayout {
   size_t emb, q, att, z, attn_logits, proj, wcol, slabs, slab_floats, total;
-  size_t dedup;   // int32: [0] = number of distinct parents, [4 .. 4+G) = their representative rows (ascending), [4+G .. 4+2G) = slot of every row
+  size_t dedup;   // int32: [0] = number of distinct parents, [1] = number of live rows, [4 .. 4+G) = the parents' representative rows (ascending),
+                  // [4+G .. 4+2G) = slot of every row, [4+2G ..) = previous-state row of every row, [4+3G ..) = live rows (ascending)
   int Ep, Ap, Fp, Zp;
 };
 StepLayout step_layout(const ssc_model_cfg* c, int G, int R) {
@@ -81,7 +83,7 @@ StepLayout step_layout(const ssc_model_cfg* c, int G, int R) {
   l.attn_logits = o; o += r64((size_t)G * R);
   l.proj = o; o += r64(c->tied ? (size_t)G * l.Ep : 0);
   l.wcol = o; o += r64((size_t)4 * c->H);
-  l.dedup = o; o += r64((size_t)3 * G + 8);
+  l.dedup = o; o += r64((size_t)6 * G + 8);   // (+ two counts per workgroup of the list kernels)
   size_t skinny = (size_t)33 * G * 4 * c->H;
   size_t full = (size_t)16 * 1024 * 1024;  // 64 MB: split-K slabs of the large GEMMs
   l.slab_floats = skinny > full ? skinny : full;
@@ -327,55 +329,77 @@ __global__ void gather_rows_kernel(const float* __restrict__ src, int ld, const 
 }
 
 // Beams of one group (S * beam consecutive rows) that descend from the same parent hold identical recurrent states after the
-// re-ordering of cbs.py:236-250.  One workgroup: rep = the first row of each (group, parent) class; out[0] = number of classes,
+// re-ordering of cbs.py:236-250.  rep = the first live row of each (group, parent) class; out[0] = number of classes,
 // out[4 .. ) their representative rows in ascending order, out[4 + n .. ) the class index (slot) of every row.
 // out[4 + 2n .. ): prow = the row of every row's previous state; `ungathered` (the states are still in the previous step's row
 // order): prow[g] = (g - g % group) + parent[g] and the representative rows are the classes' parent rows; else prow[g] = g.
-__global__ __launch_bounds__(1024) void dedup_rows_kernel(const int64_t* __restrict__ parent, int n, int group, int* __restrict__ out,
-                                                          int ungathered) {
-  // the back-pointers go to LDS once (one byte each: group <= 255, checked by the caller; n <= DEDUP_MAX_ROWS) - every later look
-  // at a neighbour's parent is an LDS read instead of a dependent global load (38 us -> ~8 us at 10000 rows)
-  extern __shared__ unsigned char sp[];
-  __shared__ int part[1024];
-  const int tid = threadIdx.x;
+// row_lp (optional): only LIVE rows count - a row whose running log-prob is <= -1e19 (no finite beam: ssc_beam_desc.skip_dead) or
+// whose last token is END (an ended beam re-emits END whatever its logits are, cbs.py:177-181) needs no decode step: its class is
+// not listed (unless a live row shares it), its slot is 0, and out[1] / out[4 + 3n .. ) = the number / the ascending list of live
+// rows for the products that run on every (live) row.  The parent of a live row was itself live, so live rows never read a row
+// that was skipped.
+// Two launches over workgroups of whole groups (<= 256 rows each, a thread per row): PHASE 0 counts every workgroup's classes and
+// live rows, PHASE 1 sums the counts of the workgroups before it and writes the lists.  (Round 3's single-workgroup form searched
+// every row's group serially: 8 us at 10000 rows in groups of 5, 400 us at 19200 rows in groups of 80 - a constrained search.)
+template <int PHASE>
+__global__ __launch_bounds__(256) void dedup_rows_kernel(const int64_t* __restrict__ parent, int n, int group, int gpb,
+                                                         int* __restrict__ out, int* __restrict__ counts, int ungathered,
+                                                         const float* __restrict__ row_lp, const int64_t* __restrict__ tokens,
+                                                         int end_index) {
+  __shared__ int first[256];
+  __shared__ int s_slot[256];
+  __shared__ int wsum[2][4];
+  __shared__ int red[2][4];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int rpb = gpb * group;   // rows of this workgroup (<= 256)
+  const int g = blockIdx.x * rpb + t;
+  const bool valid = t < rpb && g < n;
   int* urows = out + 4;
   int* slot = out + 4 + n;
   int* prow = out + 4 + 2 * n;
-  for (int g = tid; g < n; g += 1024) sp[g] = (unsigned char)parent[g];
+  int* lrows = out + 4 + 3 * n;
+  first[t] = 0x7fffffff;
+  const bool live = valid && (!row_lp || (row_lp[g] > -1e19f && tokens[g] != end_index));
+  const int p = valid ? (int)parent[g] : 0;
+  const int cls = (t / group) * group + p;   // (p < group: a back-pointer within the group)
   __syncthreads();
-  auto first_of = [&](int g) -> int {   // the first row of g's group with the same parent
-    const int g0 = g - g % group;
-    const unsigned char pg = sp[g];
-    for (int k = g0; k < g; ++k)
-      if (sp[k] == pg) return k;
-    return g;
-  };
-  const int per = (n + 1023) / 1024;
-  const int lo = min(tid * per, n), hi = min(lo + per, n);
-  int cnt = 0;
-  for (int g = lo; g < hi; ++g) cnt += first_of(g) == g;
-  part[tid] = cnt;
+  if (live) atomicMin(&first[cls], t);
   __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {  // inclusive scan
-    const int v = tid >= off ? part[tid - off] : 0;
-    __syncthreads();
-    part[tid] += v;
-    __syncthreads();
+  const int f = live ? first[cls] : -1;
+  const bool rep = live && f == t;
+  const unsigned long long brep = __ballot(rep), blive = __ballot(live);
+  if (lane == 0) { wsum[0][wave] = __popcll(brep); wsum[1][wave] = __popcll(blive); }
+  __syncthreads();
+  const int nrep = wsum[0][0] + wsum[0][1] + wsum[0][2] + wsum[0][3];
+  const int nlive = wsum[1][0] + wsum[1][1] + wsum[1][2] + wsum[1][3];
+  if (PHASE == 0) {
+    if (t == 0) { counts[2 * blockIdx.x] = nrep; counts[2 * blockIdx.x + 1] = nlive; }
+    if (valid) { urows[g] = 0; lrows[g] = 0; }   // entries past the counts are never used; keep them in range
+    return;
   }
-  int pos = part[tid] - cnt;
-  for (int g = lo; g < hi; ++g)
-    if (first_of(g) == g) { urows[pos] = ungathered ? g - g % group + (int)sp[g] : g; slot[g] = pos; ++pos; }
-  if (tid == 1023) out[0] = part[1023];
-  for (int i = part[1023] + tid; i < n; i += 1024) urows[i] = 0;   // entries past the count are never used; keep them in range
+  int orep = 0, olive = 0;   // the classes / live rows of the workgroups before this one
+  for (int j = t; j < (int)blockIdx.x; j += 256) { orep += counts[2 * j]; olive += counts[2 * j + 1]; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { orep += __shfl_xor(orep, o, 64); olive += __shfl_xor(olive, o, 64); }
+  if (lane == 0) { red[0][wave] = orep; red[1][wave] = olive; }
   __syncthreads();
-  __threadfence_block();
-  // slots of the non-representative rows: their representative lies EARLIER in the same group; its slot was written above by this
-  // or another thread of the workgroup (global memory, one workgroup: visible after the barrier)
-  for (int g = lo; g < hi; ++g) {
-    const int f = first_of(g);
-    if (f != g) slot[g] = slot[f];
-    prow[g] = ungathered ? g - g % group + (int)sp[g] : g;
+  orep = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+  olive = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+  int rrep = __popcll(brep & below), rlive = __popcll(blive & below);
+  for (int w = 0; w < wave; ++w) { rrep += wsum[0][w]; rlive += wsum[1][w]; }
+  const int prev_row = g - g % group + p;
+  if (rep) {
+    urows[orep + rrep] = ungathered ? prev_row : g;
+    s_slot[t] = orep + rrep;
   }
+  if (live) lrows[olive + rlive] = g;
+  __syncthreads();
+  if (valid) {
+    slot[g] = live ? s_slot[f] : 0;
+    prow[g] = (ungathered && live) ? prev_row : g;
+  }
+  if (blockIdx.x == gridDim.x - 1 && t == 0) { out[0] = orep + nrep; out[1] = olive + nlive; }
 }
 
 __global__ void dec_add2d_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb, int cols,
@@ -485,14 +509,33 @@ extern "C" int ssc_decode_step(const ssc_model_cfg* cfg, const ssc_params* p, co
   const bool dedup = d->parent && d->group > 1 && d->group <= 255 && G <= DEDUP_MAX_ROWS && G % d->group == 0 && il.token_table &&
                      !d->emb_override && G >= 512 && ssc_g_dec_dedup && H % 4 == 0;   // (16-byte operand rows: the products over the row lists are then ONE launch, one slab)
   const int* ucount = nullptr; const int* urows = nullptr; const int* slot = nullptr; const int* prow = nullptr;
+  // rows that need no step at all (ssc_decode_step_desc.row_lp): every product runs on the live rows / live parent classes only; the
+  // per-row kernels still visit the skipped rows and leave garbage there, which no live row ever reads
+  const bool live = dedup && att_table && d->row_lp && !cfg->tied;
+  const int* lcount = nullptr; const int* lrows = nullptr;
   // un-gathered states: every reader of h1 / c1 / hd / cd must go through the row lists
   if (d->ungathered && !(dedup && att_table)) return SSC_EINVAL;
   if (dedup) {
     int* dd = reinterpret_cast<int*>(W + l.dedup);
-    SSC_LAUNCH(dedup_rows_kernel, dim3(1), dim3(1024), (size_t)((G + 15) & ~15), st, d->parent, G, d->group, dd, d->ungathered ? 1 : 0);
+    const int gpb = std::max(1, 256 / d->group), nwg = ssc_cdiv(G, gpb * d->group);
+    int* counts = dd + 4 + 4 * G;
+    SSC_LAUNCH(dedup_rows_kernel<0>, dim3(nwg), dim3(256), 0, st, d->parent, G, d->group, gpb, dd, counts, d->ungathered ? 1 : 0,
+               live ? d->row_lp : nullptr, d->tokens, d->end_index);
+    SSC_CHECK_LAUNCH();
+    SSC_LAUNCH(dedup_rows_kernel<1>, dim3(nwg), dim3(256), 0, st, d->parent, G, d->group, gpb, dd, counts, d->ungathered ? 1 : 0,
+               live ? d->row_lp : nullptr, d->tokens, d->end_index);
     SSC_CHECK_LAUNCH();
     ucount = dd; urows = dd + 4; slot = dd + 4 + G; prow = dd + 4 + 2 * G;
+    if (live) { lcount = dd + 1; lrows = dd + 4 + 3 * G; }
   }
+  // a product over every LIVE row, written to the rows' own places (ssc_gemm with one row list for A and C; one launch, no split)
+  auto gemm_live = [&](std::initializer_list<Seg> segs, int N, float* Cc, int ldc, const float* bias) -> int {
+    ssc_gemm_desc g;
+    fill_desc(g, segs, G, N);
+    g.C = Cc; g.ldc = ldc; g.bias = bias; g.splits = 1; g.workspace = nullptr; g.workspace_floats = 0;
+    g.m_count = lcount; g.a_rows = lrows; g.c_rows = lrows;
+    return ssc_gemm(&g, st);
+  };
   float* slabs_u = slabs + (size_t)G * H4;   // second product of the decoder gates (distinct parents): behind the first one's rows
 
   // embedding + attention LSTM (updown_captioner.py:430, updown_cell.py:143-148)
@@ -520,7 +563,8 @@ extern "C" int ssc_decode_step(const ssc_model_cfg* cfg, const ssc_params* p, co
     SSC_TRY(ssc_lstm_fwd(&f, st));
   }
   // attention over the image's regions (attention.py:69-95, updown_cell.py:151-158)
-  SSC_TRY(gemm_nt(st, slabs, l.slab_floats, {{d->h1_out, H, p->wq, p->ld_wq, H}}, G, A, W + l.q, l.Ap));
+  if (live) SSC_TRY(gemm_live({{d->h1_out, H, p->wq, p->ld_wq, H}}, A, W + l.q, l.Ap, nullptr));
+  else SSC_TRY(gemm_nt(st, slabs, l.slab_floats, {{d->h1_out, H, p->wq, p->ld_wq, H}}, G, A, W + l.q, l.Ap));
   if (att_table)
     SSC_TRY(ssc_attn_weights(W + l.q, l.Ap, I + il.pv, p->wa, I + il.mask, G, R, A, rpi, W + l.attn_logits, d->alpha, st));
   else
@@ -535,8 +579,12 @@ extern "C" int ssc_decode_step(const ssc_model_cfg* cfg, const ssc_params* p, co
     if (att_table && dedup) {   // hd' segment on the distinct parents, [h1 | z] on every row
       SSC_TRY(gemm_slabs(st, slabs_u, l.slab_floats - (size_t)G * H4, {{d->hd, H, I + il.wsum_dec, il.Hp, H}}, G, H4, &ns_u, ucount, urows));
       if (ns_u != 1) return SSC_EINVAL;
-      SSC_TRY(gemm_slabs(st, slabs, (size_t)G * H4, {{d->h1_out, H, p->dec_w_ih + F, p->ld_dec_w_ih, H}, {W + l.z, l.Zp, I + il.wz, il.Zp, Z}},
-                         G, H4, &ns));
+      if (live) {
+        SSC_TRY(gemm_live({{d->h1_out, H, p->dec_w_ih + F, p->ld_dec_w_ih, H}, {W + l.z, l.Zp, I + il.wz, il.Zp, Z}}, H4, slabs, H4, nullptr));
+        ns = 1;
+      } else
+        SSC_TRY(gemm_slabs(st, slabs, (size_t)G * H4, {{d->h1_out, H, p->dec_w_ih + F, p->ld_dec_w_ih, H}, {W + l.z, l.Zp, I + il.wz, il.Zp, Z}},
+                           G, H4, &ns));
     } else if (att_table)   // the attended-feature segment comes from the per-image table inside the cell kernel
       SSC_TRY(gemm_slabs(st, slabs, l.slab_floats,
                          {{d->h1_out, H, p->dec_w_ih + F, p->ld_dec_w_ih, H}, {d->hd, H, I + il.wsum_dec, il.Hp, H},
@@ -565,6 +613,8 @@ extern "C" int ssc_decode_step(const ssc_model_cfg* cfg, const ssc_params* p, co
     SSC_TRY(gemm_nt(st, slabs, l.slab_floats, {{d->hd_out, H, p->proj_w, p->ld_proj_w, H}}, G, E, W + l.proj, l.Ep));
     SSC_TRY(ssc_bias_tanh(W + l.proj, l.Ep, G, E, p->proj_b, st));
     SSC_TRY(gemm_nt(st, slabs, l.slab_floats, {{W + l.proj, l.Ep, p->emb, p->ld_emb, E}}, G, V, d->log_probs, V));
+  } else if (live) {
+    SSC_TRY(gemm_live({{d->hd_out, H, p->out_w, p->ld_out_w, H}}, V, d->log_probs, V, p->out_b));
   } else {
     SSC_TRY(gemm_nt(st, slabs, l.slab_floats, {{d->hd_out, H, p->out_w, p->ld_out_w, H}}, G, V, d->log_probs, V, p->out_b));
   }

@@ -96,6 +96,9 @@ class DecodeEngine:
         # "_ungathered": the states are the previous call's outputs in ITS row order (cbs_search left out the re-ordering by
         # back-pointer because ungathered_ok() said this call reads them through the parent lists)
         ungathered = bool(states.get("_ungathered", False))
+        # "_skip": (running log-probs (B,S,beam), end index) from cbs_search(skip_dead=True): rows without a finite beam and rows
+        # whose beam has ended need no step (ssc_decode_step_desc.row_lp)
+        skip = states.get("_skip")
         st = {k: v.contiguous() for k, v in states.items() if not k.startswith("_")}
         tokens = tokens.to(torch.int64).contiguous()
         eps = eps.to(self.device, torch.float32).contiguous()
@@ -122,7 +125,8 @@ class DecodeEngine:
                                    new["h_decoder"].data_ptr(), new["c_decoder"].data_ptr(), alpha.data_ptr(),
                                    lp.data_ptr() if lp is not None else None, 1 if raw_logits else 0,
                                    1 if emb_table is not None else 0,
-                                   parent.data_ptr() if has_parent else None, group, att_table, 1 if ungathered else 0)
+                                   parent.data_ptr() if has_parent else None, group, att_table, 1 if ungathered else 0,
+                                   skip[0].data_ptr() if skip is not None else None, int(skip[1]) if skip is not None else 0)
         p = self._params()
         if emb_table is not None:  # rows of `emb_table` are the token embeddings themselves (UpDownCell.forward API)
             p.emb = emb_table.data_ptr()
@@ -279,7 +283,9 @@ def cbs_search(start_predictions: torch.Tensor, start_state, step: Callable, fsm
                     break
             elif int(flag[0]) != 0:    # a plain read of pinned host memory: nothing is queued, nothing waited for
                 break
-        state["_last_lp"] = last_lp   # (for step functions that skip rows without a finite beam)
+        state["_last_lp"] = last_lp
+        if skip_dead:   # (for step functions that skip the rows whose logits will not be read: DecodeEngine.step)
+            state["_skip"] = (last_lp, end_index)
         out = step(last, state)
         lp, state = out[0].contiguous(), out[1]
         new_lp = torch.empty_like(last_lp)

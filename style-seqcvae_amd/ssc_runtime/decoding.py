@@ -60,3 +60,24 @@ def select_best_beam_with_constraints(beams, beam_log_probabilities, given_const
         valid_all.append(vb)
         best.append(vb[torch.argmax(vlp)])
     return torch.stack(best).long(), torch.stack(valid_all)
+
+
+def select_best_beam_simple_batched(beams: torch.Tensor, beam_log_probabilities: torch.Tensor, given_constraints: torch.Tensor,
+                                    min_constraints_to_satisfy: int = 2):
+    """select_best_beam_with_constraints(..., cbs_simple=True) for the whole batch in a handful of device ops instead of a Python
+    loop over the batch entries (a 100-image x 20-sample call has 2000 of them): a state s < 2**k is valid when its popcount is
+    >= min(k, min_constraints_to_satisfy) (decoding.py:52-60); the best beam is beam 0 of the valid state with the highest beam-0
+    log-prob, the first such state on ties (torch.argmax over the valid list).  -> (best (B, steps) int64, its log-prob (B))."""
+    B, S = beams.shape[:2]
+    dev = beams.device
+    k = given_constraints.to(dev).long().view(B, 1)
+    s = torch.arange(S, device=dev).view(1, S)
+    pop = torch.zeros(1, S, dtype=torch.long, device=dev)
+    for bit in range(max(1, (S - 1).bit_length())):
+        pop = pop + ((s >> bit) & 1)
+    valid = (s < (torch.ones_like(k) << k)) & (pop >= torch.clamp(k, max=min_constraints_to_satisfy))
+    lp0 = beam_log_probabilities[:, :, 0]
+    top = torch.where(valid, lp0, torch.full_like(lp0, float("-inf"))).max(dim=1, keepdim=True).values
+    first = (valid & (lp0 == top)).int().argmax(dim=1)
+    rows = torch.arange(B, device=dev)
+    return beams[rows, first, 0, :].long(), lp0[rows, first]

@@ -108,7 +108,7 @@ class DecodeStepDesc(C.Structure):
                 ("tokens", vp), ("sentiment", vp), ("eps", vp), ("h1", vp), ("c1", vp), ("hd", vp), ("cd", vp),
                 ("h1_out", vp), ("c1_out", vp), ("hd_out", vp), ("cd_out", vp), ("alpha", vp), ("log_probs", vp),
                 ("raw_logits", C.c_int), ("emb_override", C.c_int), ("parent", vp), ("group", C.c_int), ("att_table", C.c_int),
-                ("ungathered", C.c_int)]
+                ("ungathered", C.c_int), ("row_lp", vp), ("end_index", C.c_int)]
 
 
 class FsmDims(C.Structure):
