@@ -28,6 +28,13 @@ MFMA_F32_PEAK_TF = 157.3   # MI355X_MICROARCH.md: fp32 MFMA = fp32 vector peak
 MFMA_BF16_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
 
 C2 = dict(B=64, R=36, F=2048, L=20, Z=128, V=10000, E=1000, H=1200, A=768)
+C5 = dict(B=128, R=100, F=2048, L=40, Z=128, V=30000, E=1000, H=1200, A=768)
+
+
+def _dbg_env(name, default=None):
+    """A/B switches of the tools (SSC_BENCH_*): honoured only in a process that opts in with SSC_DEBUG=1, like the library's own
+    SSC_* switches - a stray variable must not change what the driver's run measures."""
+    return os.environ.get(name, default) if os.environ.get("SSC_DEBUG", "") == "1" else default
 
 
 def synth_batch(seed, B, R, F, L, V, Z, device):
@@ -152,7 +159,7 @@ def attention_roofline(device):
 
 
 def decode_roofline(dec, feats, senti, c):
-    """bf16-MFMA roofline of ONE beam-search call (50 images x 20 samples x beam 5 = 5000 rows, early stop off): a hipEvent pair
+    """bf16-MFMA roofline of ONE beam-search call (100 images x 20 samples x beam 5 = 10000 rows, early stop off): a hipEvent pair
     around every GEMM launch (ssc_prof_enable); the large products (M >= 512 rows: attention-LSTM gates, decoder gates,
     vocabulary head of every step + the per-call tables) run 6 bf16 MFMA passes per fp32 product (3xBF16), so
     achieved = 6 * sum 2MNK / sum duration against the 2.5 PFLOP/s dense bf16 peak."""
@@ -203,25 +210,25 @@ def measure_decode(model, c, rank, world, device, images, warmup):
     was_training = model.training
     model.eval()
     dec = model._dec
-    dec.weights_frozen = os.environ.get("SSC_BENCH_NO_REUSE") != "1"   # an inference run: the parameters do not change between the calls (what scripts/inference.py sets; the variable is the A/B switch)
-    chunk = int(os.environ.get("SSC_BENCH_DECODE_CHUNK", "100"))   # images per beam-search call: 100 x 20 samples x 5 beams = 10000 rows (the variable is the A/B switch)
+    dec.weights_frozen = _dbg_env("SSC_BENCH_NO_REUSE") != "1"   # an inference run: the parameters do not change between the calls (what scripts/inference.py sets; the variable is the A/B switch)
+    chunk = int(_dbg_env("SSC_BENCH_DECODE_CHUNK", "100"))   # images per beam-search call: 100 x 20 samples x 5 beams = 10000 rows (the variable is the A/B switch)
     chunk = max(1, min(chunk, images // world))
     per_rank = images // world
     n_chunks = max(1, per_rank // chunk)
     g = torch.Generator().manual_seed(4321 + rank)
     feats = [torch.randn(chunk, c["R"], c["F"], generator=g).to(device) for _ in range(min(n_chunks, 4))]
     senti = torch.ones(chunk, device=device)
-    results = {}
-    for early in (True, False):
-        # warm-up: at least `warmup` calls AND (first pass) at least 2 s of work - a GPU coming out of idle needs more than a
-        # second to reach its sustained state: with 5 calls (0.35 s) a fresh process measured 293-295 k tokens/s, every later
-        # process on the same box 312-316 k
-        t_w = time.perf_counter()
-        i = 0
-        while i < (warmup if early else 1) or (early and time.perf_counter() - t_w < 2.0):
-            diverse_decode(dec, feats[i % len(feats)], senti, 20, 5, c["L"], 1, early_stop=early)
-            torch.cuda.synchronize()
-            i += 1
+    results = {True: [0.0, 0.0, 0.0], False: [0.0, 0.0, 0.0]}
+    passes = []
+    # warm-up: at least `warmup` calls AND at least 3 s of work - a GPU coming out of idle needs seconds to reach its sustained
+    # state (BENCH_r03: the leg that ran first read 434 k tokens/s, the one behind it 498 k; alternating on one box they are 1 % apart)
+    t_w = time.perf_counter()
+    i = 0
+    while i < warmup or time.perf_counter() - t_w < 3.0:
+        diverse_decode(dec, feats[i % len(feats)], senti, 20, 5, c["L"], 1, early_stop=True)
+        torch.cuda.synchronize()
+        i += 1
+    for early in (True, False, True, False):   # alternating passes of n_chunks calls each; a leg's figure is over both of its passes
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -241,7 +248,9 @@ def measure_decode(model, c, rank, world, device, images, warmup):
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             el, tokens, rows_steps = float(tmax[0]), float(t[1]), float(t[2])
-        results[early] = (el, tokens, rows_steps)
+        for k, v in enumerate((el, tokens, rows_steps)):
+            results[early][k] += v
+        passes.append({"early_stop": early, "tokens_per_s": tokens / el})
     droof = decode_roofline(dec, feats[0], senti, c) if rank == 0 else None
     dec.weights_frozen = False       # (the train leg that may follow changes the weights)
     dec._last_ctx = None
@@ -251,16 +260,18 @@ def measure_decode(model, c, rank, world, device, images, warmup):
         return None
     el, tokens, rows_steps = results[True]
     el2, tokens2, rows_steps2 = results[False]
+    n_timed = 2 * n_chunks   # (two passes per leg)
     return {"metric": "decode tokens/sec (beam 5 x 20 latent samples per image)", "value": tokens / el, "unit": "tokens/s",
-            "n_gpus": world, "steps": n_chunks, "warmup": warmup, "ms_per_step": el / n_chunks * 1e3,
+            "n_gpus": world, "steps": n_timed, "warmup": warmup, "ms_per_step": el / n_timed * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "C4 diverse decode: %d images, 36x2048 feats, beam 5 (per-node 2), N_Z=20, max 20 steps, "
-                                   "trivial FSM, random-init weights" % (n_chunks * chunk * world),
+            "config": {"workload": "C4 diverse decode: %d images (decoded twice: two alternating passes per leg), 36x2048 feats, beam 5 "
+                                   "(per-node 2), N_Z=20, max 20 steps, trivial FSM, random-init weights" % (n_chunks * chunk * world),
                        "images_per_call": chunk, "rows_per_call": chunk * 100},
             "roofline": droof,
-            "captions_per_s": n_chunks * chunk * world * 20 / el, "row_steps_per_s": rows_steps / el,
+            "captions_per_s": n_timed * chunk * world * 20 / el, "row_steps_per_s": rows_steps / el,
             "early_stop_disabled": {"tokens_per_s": tokens2 / el2, "row_steps_per_s": rows_steps2 / el2,
-                                    "captions_per_s": n_chunks * chunk * world * 20 / el2}}
+                                    "captions_per_s": n_timed * chunk * world * 20 / el2},
+            "passes": passes}
 
 
 def measure_decode_cbs(model, c, device, n_calls=3, warmup=2, legs="all"):
@@ -450,10 +461,12 @@ def main():
                     help="decode-cbs mode: all = compiled machines, the dense A/B and the selection step alone; compiled = the product path only")
     ap.add_argument("--dump-gemm", default="", help="write the per-shape GEMM timing table (roofline leg) to this file")
     ap.add_argument("--no-decode", action="store_true", help="skip the short decode leg of the default run")
-    ap.add_argument("--dp-algo", default="auto", choices=["auto", "rccl", "xgmi"],
-                    help="gradient exchange at N > 1: rccl = torch.distributed all-reduce; xgmi = direct reduce-scatter + all-gather over "
-                         "hipIpc peer mappings (csrc/collective.hip); auto (default) = verify the direct path against RCCL at start-up, "
-                         "time both on the 446 MB gradient buffer and keep the faster (falls back to rccl when peers cannot be mapped)")
+    ap.add_argument("--dp-algo", default="rccl", choices=["auto", "rccl", "xgmi"],
+                    help="gradient exchange at N > 1: rccl (default) = torch.distributed all-reduce; xgmi = direct reduce-scatter + "
+                         "all-gather over hipIpc peer mappings (csrc/collective.hip); auto = verify the direct path against RCCL at start-up "
+                         "(over the FULL gradient buffer), time both and keep the faster (falls back to rccl when peers cannot be mapped).  "
+                         "The direct path has never run across two devices in any record of this repository (no multi-GPU node was "
+                         "available to the build), so it is opt-in until one such run exists")
     ap.add_argument("--prewarm", type=int, default=150,
                     help="untimed extra train steps before the W warm-up steps when no decode leg ran first (a GPU coming out of "
                          "idle needs > 1 s to reach its sustained state); 0 for the profiler passes")
@@ -471,7 +484,7 @@ def main():
         raise SystemExit("bench.py needs a ROCm GPU: the HIP path has no CPU fallback")
     # SSC_BENCH_ONE_DEVICE=1 (rehearsal on a one-GPU box only): every rank uses cuda:0 and gloo carries the
     # collectives; the real multi-GPU run is one rank per GPU over RCCL ("nccl" backend on ROCm).
-    rehearsal = os.environ.get("SSC_BENCH_ONE_DEVICE") == "1"
+    rehearsal = _dbg_env("SSC_BENCH_ONE_DEVICE") == "1"
     dev_index = 0 if rehearsal else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)

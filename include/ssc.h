@@ -548,6 +548,38 @@ int ssc_beam_backtrace_ctl(const int64_t* preds, const int64_t* backptrs, const 
 /* device-visible address of a pinned (hipHostMalloc / torch pin_memory) host word, for ssc_beam_desc.host_flag */
 int ssc_host_device_ptr(void* host_ptr, void** device_ptr);
 
+/* ------------------------------------------------------------------------------------------------
+ * One diverse-decode call = ONE entry point: the whole constrained beam search over nimg images x n_samples latent
+ * samples (batch entry b = (image, sample), rows (b, fsm state, beam)), every step launched from the library:
+ * ConstrainedBeamSearch.search (updown-baseline/updown/modules/cbs.py:59-277) around the eval _decode_step
+ * (var_updown/var_updown/models/updown_captioner.py:371-455), what var_updown/scripts/inference.py:117-189 runs per image
+ * and sample.  Noise is handed in for all steps (the reference draws (rows, Z) per step, updown_cell.py:206), so the
+ * random state a call consumes does not depend on where the search stops.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  int nimg, R, n_samples;        /* image context (ssc_decode_prepare over nimg images of R regions); B = nimg * n_samples */
+  int S, beam, per_node, max_steps, end_index;
+  const float* feats;            /* (nimg, R, F) */
+  const void* imgbuf;            /* from ssc_decode_prepare */
+  const float* sentiment;        /* (B) or NULL */
+  const float* eps0;             /* (B, Z): noise of the first step */
+  const float* eps;              /* (max_steps - 1, B*S*beam, Z): noise of the later steps */
+  const uint8_t* fsm;            /* (M, S, S, V) dense machines; NULL with S = 1: the trivial machine */
+  const void* tables;            /* ssc_fsm_compile of `fsm`, or NULL: dense scans */
+  ssc_fsm_dims dims;             /* of `tables` */
+  const int* mach;               /* (B) machine of every batch entry, or NULL: machine b */
+  int skip_dead;                 /* ssc_beam_desc.skip_dead + ssc_decode_step_desc.row_lp (needs `tables`) */
+  int early_stop;                /* cbs.py:167 */
+  int64_t* predictions;          /* out (B, S*beam, max_steps): columns [0, ctl[0]) are the search's; the rest holds end_index */
+  float* log_probs;              /* out (B, S, beam) */
+  int* ctl;                      /* device int32[2 + 2*max_steps], initialised by the call; ctl[0] = number of columns (steps) */
+  int* host_flag;                /* optional: device-visible address of a pinned host word (ssc_host_device_ptr), zeroed by the caller */
+  const int* host_flag_host;     /* the same word's host address: polled between steps to stop queueing */
+} ssc_search_desc;
+size_t ssc_decode_search_workspace_bytes(const ssc_model_cfg* cfg, const ssc_search_desc* d);
+int ssc_decode_search(const ssc_model_cfg* cfg, const ssc_params* p, const ssc_search_desc* d, void* workspace,
+                      size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

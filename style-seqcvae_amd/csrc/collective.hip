@@ -80,8 +80,11 @@ __device__ __forceinline__ void load_sys(f32x4 (&v)[W], const float* const (&p)[
 
 // out[i] = sum_j src[j][i], i in [0, n4) float4 units, j in fixed rank order; out may alias src[rank].  W = world size (compile
 // time): one float4 per rank in flight per thread, many waves in flight per CU
+// err: the collective's error word - once a bounded wait of this (or an earlier) collective has given up, the peers' data cannot be
+// trusted to be complete: the data kernels then leave the buffer as it is instead of writing a partial sum the update would use
 template <int W>
-__global__ __launch_bounds__(256) void xgmi_reduce_kernel(Peers p, float* __restrict__ out, size_t n4) {
+__global__ __launch_bounds__(256) void xgmi_reduce_kernel(Peers p, float* __restrict__ out, size_t n4, const int* __restrict__ err) {
+  if (err && *err) return;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
     f32x4 a[W];
@@ -95,7 +98,7 @@ __global__ __launch_bounds__(256) void xgmi_reduce_kernel(Peers p, float* __rest
     *reinterpret_cast<f32x4*>(out + 4 * i) = sa;
   }
 }
-typedef void (*reduce_fn)(Peers, float*, size_t);
+typedef void (*reduce_fn)(Peers, float*, size_t, const int*);
 inline reduce_fn pick_reduce(int W) {
   switch (W) {
     case 1: return xgmi_reduce_kernel<1>;
@@ -116,9 +119,9 @@ struct Gather {
   int world;
 };
 // blockIdx.y = source rank
-__global__ __launch_bounds__(256) void xgmi_gather_kernel(Gather g) {
+__global__ __launch_bounds__(256) void xgmi_gather_kernel(Gather g, const int* __restrict__ err) {
   const int j = blockIdx.y;
-  if (j >= g.world || !g.src[j]) return;
+  if (j >= g.world || !g.src[j] || (err && *err)) return;
   const float* s = g.src[j];
   float* d = g.dst[j];
   const size_t n4 = g.n4[j], stride = (size_t)gridDim.x * blockDim.x;
@@ -225,7 +228,7 @@ extern "C" int ssc_xgmi_allreduce(const ssc_xgmi_comm* c, size_t lo, size_t hi, 
     int grid = (int)((n4 + 255) / 256);
     if (grid > 4096) grid = 4096;
     if (grid < 1) grid = 1;
-    SSC_LAUNCH(pick_reduce(W), dim3(grid), dim3(256), 0, st, p, c->buf[r] + s_lo, n4);
+    SSC_LAUNCH(pick_reduce(W), dim3(grid), dim3(256), 0, st, p, c->buf[r] + s_lo, n4, (const int*)err);
     SSC_CHECK_LAUNCH();
   }
   // stage 1: every rank's reduced shard is in its buffer
@@ -250,7 +253,7 @@ extern "C" int ssc_xgmi_allreduce(const ssc_xgmi_comm* c, size_t lo, size_t hi, 
       int gx = (int)((most + 1023) / 1024);
       if (gx > 256) gx = 256;
       if (gx < 1) gx = 1;
-      SSC_LAUNCH(xgmi_gather_kernel, dim3(gx, W), dim3(256), 0, st, g);
+      SSC_LAUNCH(xgmi_gather_kernel, dim3(gx, W), dim3(256), 0, st, g, (const int*)err);
       SSC_CHECK_LAUNCH();
     }
   }

@@ -410,6 +410,8 @@ __global__ void dec_add2d_kernel(const float* __restrict__ a, int lda, const flo
 
 }  // namespace
 
+int ssc_decode_att_table_enabled() { return ssc_g_dec_att_table != 0; }
+
 extern "C" size_t ssc_decode_image_bytes(const ssc_model_cfg* cfg, int nimg, int R) {
   if (!cfg || nimg <= 0 || R <= 0) return 0;
   return img_layout(cfg, nimg, R).total * sizeof(float);

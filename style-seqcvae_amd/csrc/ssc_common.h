@@ -95,3 +95,4 @@ int ssc_beam_rows_dense(bool norm, const float* lp, int ldlp, const uint8_t* fsm
 int ssc_beam_merge(const float* sval, const int64_t* sidx, const float* last_lp, int B, int S, int beam, int per_node,
                    int64_t* pred, float* lp_out, int64_t* backptr, int end_index, int* ctl, int step_index, int max_steps,
                    int* host_flag, hipStream_t st);
+int ssc_decode_att_table_enabled();   // the "dec_att_table" switch (decode.hip)

@@ -39,6 +39,7 @@ class DecodeEngine:
         # Default off: the drop-in module's eval calls may be interleaved with training steps.
         self.weights_frozen = False
         self._last_ctx = None
+        self._sws = None   # workspace of search()
 
     def prepare(self, feats: torch.Tensor) -> ImageContext:
         assert feats.is_cuda and feats.dtype == torch.float32 and feats.dim() == 3 and feats.size(2) == self.dims.F
@@ -146,6 +147,60 @@ class DecodeEngine:
         att = 0 if (ctx.R > 128 or G < self.ATT_TABLE_MIN_ROWS or G // ctx.nimg < self.ATT_TABLE_MIN_ROWS_PER_IMAGE) else 1
         return bool(self.lib._raw_ssc_decode_ungathered_ok(C.byref(self._cfg), ctx.nimg, G, group, att))
 
+
+    def search(self, ctx: ImageContext, sentiment: Optional[torch.Tensor], n_samples: int, beam: int, per_node: int, max_steps: int,
+               end_index: int, eps0: torch.Tensor, eps: Optional[torch.Tensor], fsm: Optional[torch.Tensor] = None,
+               compiled: Optional["CompiledFsm"] = None, mach: Optional[torch.Tensor] = None, skip_dead: bool = False,
+               early_stop: bool = True):
+        """The whole constrained beam search of one call in ONE library call (ssc_decode_search): ctx.nimg images x n_samples
+        latent samples, batch entry b = (image, sample).  sentiment (B) or None; eps0 (B, Z), eps (max_steps - 1, B*S*beam, Z):
+        the noise of every step, drawn by the caller.  fsm (M,S,S,V) / compiled / mach as in cbs_search.
+        -> (predictions (B, S, beam, steps), log_probs (B, S, beam)); one wait at the end, for the number of steps."""
+        d = self.dims
+        B = ctx.nimg * n_samples
+        S = 1 if fsm is None else fsm.size(1)
+        G = B * S * beam
+        dev = self.device
+        if fsm is not None:
+            assert fsm.is_cuda and fsm.dtype == torch.uint8 and fsm.is_contiguous()
+            assert mach is not None or fsm.size(0) == B
+        sd = _lib.SearchDesc()
+        sd.nimg, sd.R, sd.n_samples = ctx.nimg, ctx.R, n_samples
+        sd.S, sd.beam, sd.per_node, sd.max_steps, sd.end_index = S, beam, per_node, max_steps, end_index
+        sd.feats, sd.imgbuf = ctx.feats.data_ptr(), ctx.buf.data_ptr()
+        sent = sentiment.reshape(B).to(dev, torch.float32).contiguous() if sentiment is not None else None
+        eps0 = eps0.to(dev, torch.float32).contiguous()
+        assert tuple(eps0.shape) == (B, d.Z), eps0.shape
+        if max_steps > 1:
+            eps = eps.to(dev, torch.float32).contiguous()
+            assert tuple(eps.shape) == (max_steps - 1, G, d.Z), (eps.shape, (max_steps - 1, G, d.Z))
+        sd.sentiment, sd.eps0, sd.eps = _lib.ptr(sent), _lib.ptr(eps0), _lib.ptr(eps) if max_steps > 1 else None
+        mach = mach.to(dev, torch.int32).contiguous() if mach is not None else None
+        sd.fsm, sd.mach = _lib.ptr(fsm), _lib.ptr(mach)
+        if compiled is not None:
+            assert compiled.dims.S == S and compiled.dims.P >= per_node
+            sd.tables, sd.dims = _lib.ptr(compiled.tables), compiled.dims
+        sd.skip_dead = 1 if (skip_dead and compiled is not None) else 0
+        sd.early_stop = 1 if early_stop else 0
+        pred = torch.empty(B, S * beam, max_steps, dtype=torch.int64, device=dev)
+        lps = torch.empty(B, S, beam, dtype=torch.float32, device=dev)
+        ctl = torch.empty(2 + 2 * max_steps, dtype=torch.int32, device=dev)
+        sd.predictions, sd.log_probs, sd.ctl = _lib.ptr(pred), _lib.ptr(lps), _lib.ptr(ctl)
+        flag = None
+        if early_stop:
+            flag, flag_dev = _host_flag()
+            if flag_dev is not None:
+                sd.host_flag, sd.host_flag_host = flag_dev, C.c_void_p(flag.data_ptr())
+        nbytes = self.lib.ssc_decode_search_workspace_bytes(C.byref(self._cfg), C.byref(sd))
+        if self._sws is None or self._sws.numel() < nbytes:
+            self._sws = None   # (release before growing)
+            self._sws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        p = self._params()
+        self.lib.ssc_decode_search(C.byref(self._cfg), C.byref(p), C.byref(sd), _lib.ptr(self._sws), self._sws.numel(), _lib.stream_ptr())
+        nsteps = int(ctl[0]) if early_stop else max_steps   # (the one wait of the call: its result is about to be read anyway)
+        if flag is not None:
+            _HOST_FLAGS.append(flag)
+        return pred[:, :, :nsteps].contiguous().view(B, S, beam, nsteps), lps
 
     def _step_from_embedding(self, ctx, token_embedding, states, sentiment, eps):
         G = token_embedding.size(0)

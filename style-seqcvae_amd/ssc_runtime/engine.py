@@ -323,6 +323,8 @@ class TrainEngine:
                     works.append((_EventWork(done, cur), (lo, hi)))
                 elif hi > lo:
                     works.append((dist.all_reduce(self.grads.flat[lo:hi], op=dist.ReduceOp.SUM, group=group, async_op=True), (lo, hi)))
+        if xg is not None:
+            xg.poll(self._comm_stream)   # a bounded wait that gave up leaves the gradients un-summed: reported one step later at most
         if self.dp_profile:   # exposure = time the compute stream sits between its last backward kernel and the reduced gradients
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -373,6 +375,15 @@ class TrainEngine:
                                  device=self.device if dist.get_backend(group) == "nccl" else "cpu")
                 dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
                 return float(t.item())
+            # the start-up self-test over the WHOLE gradient buffer (the construction's own covers 64 K floats): ordering / visibility
+            # problems of a 446 MB exchange do not show on a buffer that fits the caches
+            try:
+                obj.self_test(self.grads.flat.numel())
+                full_ok = True
+            except Exception as e:   # noqa: BLE001 - XgmiError is raised on every rank or on none
+                full_ok = False
+                if log:
+                    log(f"direct path failed its full-buffer self-test ({e}): using torch.distributed")
             self.grads.flat.zero_()
             r_ms = timed(lambda: dist.all_reduce(self.grads.flat, op=dist.ReduceOp.SUM, group=group))
             x_ms = timed(lambda: obj.allreduce(0, self.grads.flat.numel()))
@@ -381,7 +392,7 @@ class TrainEngine:
                 healthy = True
             except Exception:   # noqa: BLE001 - a bounded wait gave up on this rank
                 healthy = False
-            healthy = obj._agree(healthy)   # collective: every rank takes the same path
+            healthy = obj._agree(healthy and full_ok)   # collective: every rank takes the same path
             choice.update(rccl_ms=r_ms, xgmi_ms=x_ms)
             if not healthy:
                 choice.update(why="a rank timed out in the direct path")

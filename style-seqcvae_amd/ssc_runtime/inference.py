@@ -11,11 +11,10 @@ from typing import List, Optional
 
 import torch
 
-from .decode import DecodeEngine, cbs_search
+from .decode import DecodeEngine
 from .decoding import select_best_beam_simple_batched
 
 
-_RAW = not (os.environ.get("SSC_DEBUG", "") == "1" and os.environ.get("SSC_RAW_LOGITS", "1") == "0")   # A/B switch (tools): 0 = log_softmax kernel + selection on log-probs
 
 
 def diverse_decode(dec: DecodeEngine, feats: torch.Tensor, sentiment: Optional[torch.Tensor], n_samples: int, beam: int,
@@ -48,36 +47,35 @@ def diverse_decode(dec: DecodeEngine, feats: torch.Tensor, sentiment: Optional[t
         assert fsm.size(0) == nimg, (fsm.shape, nimg, n_samples)
         mach = torch.arange(nimg, dtype=torch.int32, device=dev).repeat_interleave(n_samples)
     seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if eps_steps is None else None
-    start = torch.full((B,), boundary_index, dtype=torch.long, device=dev)
     skip = bool(skip_dead) and not trivial and fsm.size(1) > 1
-    if skip and compiled is None:
+    if not trivial and fsm.size(1) > 1 and compiled is None:
         from .decode import CompiledFsm
         compiled = CompiledFsm(fsm, fill=max(8, per_node or (beam // 2) or beam))
 
+    per_node = per_node or (beam // 2) or beam
+    S = 1 if trivial else fsm.size(1)
+    G = B * S * beam
+
     def search(skip_now):
-        calls["k"] = 0
-        gen = None
-        if seed is not None:
-            # The search may queue a few steps beyond the one after which every beam had ended (the early-stop flag is polled, not
-            # waited for): their noise must not come out of the global generator, or the captions of the NEXT call would depend on
-            # host / device timing.
+        # the noise of ALL steps is drawn up front - from the caller's list, or from a generator of this call's own seeded by ONE draw
+        # of the global generator: the search may stop early (or, polled late, a few steps after it could have), and what the
+        # global random state looks like after the call must not depend on that
+        if eps_steps is not None:
+            eps0 = eps_steps[0]
+            rest = [e.to(dev, torch.float32) for e in eps_steps[1:max_steps]]
+            eps = torch.zeros(max(max_steps - 1, 1), G, d.Z, device=dev)
+            if rest:
+                eps[: len(rest)] = torch.stack(rest)
+        else:
             gen = torch.Generator(device=dev)
             gen.manual_seed(seed)
-
-        def step(tokens, state):
-            G = tokens.numel()
-            sent_rows = sent_b.view(B, 1).expand(B, G // B).reshape(G) if sent_b is not None else None
-            eps = eps_steps[calls["k"]] if eps_steps is not None else torch.randn(G, d.Z, device=dev, generator=gen)
-            calls["k"] += 1
-            lp, st, alpha = dec.step(ctx, tokens, state, sent_rows, eps, raw_logits=_RAW)
-            # the eval cell never touches the encoder-LSTM states (updown_cell.py:200-203): do not carry (and re-order by
-            # backpointer) two (G,H) tensors the next step will not read
-            return lp, {k: v for k, v in st.items() if k not in ("h_encoder", "c_encoder")}
-
-        return cbs_search(start, None, step, fsm, boundary_index, max_steps, beam, per_node or (beam // 2) or beam,
-                          early_stop=early_stop, early_stop_every=4, raw_logits=_RAW,
-                          ungathered_ok=lambda G, group: dec.ungathered_ok(ctx, G, group), mach=mach, compiled=compiled,
-                          skip_dead=skip_now)
+            eps0 = torch.randn(B, d.Z, device=dev, generator=gen)
+            eps = torch.randn(max(max_steps - 1, 1), G, d.Z, device=dev, generator=gen)
+        beams, lps = dec.search(ctx, sent_b, n_samples, beam, per_node, max_steps, boundary_index, eps0, eps,
+                                fsm=None if trivial else fsm.contiguous(), compiled=compiled, mach=mach, skip_dead=skip_now,
+                                early_stop=early_stop)
+        calls["k"] = beams.size(-1)   # one step call per column (cbs.py:127,170)
+        return beams, lps
 
     beams, lps = search(skip)
     if trivial or fsm.size(1) == 1:

@@ -123,6 +123,14 @@ class BeamDesc(C.Structure):
                 ("host_flag", vp)]
 
 
+class SearchDesc(C.Structure):
+    _fields_ = [("nimg", C.c_int), ("R", C.c_int), ("n_samples", C.c_int), ("S", C.c_int), ("beam", C.c_int), ("per_node", C.c_int),
+                ("max_steps", C.c_int), ("end_index", C.c_int), ("feats", vp), ("imgbuf", vp), ("sentiment", vp), ("eps0", vp),
+                ("eps", vp), ("fsm", vp), ("tables", vp), ("dims", FsmDims), ("mach", vp), ("skip_dead", C.c_int),
+                ("early_stop", C.c_int), ("predictions", vp), ("log_probs", vp), ("ctl", vp), ("host_flag", vp),
+                ("host_flag_host", vp)]
+
+
 # name -> (restype, argtypes).  Every symbol include/ssc.h declares is listed; tests check they all resolve.
 _i, _f, _sz = C.c_int, C.c_float, C.c_size_t
 SYMBOLS = {
@@ -193,6 +201,8 @@ SYMBOLS = {
     "ssc_beam_step_fsm": (_i, [C.POINTER(BeamDesc), vp]),
     "ssc_beam_backtrace_ctl": (_i, [vp, vp, vp, _i, _i, _i, _i, vp, vp]),
     "ssc_host_device_ptr": (_i, [vp, C.POINTER(vp)]),
+    "ssc_decode_search_workspace_bytes": (_sz, [C.POINTER(ModelCfg), C.POINTER(SearchDesc)]),
+    "ssc_decode_search": (_i, [C.POINTER(ModelCfg), C.POINTER(Params), C.POINTER(SearchDesc), vp, _sz, vp]),
 }
 
 # include/ssc_debug.h (diagnostics / profiling / tuning switches: not part of the product ABI)

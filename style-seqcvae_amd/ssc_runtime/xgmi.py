@@ -25,16 +25,25 @@ class XgmiError(RuntimeError):
 
 
 class XgmiAllReduce:
-    def __init__(self, flat: torch.Tensor, group=None, verify: bool = True):
-        if not (flat.is_cuda and flat.dtype == torch.float32 and flat.is_contiguous() and flat.data_ptr() % 16 == 0):
-            raise XgmiError("flat buffer must be a contiguous, 16-byte aligned fp32 CUDA tensor")
+    def __init__(self, flat: torch.Tensor, group=None, verify: bool = True, timeout_polls: int = 0):
+        """timeout_polls: bound of every cross-process wait in s_sleep(32) polls (0 = the library's default, 2**22: a few seconds).
+        A rank that is late by more than that - a checkpoint write, a validation pass on one rank only - makes its peers' waits
+        give up: the error word is set, the data kernels of that and every later collective leave the buffers untouched, and
+        `poll()` / `check()` raise.  Keep slow one-rank work out of the step loop, or raise the bound."""
         self.group = group
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
-        if self.world > L.SSC_XGMI_MAX_RANKS:
-            raise XgmiError(f"world size {self.world} > {L.SSC_XGMI_MAX_RANKS}")
         self.lib = L.load()
         self.flat = flat
         self.device = flat.device
+        self.timeout_polls = int(timeout_polls)
+        self._err_pending = None
+        # preconditions and the export can fail on ONE rank only (an expandable-segment / VMM allocation has no IPC handle): the
+        # failure is carried INTO the collective below and voted on, so that no rank is left waiting in all_gather_object
+        pre = None
+        if not (flat.is_cuda and flat.dtype == torch.float32 and flat.is_contiguous() and flat.data_ptr() % 16 == 0):
+            pre = "flat buffer must be a contiguous, 16-byte aligned fp32 CUDA tensor"
+        elif self.world > L.SSC_XGMI_MAX_RANKS:
+            pre = f"world size {self.world} > {L.SSC_XGMI_MAX_RANKS}"
         # 3 stages x MAX_RANKS sequence words, then (from word 32) a 32-word pattern block the peers read back through the copy
         # engine before any kernel touches a fresh mapping (_probe_peers)
         self.flags = torch.zeros(64, dtype=torch.int32, device=self.device)
@@ -43,9 +52,16 @@ class XgmiAllReduce:
         self.seq = 0
         torch.cuda.synchronize(self.device)
         self._opened = {}   # (rank, handle bytes) -> mapped allocation base (an allocation may hold both buffers)
-        mine = (self.device.index, self._export(flat), self._export(self.flags), flat.numel())
+        mine = None
+        if pre is None:
+            try:
+                mine = (self.device.index, self._export(flat), self._export(self.flags), flat.numel())
+            except Exception as e:   # noqa: BLE001 - reported through the vote
+                pre = f"export failed: {type(e).__name__}: {e}"
         handles = [None] * self.world
-        dist.all_gather_object(handles, mine, group=group)
+        dist.all_gather_object(handles, mine, group=group)   # (always entered, with None on a rank that could not export)
+        if not self._agree(pre is None and all(h is not None for h in handles)):
+            raise XgmiError(pre or "a peer rank could not export its buffers")
         # Every step that can fail on ONE rank only (mapping a peer, the self-test's comparison) is followed by a collective vote,
         # so that all ranks raise - or go on - together and never wait for each other in different collectives.
         why = self._map_peers(handles)
@@ -124,7 +140,27 @@ class XgmiAllReduce:
             return
         self.seq += 1
         st = stream if stream is not None else torch.cuda.current_stream(self.device)
-        self.lib.ssc_xgmi_allreduce(C.byref(self.comm), lo, hi, self.seq, 0, L.ptr(self.err), C.c_void_p(st.cuda_stream))
+        self.lib.ssc_xgmi_allreduce(C.byref(self.comm), lo, hi, self.seq, self.timeout_polls, L.ptr(self.err), C.c_void_p(st.cuda_stream))
+
+    def poll(self, stream: Optional[torch.cuda.Stream] = None):
+        """Non-blocking look at the error word: raises XgmiError if a wait of a collective issued BEFORE the previous poll() gave
+        up (the word travels to pinned host memory behind `stream` and is read once that copy has completed).  The training step
+        calls it once per step, so a timed-out exchange - whose data kernels have left the gradients un-summed - is reported one
+        step later at most instead of silently diverging the replicas."""
+        if self._err_pending is not None and self._err_pending[0].query():
+            code = int(self._err_pending[1][0])
+            self._err_pending = None
+            if code:
+                raise XgmiError(f"xgmi all-reduce: rank {self.rank} timed out waiting for its peers at stage {code - 1}; the gradients "
+                                "of that step were NOT summed")
+        if self._err_pending is None:
+            st = stream if stream is not None else torch.cuda.current_stream(self.device)
+            host = torch.empty(1, dtype=torch.int32).pin_memory()
+            with torch.cuda.stream(st):
+                host.copy_(self.err, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(st)
+            self._err_pending = (ev, host)
 
     def close(self):
         """Collective: unmap the peers' buffers (before the owning processes exit)."""

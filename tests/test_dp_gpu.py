@@ -189,7 +189,8 @@ def _xgmi_worker(rank, world, port, ret):
         want[lo:hi] = sum(gathered)
         assert torch.equal(ret_vals, want), (lo, hi, (ret_vals - want).abs().max())
     xg.check()
-    assert torch.equal(want[64:8], total[64:8])
+    # a range that was reduced exactly once (by the whole-buffer call only) against the independently computed sum
+    assert torch.equal(flat.cpu()[4 * 300_000:n - 4], total[4 * 300_000:n - 4])
     if rank == 0:
         ret.put("ok")
     dist.barrier()

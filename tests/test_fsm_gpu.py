@@ -287,3 +287,66 @@ def test_decode_step_skips_rows_nobody_reads(tmp_path, end_bias):
     # the constraint words are in the captions (token ids of "dog"/"dogs" = 4/5 in this vocabulary are not asserted: Vocabulary.synthetic
     # has no such words - the machines constrain ids by position; what is asserted is the equality above and a non-trivial search)
     assert int((outs[0] != 1).sum()) > 0
+
+
+def _small_captioner(V, end_bias=0.0, seed=13, H=64):
+    from ssc_runtime.vocab import Vocabulary
+    from var_updown.models import UpDownCaptioner
+    torch.manual_seed(seed)
+    m = UpDownCaptioner(Vocabulary.synthetic(V), image_feature_size=64, embedding_size=40, hidden_size=H,
+                        attention_projection_size=24, max_caption_length=9, beam_size=3, z_space=8, prior_std=1.0,
+                        simple_vae=False, latent_embedding="glove", sentiment_vae=1, senti_prior_multip=0.5,
+                        device=torch.device("cuda")).to("cuda")
+    with torch.no_grad():
+        m._output_layer.bias[1] += end_bias
+    m.eval()
+    m._engine()
+    return m
+
+
+@pytest.mark.parametrize("nimg,ns,beam,machines,end_bias,early", [(8, 8, 5, False, 0.0, False), (8, 8, 5, False, 7.0, True),
+                                                                 (2, 3, 3, False, 0.0, True), (8, 4, 3, True, 0.0, False),
+                                                                 (8, 4, 3, True, 5.0, True), (2, 2, 2, True, 0.0, True)])
+def test_one_call_search_equals_the_step_by_step_search(tmp_path, nimg, ns, beam, machines, end_bias, early):
+    """ssc_decode_search (the whole search launched from the library: DecodeEngine.search) against cbs_search driving
+    DecodeEngine.step from Python with the same noise: beams, log-probs and step count bit-equal.  Large calls (parent lists,
+    attended-feature table, un-gathered states) and small ones (states re-ordered by ssc_gather_rows); trivial machine and built
+    machines shared per image; searches that stop early."""
+    V, R, Z, steps = 400, 6, 8, 9
+    m = _small_captioner(V, end_bias)
+    dec = m._dec
+    g = torch.Generator().manual_seed(21)
+    feats = torch.randn(nimg, R, 64, generator=g).cuda()
+    senti = torch.randint(-1, 2, (nimg,), generator=g).float().cuda()
+    B = nimg * ns
+    fsm = comp = mach = None
+    S = 1
+    if machines:
+        sets = [(), ("dog",), ("dog", "cat"), ("fire hydrant", "dog"), ("dog", "cat", "red"), ("cat",), ("red", "dog"), ("dog", "cat", "fire hydrant")][:nimg]
+        fsm = _machines(tmp_path, V, sets).cuda()
+        S = fsm.size(1)
+        comp = CompiledFsm(fsm, fill=8)
+        mach = torch.arange(nimg, dtype=torch.int32, device="cuda").repeat_interleave(ns)
+    G = B * S * beam
+    eps0 = torch.randn(B, Z, generator=g).cuda()
+    eps = torch.randn(steps - 1, G, Z, generator=g).cuda()
+    sent_b = senti.view(nimg, 1).expand(nimg, ns).reshape(B)
+    ctx = dec.prepare(feats)
+    calls = {"k": 0}
+
+    def step(tokens, state):
+        n = tokens.numel()
+        e = eps0 if calls["k"] == 0 else eps[calls["k"] - 1]
+        calls["k"] += 1
+        lp, st, _ = dec.step(ctx, tokens, state, sent_b.view(B, 1).expand(B, n // B).reshape(n), e, raw_logits=True)
+        return lp, {k: v for k, v in st.items() if k not in ("h_encoder", "c_encoder")}
+    start = torch.full((B,), 1, dtype=torch.long, device="cuda")
+    want_p, want_lp = cbs_search(start, None, step, fsm, 1, steps, beam, max(1, beam // 2), early_stop=early, early_stop_every=1,
+                                 raw_logits=True, ungathered_ok=lambda n, grp: dec.ungathered_ok(ctx, n, grp), mach=mach, compiled=comp)
+    ctx2 = dec.prepare(feats)
+    got_p, got_lp = dec.search(ctx2, sent_b, ns, beam, max(1, beam // 2), steps, 1, eps0, eps, fsm=fsm, compiled=comp, mach=mach,
+                               early_stop=early)
+    assert got_p.shape == want_p.shape, (got_p.shape, want_p.shape)
+    assert torch.equal(got_p, want_p) and torch.equal(got_lp, want_lp)
+    if early and end_bias > 0 and not machines:   # (with machines the beams that hold only fills never all end: cbs.py:167 does not fire)
+        assert got_p.shape[-1] < steps
