@@ -209,12 +209,13 @@ int ssc_attn_fwd_pool(const float* q, int ldq, const float* pv, const float* wa,
 int ssc_attn_bwd(const float* datt, int lddatt, const float* q, int ldq, const float* pv, const float* wa,
                  const float* alpha, const float* feats, int G, int R, int A, int F, float* dq, int lddq,
                  float* dpv_acc, float* dwa_acc, float* scratch_dalpha, void* stream);
-/* The same when the attention weights also pooled obj (ssc_attn_fwd_pool): dalpha[g,r] += (dpool_a[g,:D] + dpool_b[g,:D]) . obj[g,r,:D]
- * (two addends of the pooled tensor's gradient, e.g. the LSTM input gradients and the KL term; dpool_b may be 0). */
+/* The same when the attention weights also pooled obj (ssc_attn_fwd_pool): dalpha[g,r] += (dpool_a[g,:Da] + dpool_b[g,:D]) . obj[g,r,:D]
+ * (two addends of the pooled tensor's gradient, e.g. the LSTM input gradients and the KL term; dpool_b may be 0; Da <= D: dpool_a
+ * covers the first Da entries only - the conditioning block is the whole pooled vector or its first entry, updown_cell.py:169-172). */
 int ssc_attn_bwd_pool(const float* datt, int lddatt, const float* q, int ldq, const float* pv, const float* wa,
                       const float* alpha, const float* feats, int G, int R, int A, int F, float* dq, int lddq,
                       float* dpv_acc, float* dwa_acc, float* scratch_dalpha, const float* obj, int D, const float* dpool_a,
-                      int lddpa, const float* dpool_b, int lddpb, void* stream);
+                      int lddpa, int Da, const float* dpool_b, int lddpb, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Latent head epilogue: fc_mean / fc_log_var bias add, reparameterised sample and closed-form KL
@@ -241,6 +242,12 @@ int ssc_latent_fwd(const ssc_latent_fwd_desc* d, void* stream);
 /* eval-mode sample: z = eps*sqrt(prior_var) + prior_mean (updown_cell.py:200-208). */
 int ssc_latent_prior_sample(const float* eps, int ldeps, const float* sent, float pm_scale, float prior_var, int G, int Z,
                             float* z, int ldz, void* stream);
+
+/* the same with a per-row, per-dimension prior mean pm (G, ldpm) - SENTIMENT_VAE = 2, where the prior mean of a step is the
+ * attention-pooled attribute means (updown_cell.py:160-163,200-208) - and / or variance pv (G, ldpv); a NULL pm / pv falls back to
+ * pm_scale * sent / prior_var. */
+int ssc_latent_prior_sample_pm(const float* eps, int ldeps, const float* pm, int ldpm, const float* pv, int ldpv, const float* sent,
+                               float pm_scale, float prior_var, int G, int Z, float* z, int ldz, void* stream);
 
 /* latent backward (Appendix A.4): dz -> dmulv (B,2Z) = [dmu | dlv];  k[b] = gk[b]*w[b]. */
 typedef struct {
@@ -447,6 +454,14 @@ typedef struct {
                               * (states, alpha, log_probs row) are unspecified.  Honoured where parent sharing and the attended-feature
                               * table are in use (untied head); elsewhere every row is computed */
   int end_index;             /* used with row_lp */
+  const float* obj_atts;     /* cfg->kld_mode 2 (SENTIMENT_VAE = 2): per-region attribute means (nimg, R, Z) of the image context.  The step's
+                              * prior mean is their attention-weighted sum (updown_cell.py:160-163), z = eps sqrt(prior_var) + that
+                              * (:200-208), and its leading cfg->S entries (all Z: LATENT_EMBEDDING "glove"; 1: "senti_word_net",
+                              * :169-172) condition the decoder LSTM (:219-222) */
+  float* prior_mean_out;     /* optional (G, Z) ld Z: the pooled prior mean of every row (what the cell returns, updown_cell.py:231) */
+  const float* prior_mean;   /* optional (G, Z) ld Z: the caller's own prior mean instead of pm_scale * sentiment (_decode_step's
+                              * prior_mean argument, updown_captioner.py:371-381); ignored with kld_mode 2, whose cell replaces it */
+  const float* prior_var;    /* optional (G, Z) ld Z: the caller's own prior variance instead of cfg->prior_var */
 } ssc_decode_step_desc;
 /* 1 if a step of G rows in groups of `group` (0: group size not known yet - any divisor of G above 1 will do) over an image context of
  * nimg images with this att_table mode can take un-gathered states */
@@ -564,6 +579,7 @@ typedef struct {
   const float* sentiment;        /* (B) or NULL */
   const float* eps0;             /* (B, Z): noise of the first step */
   const float* eps;              /* (max_steps - 1, B*S*beam, Z): noise of the later steps */
+  const float* obj_atts;         /* cfg->kld_mode 2: (nimg, R, Z) per-region attribute means (ssc_decode_step_desc.obj_atts); else NULL */
   const uint8_t* fsm;            /* (M, S, S, V) dense machines; NULL with S = 1: the trivial machine */
   const void* tables;            /* ssc_fsm_compile of `fsm`, or NULL: dense scans */
   ssc_fsm_dims dims;             /* of `tables` */

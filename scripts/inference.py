@@ -65,14 +65,16 @@ def main():
     if _A.synthetic:
         vocabulary = Vocabulary.synthetic(_A.vocab_size)
         data = SyntheticCaptionData(_A.synthetic, _A.num_boxes, _C.MODEL.IMAGE_FEATURE_SIZE, _C.DATA.MAX_CAPTION_LENGTH,
-                                    _A.vocab_size, seed=4321)
+                                    _A.vocab_size, seed=4321,
+                                    obj_dim=_C.MODEL.Z_SPACE if (_C.MODEL.SENTIMENT_VAE == 2 and not _C.MODEL.SIMPLE_VAE) else 0)
     else:
         vocabulary = Vocabulary.from_files(_C.DATA.VOCABULARY)
         if not _A.infer_tensors:
             raise SystemExit("pass --infer-tensors file.pt or --synthetic N (h5 readers are out of scope)")
         data = TensorFileData(_A.infer_tensors)
     cls = _LocalGlove if (_C.MODEL.EMBEDDING_SIZE in (300, 600) and _A.checkpoint_path) else UpDownCaptioner
-    model = cls.from_config(_C, vocabulary=vocabulary, device=device).to(device)
+    extra = {"mean_choice": {}} if _C.MODEL.SENTIMENT_VAE == 2 else {}   # (per-region attribute MEANS come with the data: data.obj)
+    model = cls.from_config(_C, vocabulary=vocabulary, device=device, **extra).to(device)
     if _A.checkpoint_path:
         model.load_state_dict(torch.load(_A.checkpoint_path, map_location=device, weights_only=True)["model"])
     model.eval()
@@ -133,8 +135,10 @@ def main():
                 fsm = fsm.to(device)
                 ncons = torch.tensor([len(constraints.get(int(data.image_id[lo + i]), [])[:kmax]) for i in range(n_here)]
                                      ).repeat_interleave(n_z)
+            obj = data.obj[lo: lo + n_here, : feats.size(1)].to(device) if getattr(data, "obj", None) is not None else None
             pred, _ = diverse_decode(model._dec, feats, senti, n_z, beam, _C.DATA.MAX_CAPTION_LENGTH, boundary, fsm=fsm,
-                                     num_constraints=ncons, min_constraints_to_satisfy=_C.MODEL.MIN_CONSTRAINTS_TO_SATISFY)
+                                     num_constraints=ncons, min_constraints_to_satisfy=_C.MODEL.MIN_CONSTRAINTS_TO_SATISFY,
+                                     obj_means=obj)
             # ids -> words, cut at the first @@BOUNDARY@@ (inference.py:180-182): one table lookup for the whole chunk - the
             # per-token Python calls this replaces took as long as the chunk's 20 decode steps on the GPU
             ids = pred.cpu().numpy()                                   # (images, n_z, steps)

@@ -45,6 +45,9 @@ parser.add_argument("--eps-source", default="device", choices=["cpu", "device"],
                     help="cpu: the reference's CPU randn stream per step; device: GPU RNG, no host traffic")
 parser.add_argument("--zero-eps", action="store_true", help="testing: eps = 0 (deterministic z = mean)")
 parser.add_argument("--stop-after", type=int, default=0, help="testing: stop after this iteration (NUM_ITERATIONS keeps defining the schedule)")
+parser.add_argument("--attribute-table", default="",
+                    help="SENTIMENT_VAE 2: json {attribute word: [Z_SPACE floats]} - the table the reference builds from its sentiment-GloVe / "
+                         "SentiWordNet files (updown_captioner.py:79-93); only needed when obj_atts arrive as attribute strings")
 parser.add_argument("--fused-optimizer", action="store_true",
                     help="clip + SGD in one HIP pass on the flat buffers instead of torch.optim.SGD")
 
@@ -75,8 +78,9 @@ def main():
 
     if _A.synthetic:
         vocabulary = Vocabulary.synthetic(_A.vocab_size)
+        sv2 = _C.MODEL.SENTIMENT_VAE == 2 and not _C.MODEL.SIMPLE_VAE
         data = SyntheticCaptionData(_A.synthetic, _A.num_boxes, _C.MODEL.IMAGE_FEATURE_SIZE, _C.DATA.MAX_CAPTION_LENGTH,
-                                    _A.vocab_size, seed=1234)
+                                    _A.vocab_size, seed=1234, obj_dim=_C.MODEL.Z_SPACE if sv2 else 0)
     else:
         vocabulary = Vocabulary.from_files(_C.DATA.VOCABULARY)
         if not _A.train_tensors:
@@ -86,7 +90,12 @@ def main():
     if _C.OPTIM.BATCH_SIZE % world:
         raise SystemExit("OPTIM.BATCH_SIZE (global) must be divisible by the number of ranks")
 
-    model = UpDownCaptioner.from_config(_C, vocabulary=vocabulary, cbs_simple=_C.MODEL.CBS_SIMPLE, device=device).to(device)
+    extra = {}
+    if _C.MODEL.SENTIMENT_VAE == 2:
+        # the attribute table (word -> Z_SPACE floats) the reference reads from hard-coded pickle paths (updown_captioner.py:79-86).
+        # Needed only for obj_atts given as attribute STRINGS; the tensor files / the synthetic source carry the per-region means.
+        extra["mean_choice"] = {k: np.asarray(v) for k, v in json.load(open(_A.attribute_table)).items()} if _A.attribute_table else {}
+    model = UpDownCaptioner.from_config(_C, vocabulary=vocabulary, cbs_simple=_C.MODEL.CBS_SIMPLE, device=device, **extra).to(device)
     model.eps_source = _A.eps_source
     model.train()
     eng = model._engine()
@@ -134,12 +143,12 @@ def main():
             loss_b, kld_b = eng.train_step(batch["image_features"], batch["caption_tokens"], batch["sentiment"], eps, lr=lr,
                                            kld_weight=_C.MODEL.KLD_WEIGHT, momentum=_C.OPTIM.MOMENTUM,
                                            weight_decay=_C.OPTIM.WEIGHT_DECAY, max_norm=_C.OPTIM.CLIP_GRADIENTS,
-                                           decoder_frozen=not train_decoder)
+                                           decoder_frozen=not train_decoder, obj_atts=batch.get("obj_atts"))
             reconstr_loss, kld_loss = loss_b.mean(), kld_b.mean()
             loss = reconstr_loss + kld_loss / _C.MODEL.KLD_WEIGHT
         else:
             optimizer.zero_grad()
-            out = model(batch["image_features"], None, None, batch["caption_tokens"], batch["sentiment"])
+            out = model(batch["image_features"], batch.get("obj_atts"), None, batch["caption_tokens"], batch["sentiment"])
             reconstr_loss, kld_loss = out["loss"].mean(), out["kld"].mean()
             loss = reconstr_loss + kld_loss / _C.MODEL.KLD_WEIGHT
             for group in optimizer.param_groups:

@@ -220,7 +220,10 @@ __global__ __launch_bounds__(64) void attn_apply_kernel(const float* __restrict_
 __global__ void attn_pool_kernel(const float* __restrict__ alpha, const float* __restrict__ x, int G, int R, int D,
                                  int rows_per_image, float* __restrict__ out, int ldo) {
   const int g = blockIdx.y, d = blockIdx.x * blockDim.x + threadIdx.x;
-  if (d >= D) return;
+  if (d >= D) {   // the pad columns of a 16-byte padded row (ldo >= r4(D)) are zeroed: the row can then be a K-segment of r4(D) columns
+    if (d < ((D + 3) & ~3) && d < ldo) out[(size_t)g * ldo + d] = 0.f;
+    return;
+  }
   const float* xp = x + (size_t)(g / rows_per_image) * R * D + d;
   float acc = 0.f;
   for (int r = 0; r < R; ++r) acc += alpha[(size_t)g * R + r] * xp[(size_t)r * D];
@@ -233,7 +236,7 @@ __global__ void attn_pool_kernel(const float* __restrict__ alpha, const float* _
 __global__ __launch_bounds__(256) void attn_dalpha_kernel(const float* __restrict__ datt, int lddatt,
                                                           const float* __restrict__ feats, int G, int R, int F,
                                                           float* __restrict__ dalpha, const float* __restrict__ obj, int D,
-                                                          const float* __restrict__ dpa, int lddpa,
+                                                          const float* __restrict__ dpa, int lddpa, int Da,
                                                           const float* __restrict__ dpb, int lddpb) {
   int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
   int lane = threadIdx.x & 63;
@@ -253,7 +256,10 @@ __global__ __launch_bounds__(256) void attn_dalpha_kernel(const float* __restric
   }
   if (obj) {
     const float* op = obj + (size_t)wid * D;
-    for (int k = lane; k < D; k += 64) s += (dpa[(size_t)g * lddpa + k] + (dpb ? dpb[(size_t)g * lddpb + k] : 0.f)) * op[k];
+    // (dpa holds Da <= D columns: the conditioning block of the language LSTMs is the whole pooled vector - "glove" - or its
+    // first entry only - "senti_word_net", updown_cell.py:169-172)
+    for (int k = lane; k < D; k += 64)
+      s += ((k < Da ? dpa[(size_t)g * lddpa + k] : 0.f) + (dpb ? dpb[(size_t)g * lddpb + k] : 0.f)) * op[k];
   }
   s = ssc_wave_sum(s);
   if (lane == 0) dalpha[wid] = s;
@@ -402,7 +408,7 @@ extern "C" int ssc_attn_fwd_pool(const float* q, int ldq, const float* pv, const
 extern "C" int ssc_attn_pool(const float* alpha, const float* x, int G, int R, int D, int rows_per_image, float* out, int ldo,
                              void* stream) {
   if (!alpha || !x || !out || G <= 0 || R <= 0 || D <= 0 || rows_per_image <= 0 || ldo < D) return SSC_EINVAL;
-  SSC_LAUNCH(attn_pool_kernel, dim3(ssc_cdiv(D, 128), G), dim3(128), 0, (hipStream_t)stream, alpha, x, G, R, D, rows_per_image,
+  SSC_LAUNCH(attn_pool_kernel, dim3(ssc_cdiv((D + 3) & ~3, 128), G), dim3(128), 0, (hipStream_t)stream, alpha, x, G, R, D, rows_per_image,
              out, ldo);
   SSC_CHECK_LAUNCH();
   return SSC_OK;
@@ -429,18 +435,18 @@ extern "C" int ssc_attn_bwd(const float* datt, int lddatt, const float* q, int l
                             const float* alpha, const float* feats, int G, int R, int A, int F, float* dq, int lddq,
                             float* dpv_acc, float* dwa_acc, float* scratch_dalpha, void* stream) {
   return ssc_attn_bwd_pool(datt, lddatt, q, ldq, pv, wa, alpha, feats, G, R, A, F, dq, lddq, dpv_acc, dwa_acc, scratch_dalpha,
-                           nullptr, 0, nullptr, 0, nullptr, 0, stream);
+                           nullptr, 0, nullptr, 0, 0, nullptr, 0, stream);
 }
 
 extern "C" int ssc_attn_bwd_pool(const float* datt, int lddatt, const float* q, int ldq, const float* pv, const float* wa,
                                  const float* alpha, const float* feats, int G, int R, int A, int F, float* dq, int lddq,
                                  float* dpv_acc, float* dwa_acc, float* scratch_dalpha, const float* obj, int D,
-                                 const float* dpool_a, int lddpa, const float* dpool_b, int lddpb, void* stream) {
+                                 const float* dpool_a, int lddpa, int Da, const float* dpool_b, int lddpb, void* stream) {
   if (!datt || !q || !pv || !wa || !alpha || !feats || !dq || !dpv_acc || !dwa_acc || !scratch_dalpha) return SSC_EINVAL;
   if (G <= 0 || R <= 0 || A <= 0 || F <= 0 || R > 64 * MAXR_LANE || lddatt < F || ldq < A || lddq < A) return SSC_EINVAL;
-  if (obj && (!dpool_a || D <= 0 || lddpa < D || (dpool_b && lddpb < D))) return SSC_EINVAL;
+  if (obj && (!dpool_a || D <= 0 || Da < 0 || Da > D || lddpa < Da || (dpool_b && lddpb < D))) return SSC_EINVAL;
   SSC_LAUNCH(attn_dalpha_kernel, dim3(ssc_cdiv(G * R, 4)), dim3(256), 0, (hipStream_t)stream, datt, lddatt, feats,
-                     G, R, F, scratch_dalpha, obj, D, dpool_a, lddpa, dpool_b, lddpb);
+                     G, R, F, scratch_dalpha, obj, D, dpool_a, lddpa, Da, dpool_b, lddpb);
   SSC_CHECK_LAUNCH();
   SSC_LAUNCH(attn_bwd_apply_kernel, dim3(ssc_cdiv(A, 256), G), dim3(256), 0, (hipStream_t)stream, q, ldq, pv, wa,
                      alpha, scratch_dalpha, G, R, A, dq, lddq, dpv_acc, dwa_acc);

@@ -20,8 +20,8 @@ inline size_t r4(size_t x) { return (x + 3) & ~(size_t)3; }
 inline size_t r64(size_t x) { return (x + 63) & ~(size_t)63; }
 
 struct ImgLayout {
-  size_t mask, avg, pv, ga_avg, wsum_att, wsum_dec, wz, emb_gates, pd, scratch, scratch_floats, total;
-  int Fp, Hp, Zp;
+  size_t mask, avg, pv, ga_avg, wsum_att, wsum_dec, wz, wc, emb_gates, pd, scratch, scratch_floats, total;
+  int Fp, Hp, Zp, Sp;
   bool token_table;   // emb_gates holds the (V, 4H) table emb . W_ih^att[:, :E]^T
   bool att_table;     // pd holds P[img, r, :] = W_ih^dec[:, :F] v_{img,r} (nimg*R x 4H): the decoder gates' attended-feature term per region
 };
@@ -51,6 +51,9 @@ ImgLayout img_layout(const ssc_model_cfg* c, int nimg, int R) {
   l.wsum_att = o; o += r64((size_t)4 * c->H * l.Hp);
   l.wsum_dec = o; o += r64((size_t)4 * c->H * l.Hp);
   l.wz = o; o += r64((size_t)4 * c->H * l.Zp);
+  // SENTIMENT_VAE = 2 with the whole pooled attribute vector as conditioning (S = Z columns): their block of W_ih^dec, 16-byte rows
+  l.Sp = (int)r4(c->S);
+  l.wc = o; o += r64(c->kld_mode == 2 && c->S > 1 ? (size_t)4 * c->H * l.Sp : 0);
   l.token_table = nimg >= DEC_TOKEN_TABLE_MIN_IMAGES;
   l.emb_gates = o; o += r64(l.token_table ? (size_t)c->V * 4 * c->H : 0);
   // The attended-feature segment of the decoder gate product, att . W_ih^dec[:, :F]^T with att = sum_r alpha_r v_r, is linear in
@@ -67,7 +70,7 @@ ImgLayout img_layout(const ssc_model_cfg* c, int nimg, int R) {
 }
 
 struct StepLayout {
-  size_t emb, q, att, z, attn_logits, proj, wcol, slabs, slab_floats, total;
+  size_t emb, q, att, z, pm, c1, attn_logits, proj, wcol, slabs, slab_floats, total;
   size_t dedup;   // int32: [0] = number of distinct parents, [1] = number of live rows, [4 .. 4+G) = the parents' representative rows (ascending),
                   // [4+G .. 4+2G) = slot of every row, [4+2G ..) = previous-state row of every row, [4+3G ..) = live rows (ascending)
   int Ep, Ap, Fp, Zp;
@@ -80,6 +83,8 @@ StepLayout step_layout(const ssc_model_cfg* c, int G, int R) {
   l.q = o; o += r64((size_t)G * l.Ap);
   l.att = o; o += r64((size_t)G * l.Fp);
   l.z = o; o += r64((size_t)G * l.Zp);
+  l.pm = o; o += r64(c->kld_mode == 2 ? (size_t)G * l.Zp : 0);   // SENTIMENT_VAE = 2: the pooled prior mean of every row
+  l.c1 = o; o += r64(c->kld_mode == 2 ? (size_t)G : 0);           //   and its first entry (the one conditioning column of "senti_word_net")
   l.attn_logits = o; o += r64((size_t)G * R);
   l.proj = o; o += r64(c->tied ? (size_t)G * l.Ep : 0);
   l.wcol = o; o += r64((size_t)4 * c->H);
@@ -459,9 +464,18 @@ extern "C" int ssc_decode_prepare_from(const ssc_model_cfg* cfg, const ssc_param
     SSC_LAUNCH(dec_add2d_kernel, grid, dim3(256), 0, st, p->dec_w_ih + F + H, p->ld_dec_w_ih, p->dec_w_hh, p->ld_dec_w_hh, H,
                        W + l.wsum_dec, l.Hp);
     SSC_CHECK_LAUNCH();
+    // (zero pad columns: the z / conditioning K-segments of the decode step run over r4(Z) / r4(S) columns - a K that is no multiple
+    // of 4 would push its segment onto the 4 B/lane kernel, in a launch of its own)
+    if (l.Zp != Z && hipMemsetAsync(W + l.wz, 0, (size_t)H4 * l.Zp * sizeof(float), st) != hipSuccess) return SSC_EHIP;
     if (hipMemcpy2DAsync(W + l.wz, (size_t)l.Zp * sizeof(float), p->dec_w_ih + F + 2 * H + S, (size_t)p->ld_dec_w_ih * sizeof(float),
                          (size_t)Z * sizeof(float), H4, hipMemcpyDeviceToDevice, st) != hipSuccess)
       return SSC_EHIP;
+    if (cfg->kld_mode == 2 && S > 1) {
+      if (hipMemsetAsync(W + l.wc, 0, (size_t)H4 * l.Sp * sizeof(float), st) != hipSuccess) return SSC_EHIP;
+      if (hipMemcpy2DAsync(W + l.wc, (size_t)l.Sp * sizeof(float), p->dec_w_ih + F + 2 * H, (size_t)p->ld_dec_w_ih * sizeof(float),
+                           (size_t)S * sizeof(float), H4, hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return SSC_EHIP;
+    }
   }
   return SSC_OK;
 }
@@ -488,7 +502,9 @@ extern "C" int ssc_decode_step(const ssc_model_cfg* cfg, const ssc_params* p, co
   if (!d->feats || !d->imgbuf || !d->tokens || !d->eps || !d->h1 || !d->c1 || !d->hd || !d->cd || !d->h1_out ||
       !d->c1_out || !d->hd_out || !d->cd_out || !d->alpha)
     return SSC_EINVAL;
-  if ((cfg->S || cfg->pm_scale != 0.f) && !d->sentiment) return SSC_EINVAL;
+  const bool sv2 = cfg->kld_mode == 2;   // SENTIMENT_VAE = 2: prior mean and conditioning from the attention-pooled attribute means
+  if (sv2 ? (!d->obj_atts || (cfg->S != 1 && cfg->S != cfg->Z) || cfg->pm_scale != 0.f) : ((cfg->S || cfg->pm_scale != 0.f) && !d->sentiment))
+    return SSC_EINVAL;
   const int nimg = G / rpi;
   const ImgLayout il = img_layout(cfg, nimg, R);
   const StepLayout l = step_layout(cfg, G, R);
@@ -573,36 +589,49 @@ extern "C" int ssc_decode_step(const ssc_model_cfg* cfg, const ssc_params* p, co
     SSC_TRY(ssc_attn_fwd(W + l.q, l.Ap, I + il.pv, p->wa, I + il.mask, d->feats, G, R, A, F, rpi, W + l.attn_logits, d->alpha,
                          W + l.att, l.Fp, st));
   // z ~ N(prior_mean, prior_var) (updown_cell.py:200-208)
-  SSC_TRY(ssc_latent_prior_sample(d->eps, Z, cfg->pm_scale != 0.f ? d->sentiment : nullptr, cfg->pm_scale, cfg->prior_var,
-                                  G, Z, W + l.z, l.Zp, st));
+  if (sv2) {   // prior mean = sum_r alpha_r obj_atts_r (updown_cell.py:160-163)
+    SSC_TRY(ssc_attn_pool(d->alpha, d->obj_atts, G, R, Z, rpi, W + l.pm, l.Zp, st));
+    SSC_TRY(ssc_latent_prior_sample_pm(d->eps, Z, W + l.pm, l.Zp, d->prior_var, Z, nullptr, 0.f, cfg->prior_var, G, Z, W + l.z, l.Zp, st));
+    if (S == 1) SSC_TRY(ssc_copy_strided(W + l.pm, l.Zp, G, W + l.c1, st));   // c = prior_mean[:, 0] (updown_cell.py:171-172)
+    if (d->prior_mean_out && hipMemcpy2DAsync(d->prior_mean_out, (size_t)Z * sizeof(float), W + l.pm, (size_t)l.Zp * sizeof(float),
+                                              (size_t)Z * sizeof(float), G, hipMemcpyDeviceToDevice, st) != hipSuccess)
+      return SSC_EHIP;
+  } else if (d->prior_mean || d->prior_var) {   // the caller's own prior (updown_captioner.py:371-381)
+    SSC_TRY(ssc_latent_prior_sample_pm(d->eps, Z, d->prior_mean, Z, d->prior_var, Z, cfg->pm_scale != 0.f ? d->sentiment : nullptr,
+                                       cfg->pm_scale, cfg->prior_var, G, Z, W + l.z, l.Zp, st));
+  } else
+    SSC_TRY(ssc_latent_prior_sample(d->eps, Z, cfg->pm_scale != 0.f ? d->sentiment : nullptr, cfg->pm_scale, cfg->prior_var,
+                                    G, Z, W + l.z, l.Zp, st));
   // decoder LSTM (updown_cell.py:211-229)
   {
     int ns_u = 0;
+    const int KC = sv2 && S > 1 ? il.Sp : 0;   // conditioning block as a K-segment over its 16-byte padded width (a segment with K = 0 is dropped)
+    const Seg cseg{W + l.pm, l.Zp, I + il.wc, il.Sp, KC};
     if (att_table && dedup) {   // hd' segment on the distinct parents, [h1 | z] on every row
       SSC_TRY(gemm_slabs(st, slabs_u, l.slab_floats - (size_t)G * H4, {{d->hd, H, I + il.wsum_dec, il.Hp, H}}, G, H4, &ns_u, ucount, urows));
       if (ns_u != 1) return SSC_EINVAL;
       if (live) {
-        SSC_TRY(gemm_live({{d->h1_out, H, p->dec_w_ih + F, p->ld_dec_w_ih, H}, {W + l.z, l.Zp, I + il.wz, il.Zp, Z}}, H4, slabs, H4, nullptr));
+        SSC_TRY(gemm_live({{d->h1_out, H, p->dec_w_ih + F, p->ld_dec_w_ih, H}, {W + l.z, l.Zp, I + il.wz, il.Zp, l.Zp}, cseg}, H4, slabs, H4, nullptr));
         ns = 1;
       } else
-        SSC_TRY(gemm_slabs(st, slabs, (size_t)G * H4, {{d->h1_out, H, p->dec_w_ih + F, p->ld_dec_w_ih, H}, {W + l.z, l.Zp, I + il.wz, il.Zp, Z}},
+        SSC_TRY(gemm_slabs(st, slabs, (size_t)G * H4, {{d->h1_out, H, p->dec_w_ih + F, p->ld_dec_w_ih, H}, {W + l.z, l.Zp, I + il.wz, il.Zp, l.Zp}, cseg},
                            G, H4, &ns));
     } else if (att_table)   // the attended-feature segment comes from the per-image table inside the cell kernel
       SSC_TRY(gemm_slabs(st, slabs, l.slab_floats,
                          {{d->h1_out, H, p->dec_w_ih + F, p->ld_dec_w_ih, H}, {d->hd, H, I + il.wsum_dec, il.Hp, H},
-                          {W + l.z, l.Zp, I + il.wz, il.Zp, Z}}, G, H4, &ns));
+                          {W + l.z, l.Zp, I + il.wz, il.Zp, l.Zp}, cseg}, G, H4, &ns));
     else
       SSC_TRY(gemm_slabs(st, slabs, l.slab_floats,
                          {{W + l.att, l.Fp, p->dec_w_ih, p->ld_dec_w_ih, F}, {d->h1_out, H, p->dec_w_ih + F, p->ld_dec_w_ih, H},
-                          {d->hd, H, I + il.wsum_dec, il.Hp, H}, {W + l.z, l.Zp, I + il.wz, il.Zp, Z}}, G, H4, &ns));
+                          {d->hd, H, I + il.wsum_dec, il.Hp, H}, {W + l.z, l.Zp, I + il.wz, il.Zp, l.Zp}, cseg}, G, H4, &ns));
     ssc_lstm_fwd_desc f{};
     f.B = G; f.H = H;
     f.slabs = slabs; f.nslab = ns; f.slab_stride = (size_t)G * H4;
     if (ns_u) { f.slabs2 = slabs_u; f.nslab2 = ns_u; f.slab2_stride = (size_t)G * H4; f.slab2_rows = slot; }
     f.b_ih = p->dec_b_ih; f.b_hh = p->dec_b_hh;
-    if (S) {
+    if (S == 1) {   // one conditioning column: the sentiment (SENTIMENT_VAE = 1) or the pooled prior mean's first entry (2, "senti_word_net")
       SSC_TRY(ssc_copy_strided(p->dec_w_ih + F + 2 * H, p->ld_dec_w_ih, H4, W + l.wcol, st));
-      f.sent = d->sentiment; f.wcol = W + l.wcol; f.ldwcol = 1;
+      f.sent = sv2 ? W + l.c1 : d->sentiment; f.wcol = W + l.wcol; f.ldwcol = 1;
     }
     f.c_prev = d->cd; f.ld_cprev = H; f.c_prev_rows = prow;
     f.c_out = d->cd_out; f.ld_cout = H; f.h_out = d->hd_out; f.ld_hout = H;

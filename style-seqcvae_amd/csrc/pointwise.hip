@@ -854,9 +854,28 @@ __global__ void latent_prior_sample_kernel(const float* __restrict__ eps, int ld
                                            float pm_scale, float sd, int G, int Z, float* __restrict__ z, int ldz) {
   int g = blockIdx.y;
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= Z) return;
+  if (i >= Z) {   // pad columns of a 16-byte padded row are zeroed (the row is a K-segment of r4(Z) columns in the decode step)
+    if (i < ((Z + 3) & ~3) && i < ldz) z[(size_t)g * ldz + i] = 0.f;
+    return;
+  }
   float pm = sent ? pm_scale * sent[g] : 0.f;
   z[(size_t)g * ldz + i] = eps[(size_t)g * ldeps + i] * sd + pm;
+}
+
+// the same with a per-row, per-dimension prior mean (SENTIMENT_VAE = 2: the attention-pooled attribute means, updown_cell.py:160-163)
+// ... and, optionally, a per-element prior variance (a caller of _decode_step that hands its own prior, updown_captioner.py:371-381)
+__global__ void latent_prior_sample_pm_kernel(const float* __restrict__ eps, int ldeps, const float* __restrict__ pm, int ldpm,
+                                              const float* __restrict__ pv, int ldpv, const float* __restrict__ sent, float pm_scale,
+                                              float sd, int G, int Z, float* __restrict__ z, int ldz) {
+  int g = blockIdx.y;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Z) {
+    if (i < ((Z + 3) & ~3) && i < ldz) z[(size_t)g * ldz + i] = 0.f;
+    return;
+  }
+  const float m = pm ? pm[(size_t)g * ldpm + i] : (sent ? pm_scale * sent[g] : 0.f);
+  const float s = pv ? sqrtf(pv[(size_t)g * ldpv + i]) : sd;
+  z[(size_t)g * ldz + i] = eps[(size_t)g * ldeps + i] * s + m;
 }
 
 // latent_fwd_kernel for MANY partial slabs (the cdiv(H,16) partial products of lstm_fwd_p_kernel): one 256-thread workgroup per
@@ -1354,8 +1373,18 @@ extern "C" int ssc_latent_fwd(const ssc_latent_fwd_desc* d, void* stream) {
 extern "C" int ssc_latent_prior_sample(const float* eps, int ldeps, const float* sent, float pm_scale, float prior_var,
                                        int G, int Z, float* z, int ldz, void* stream) {
   if (!eps || !z || G <= 0 || Z <= 0) return SSC_EINVAL;
-  SSC_LAUNCH(latent_prior_sample_kernel, dim3(ssc_cdiv(Z, 64), G), dim3(64), 0, S(stream), eps, ldeps, sent,
+  SSC_LAUNCH(latent_prior_sample_kernel, dim3(ssc_cdiv((Z + 3) & ~3, 64), G), dim3(64), 0, S(stream), eps, ldeps, sent,
                      pm_scale, sqrtf(prior_var), G, Z, z, ldz);
+  SSC_CHECK_LAUNCH();
+  return SSC_OK;
+}
+
+extern "C" int ssc_latent_prior_sample_pm(const float* eps, int ldeps, const float* pm, int ldpm, const float* pv, int ldpv,
+                                          const float* sent, float pm_scale, float prior_var, int G, int Z, float* z, int ldz,
+                                          void* stream) {
+  if (!eps || !z || G <= 0 || Z <= 0 || ldeps < Z || (pm && ldpm < Z) || (pv && ldpv < Z) || ldz < Z) return SSC_EINVAL;
+  SSC_LAUNCH(latent_prior_sample_pm_kernel, dim3(ssc_cdiv((Z + 3) & ~3, 64), G), dim3(64), 0, S(stream), eps, ldeps, pm, ldpm, pv, ldpv, sent,
+             pm_scale, sqrtf(prior_var), G, Z, z, ldz);
   SSC_CHECK_LAUNCH();
   return SSC_OK;
 }

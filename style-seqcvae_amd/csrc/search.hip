@@ -63,7 +63,7 @@ bool desc_ok(const ssc_model_cfg* cfg, const ssc_search_desc* d) {
   if (!d->feats || !d->imgbuf || !d->eps0 || (d->max_steps > 1 && !d->eps) || !d->predictions || !d->log_probs || !d->ctl) return false;
   if (d->S > 1 && !d->fsm) return false;
   if (d->skip_dead && !d->tables) return false;
-  if ((cfg->S || cfg->pm_scale != 0.f) && !d->sentiment) return false;
+  if (cfg->kld_mode == 2 ? !d->obj_atts : ((cfg->S || cfg->pm_scale != 0.f) && !d->sentiment)) return false;
   return true;
 }
 
@@ -126,6 +126,7 @@ extern "C" int ssc_decode_search(const ssc_model_cfg* cfg, const ssc_params* p, 
   bool table_ready = false;
   ssc_decode_step_desc sd{};
   sd.R = d->R; sd.feats = d->feats; sd.imgbuf = d->imgbuf; sd.alpha = alpha; sd.log_probs = logits; sd.raw_logits = 1;
+  sd.obj_atts = d->obj_atts;
   // ---- first step: one row per batch entry (cbs.py:127) ------------------------------------------------------------------
   sd.G = B; sd.rows_per_image = d->n_samples; sd.tokens = tokens0; sd.sentiment = d->sentiment; sd.eps = d->eps0;
   sd.h1 = stt[1][0]; sd.c1 = stt[1][1]; sd.hd = stt[1][2]; sd.cd = stt[1][3];

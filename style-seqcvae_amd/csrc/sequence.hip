@@ -26,7 +26,9 @@ struct Layout {
   int B, R, L, T;
   int V, E, H, A, F, Z, S, tied;
   int Ep, Hp, Ap, Fp, Zp, Vp, H4, XW;  // padded leading dims ; XW = ld of dx = [datt | dh1 | dhd' | (dc)]
-  int D, Dp, NX;   // D: width of the attention-pooled conditioning c (kld_mode 2: SENTIMENT_VAE = 2, D = S), else 0; NX = columns of dx
+  int D, Dp, SC, NX;   // D: width of the attention-pooled prior mean (kld_mode 2: SENTIMENT_VAE = 2, D = Z), else 0; SC: how many of its
+                       // leading entries condition the language LSTMs (= S: all D with LATENT_EMBEDDING "glove", 1 with "senti_word_net",
+                       // updown_cell.py:169-172); NX = columns of dx
   size_t wc_e, wc_d, pool, dpm;   // D > 0: 16-byte aligned zero-padded copies of the c-blocks of W_ih^enc / W_ih^dec (H4 x Dp), the pooled c of every step (T*B x Dp), the KL term's gradient on the prior mean (B x Dp)
   size_t total = 0;                    // floats
   size_t act;   // int32: [0] = number of (t, b) rows with a real target (w = 1), [4 ...] = their row numbers t*B+b, ascending
@@ -52,11 +54,11 @@ Layout make_layout(const ssc_model_cfg* c, int B, int R, int L) {
   l.V = c->V; l.E = c->E; l.H = c->H; l.A = c->A; l.F = c->F; l.Z = c->Z; l.S = c->S; l.tied = c->tied;
   l.Ep = (int)r4(l.E); l.Hp = (int)r4(l.H); l.Ap = (int)r4(l.A); l.Fp = (int)r4(l.F); l.Zp = (int)r4(l.Z);
   l.Vp = (int)r4(l.V); l.H4 = 4 * l.H;
-  l.D = c->kld_mode == 2 ? c->S : 0; l.Dp = (int)r4(l.D);
+  l.D = c->kld_mode == 2 ? c->Z : 0; l.Dp = (int)r4(l.D); l.SC = l.D ? c->S : 0;
   // with a pooled conditioning block the input-gradient products of the language LSTMs run over the c-block columns too (they
   // follow the hd' block in W_ih^enc / W_ih^dec), rounded up to 16-byte rows: the row padding of W_ih^enc / columns of the
   // z-block of W_ih^dec, whose products land in pad columns of dx that nobody reads
-  l.NX = l.D ? (int)r4(l.F + 2 * l.H + l.D) : l.F + 2 * l.H;
+  l.NX = l.D ? (int)r4(l.F + 2 * l.H + l.SC) : l.F + 2 * l.H;
   l.XW = (int)r4(l.NX);
   const size_t T = l.T, TB = T * B, T1B = (T + 1) * (size_t)B;
   l.tok = l.take(2 * (size_t)(L + 2) * B);
@@ -313,7 +315,7 @@ int add2d(const float* a, int lda, const float* b, int ldb, int rows, int cols, 
 struct ViewArgs {
   const float *att_ih, *att_hh, *dec_ih, *dec_hh, *dec_z, *enc_s, *dec_s;   // row-n bases: [n * ld + column offset]
   int ld_att_ih, ld_att_hh, ld_dec_ih, ld_dec_hh, ld_enc_ih;
-  int H, Hp, Z, Zp, S, D, Dp;
+  int H, Hp, Z, Zp, S, D, Dp, SC;
   float *wsum_att, *wsum_dec, *wz, *wcol_e, *wcol_d, *wc_e, *wc_d;
 };
 __global__ void weight_views_kernel(const ViewArgs a) {
@@ -325,13 +327,13 @@ __global__ void weight_views_kernel(const ViewArgs a) {
   // (pad columns Z..Zp-1 are zero: the backward multiplies with all Zp columns so that the product keeps 16-byte rows when Z is
   // no multiple of 4 - the reference's shipped Z_SPACE is 150)
   for (int k = tid; k < a.Zp; k += blockDim.x) a.wz[(size_t)n * a.Zp + k] = k < a.Z ? a.dec_z[(size_t)n * a.ld_dec_ih + k] : 0.f;
-  if (a.S == 1 && tid == 0) {
+  if (a.S == 1 && !a.D && tid == 0) {
     a.wcol_e[n] = a.enc_s[(size_t)n * a.ld_enc_ih];
     a.wcol_d[n] = a.dec_s[(size_t)n * a.ld_dec_ih];
   }
   for (int k = tid; k < a.Dp; k += blockDim.x) {   // SENTIMENT_VAE = 2: the 150 conditioning columns, zero-padded to 16-byte rows
-    a.wc_e[(size_t)n * a.Dp + k] = k < a.D ? a.enc_s[(size_t)n * a.ld_enc_ih + k] : 0.f;
-    a.wc_d[(size_t)n * a.Dp + k] = k < a.D ? a.dec_s[(size_t)n * a.ld_dec_ih + k] : 0.f;
+    a.wc_e[(size_t)n * a.Dp + k] = k < a.SC ? a.enc_s[(size_t)n * a.ld_enc_ih + k] : 0.f;
+    a.wc_d[(size_t)n * a.Dp + k] = k < a.SC ? a.dec_s[(size_t)n * a.ld_dec_ih + k] : 0.f;
   }
 }
 int prepare_weight_views(const Layout& l, const ssc_params* p, float* W, hipStream_t st) {
@@ -341,7 +343,7 @@ int prepare_weight_views(const Layout& l, const ssc_params* p, float* W, hipStre
   a.dec_z = p->dec_w_ih + F + 2 * H + S; a.enc_s = p->enc_w_ih + F + 2 * H; a.dec_s = p->dec_w_ih + F + 2 * H;
   a.ld_att_ih = p->ld_att_w_ih; a.ld_att_hh = p->ld_att_w_hh; a.ld_dec_ih = p->ld_dec_w_ih; a.ld_dec_hh = p->ld_dec_w_hh;
   a.ld_enc_ih = p->ld_enc_w_ih;
-  a.H = H; a.Hp = l.Hp; a.Z = l.Z; a.Zp = l.Zp; a.S = S; a.D = l.D; a.Dp = l.Dp;
+  a.H = H; a.Hp = l.Hp; a.Z = l.Z; a.Zp = l.Zp; a.S = S; a.D = l.D; a.Dp = l.Dp; a.SC = l.SC;
   a.wc_e = W + l.wc_e; a.wc_d = W + l.wc_d;
   a.wsum_att = W + l.wsum_att; a.wsum_dec = W + l.wsum_dec; a.wz = W + l.wz; a.wcol_e = W + l.wcol_e; a.wcol_d = W + l.wcol_d;
   SSC_LAUNCH(weight_views_kernel, dim3(l.H4), dim3(256), 0, st, a);
@@ -373,10 +375,11 @@ int check_cfg(const ssc_model_cfg* c, const ssc_params* p, const ssc_batch* b) {
   if (!c || !p || !b) return SSC_EINVAL;
   if (c->V <= 1 || c->E <= 0 || c->H <= 0 || c->A <= 0 || c->F <= 0 || c->Z <= 0) return SSC_EINVAL;
   if (c->kld_mode < 0 || c->kld_mode > 2) return SSC_EINVAL;
-  if (c->kld_mode == 2 ? (c->S < 2 || c->S != c->Z || !b || !b->obj_atts) : (c->S != 0 && c->S != 1)) return SSC_EINVAL;
+  // kld_mode 2 (SENTIMENT_VAE = 2): the conditioning block is the whole pooled attribute vector (S = Z) or its first entry (S = 1)
+  if (c->kld_mode == 2 ? ((c->S != 1 && c->S != c->Z) || c->pm_scale != 0.f || !b->obj_atts) : (c->S != 0 && c->S != 1)) return SSC_EINVAL;
   if (b->B <= 0 || b->R <= 0 || b->L <= 0 || b->R > 256) return SSC_EINVAL;
   if (!b->feats || !b->caps || !b->eps) return SSC_EINVAL;
-  if ((c->S == 1 || c->pm_scale != 0.f) && !b->sentiment) return SSC_EINVAL;
+  if (((c->S == 1 && c->kld_mode != 2) || c->pm_scale != 0.f) && !b->sentiment) return SSC_EINVAL;
   if (!p->emb || !p->att_w_ih || !p->att_w_hh || !p->att_b_ih || !p->att_b_hh || !p->wq || !p->wv || !p->wa ||
       !p->enc_w_ih || !p->enc_w_hh || !p->enc_b_ih || !p->enc_b_hh || !p->dec_w_ih || !p->dec_w_hh || !p->dec_b_ih ||
       !p->dec_b_hh || !p->fc_mean_w || !p->fc_mean_b || !p->fc_lv_w || !p->fc_lv_b)
@@ -564,7 +567,7 @@ extern "C" int ssc_train_fwd(const ssc_model_cfg* cfg, const ssc_params* p, cons
       d.B = B; d.H = H;
       d.slabs = W + l.sl_ge; d.nslab = n_ge_r + n_ge_a; d.slab_stride = sG;
       d.b_ih = p->enc_b_ih; d.b_hh = p->enc_b_hh;
-      if (S == 1) { d.sent = bt->sentiment; d.wcol = W + l.wcol_e; d.ldwcol = 1; }
+      if (S == 1 && !l.D) { d.sent = bt->sentiment; d.wcol = W + l.wcol_e; d.ldwcol = 1; }
       d.c_prev = cep; d.ld_cprev = l.Hp;
       d.gates_out = W + l.gates_e + (size_t)t * B * H4;
       d.c_out = cen; d.ld_cout = l.Hp; d.h_out = hen; d.ld_hout = l.Hp;
@@ -603,7 +606,7 @@ extern "C" int ssc_train_fwd(const ssc_model_cfg* cfg, const ssc_params* p, cons
       d.B = B; d.H = H;
       d.slabs = W + l.sl_gd; d.nslab = n_gd_r + n_gd_a; d.slab_stride = sG;
       d.b_ih = p->dec_b_ih; d.b_hh = p->dec_b_hh;
-      if (S == 1) { d.sent = bt->sentiment; d.wcol = W + l.wcol_d; d.ldwcol = 1; }
+      if (S == 1 && !l.D) { d.sent = bt->sentiment; d.wcol = W + l.wcol_d; d.ldwcol = 1; }
       d.c_prev = cdp; d.ld_cprev = l.Hp;
       d.gates_out = W + l.gates_d + (size_t)t * B * H4;
       d.c_out = cdn; d.ld_cout = l.Hp; d.h_out = hdn; d.ld_hout = l.Hp;
@@ -854,7 +857,7 @@ static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const s
     //    KL term's gradient on the prior mean)
     SSC_TRY(ssc_attn_bwd_pool(dx, XW, W + l.q + (size_t)t * B * l.Ap, l.Ap, W + l.pv, p->wa, W + l.alpha + (size_t)t * B * R,
                               bt->feats, B, R, A, F, dq, l.Ap, W + l.dpv, W + l.dwa, W + l.dalpha, l.D ? bt->obj_atts : nullptr, l.D,
-                              dx + F + 2 * H, XW, W + l.dpm, l.Dp, st));
+                              dx + F + 2 * H, XW, l.SC, W + l.dpm, l.Dp, st));
     // 8-9. attention LSTM: dh1 = dx[h1 block] + g_h1' slabs + dq Wq; the K = A product is formed inside the cell kernel
     //      (ssc_lstm_bwd_x) while its LDS images fit, else it is a split-K product of its own
     {
@@ -894,7 +897,7 @@ static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const s
 
   if (g_loop.on) { (void)hipEventRecord(g_loop.e[3], st); g_loop.bwd = true; }
 
-  if (S == 1) {  // sentiment replicated over time (row = t*B+b) for the rank-1 column gradients
+  if (S == 1 && !l.D) {  // sentiment replicated over time (row = t*B+b) for the rank-1 column gradients
     SSC_LAUNCH(repeat_kernel, dim3(ssc_cdiv(TB, 256)), dim3(256), 0, st, bt->sentiment, B, T, W + l.sent_all);
     SSC_CHECK_LAUNCH();
   }
@@ -980,9 +983,9 @@ static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const s
   // encoder LSTM
   if (g->enc_w_ih) {
     float* gw = g->enc_w_ih; int ld = g->ld_enc_w_ih;
-    if (S == 1) SSC_TRY(ssc_colsum2(dge, H4, TB, H4, W + l.sent_all, gw + F + 2 * H, ld, nullptr, 0, c.slabs, st));
+    if (S == 1 && !l.D) SSC_TRY(ssc_colsum2(dge, H4, TB, H4, W + l.sent_all, gw + F + 2 * H, ld, nullptr, 0, c.slabs, st));
     if (l.D && hipMemcpy2DAsync(gw + F + 2 * H, (size_t)ld * sizeof(float), W + l.wc_e, (size_t)l.Dp * sizeof(float),
-                                (size_t)l.D * sizeof(float), H4, hipMemcpyDeviceToDevice, st) != hipSuccess)
+                                (size_t)l.SC * sizeof(float), H4, hipMemcpyDeviceToDevice, st) != hipSuccess)
       return SSC_EHIP;
   }
   if (g->enc_b_ih && g->enc_b_hh) {
@@ -1025,9 +1028,9 @@ static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const s
   }
   if (g->dec_w_ih) {
     float* gw = g->dec_w_ih; int ld = g->ld_dec_w_ih;
-    if (S == 1) SSC_TRY(ssc_colsum2(dgd, H4, TB, H4, W + l.sent_all, gw + F + 2 * H, ld, nullptr, 0, c.slabs, st));
+    if (S == 1 && !l.D) SSC_TRY(ssc_colsum2(dgd, H4, TB, H4, W + l.sent_all, gw + F + 2 * H, ld, nullptr, 0, c.slabs, st));
     if (l.D && hipMemcpy2DAsync(gw + F + 2 * H, (size_t)ld * sizeof(float), W + l.wc_d, (size_t)l.Dp * sizeof(float),
-                                (size_t)l.D * sizeof(float), H4, hipMemcpyDeviceToDevice, st) != hipSuccess)
+                                (size_t)l.SC * sizeof(float), H4, hipMemcpyDeviceToDevice, st) != hipSuccess)
       return SSC_EHIP;
   }
   if (g->dec_w_hh) {

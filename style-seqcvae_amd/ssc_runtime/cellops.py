@@ -44,8 +44,8 @@ def cell_train_step(dims: ModelDims, P: Dict[str, torch.Tensor], feats: torch.Te
                     states: Optional[Dict[str, torch.Tensor]], sentiment: Optional[torch.Tensor], eps: torch.Tensor,
                     obj_atts: Optional[torch.Tensor] = None, training: bool = True, prior_mean: Optional[torch.Tensor] = None,
                     prior_var: Optional[torch.Tensor] = None):
-    """One UpDownCell step through the op-level C ABI -> (h_decoder, states, mean, log_var, alpha, cond) with cond = the
-    attention-pooled attribute means (G,S) when S > 1, else None.
+    """One UpDownCell step through the op-level C ABI -> (h_decoder, states, mean, log_var, alpha, pooled) with pooled = the
+    attention-pooled attribute means (G,Z) when obj_atts is given (SENTIMENT_VAE = 2), else None.
     feats (G,R,F), emb (G,E), sentiment (G,) or None, eps (G,Z).
     dims.S selects the conditioning of the language LSTMs (updown_cell.py:47-81): 0 none, 1 the sentiment column,
     > 1 (SENTIMENT_VAE = 2: 150) the attention-pooled attribute means c = sum_r alpha_r obj_atts_r (updown_cell.py:160-163),
@@ -82,12 +82,19 @@ def cell_train_step(dims: ModelDims, P: Dict[str, torch.Tensor], feats: torch.Te
     sent = sentiment.reshape(G).contiguous().float() if (sentiment is not None and (S == 1 or dims.pm_scale != 0.0)) else None
     hd_prev = st["h_decoder"]
     cond = None      # (G, S) conditioning block of the language LSTMs when S > 1
-    if S > 1:
-        if obj_atts is None:
-            raise ValueError("SENTIMENT_VAE = 2 needs obj_atts (G, R, %d): per-region attribute means" % S)
+    pooled = None    # (G, Z) attention-pooled attribute means: the prior mean of SENTIMENT_VAE = 2
+    if S > 1 and obj_atts is None:
+        raise ValueError("SENTIMENT_VAE = 2 needs obj_atts (G, R, %d): per-region attribute means" % S)
+    if obj_atts is not None:
         oa = obj_atts.to(dev, torch.float32).contiguous()
-        cond = torch.empty(G, S, **f32)
-        lib.ssc_attn_pool(L.ptr(alpha), L.ptr(oa), G, R, S, 1, L.ptr(cond), S, L.stream_ptr())
+        assert tuple(oa.shape) == (G, R, Z), (oa.shape, (G, R, Z))
+        pooled = torch.empty(G, Z, **f32)
+        lib.ssc_attn_pool(L.ptr(alpha), L.ptr(oa), G, R, Z, 1, L.ptr(pooled), Z, L.stream_ptr())
+        if S > 1:        # LATENT_EMBEDDING "glove": the whole vector conditions the language LSTMs (S = Z = 150)
+            assert S == Z
+            cond = pooled
+        elif S == 1:     # "senti_word_net": its first entry does (updown_cell.py:171-172)
+            sent = pooled[:, 0].contiguous()
     csegs_e = csegs_d = []
     w_e, w_ehh = P[P_ENC + "weight_ih"], P[P_ENC + "weight_hh"]
     lde, be = w_e.stride(0), w_e.data_ptr()
@@ -98,8 +105,8 @@ def cell_train_step(dims: ModelDims, P: Dict[str, torch.Tensor], feats: torch.Te
         # eval (updown_cell.py:200-208): the encoder LSTM is skipped, mean / var are the prior's.  A per-row VECTOR prior mean
         # (SENTIMENT_VAE = 2, or one handed in) is applied with two elementwise torch ops - this stand-alone step is the
         # module-level API, not the hot path (the fused decode step handles the scalar priors of modes 0 / 1).
-        pm = cond if cond is not None else (prior_mean.to(dev, torch.float32) if prior_mean is not None
-                                            else torch.zeros(G, Z, **f32))
+        pm = pooled if pooled is not None else (prior_mean.to(dev, torch.float32) if prior_mean is not None
+                                                else torch.zeros(G, Z, **f32))
         pv = prior_var.to(dev, torch.float32) if prior_var is not None else torch.full((G, Z), float(dims.prior_var), **f32)
         mu, lv = pm, pv.log()
         z = (eps * pv.sqrt() + pm).contiguous()
@@ -137,4 +144,4 @@ def cell_train_step(dims: ModelDims, P: Dict[str, torch.Tensor], feats: torch.Te
     hd, cd = _lstm(lib, pre, P[P_DEC + "bias_ih"], P[P_DEC + "bias_hh"], st["c_decoder"], sent if S == 1 else None,
                    bd + 4 * (F + 2 * H), ldd)
     new = {"h1": h1, "c1": c1, "h_encoder": he, "c_encoder": ce, "h_decoder": hd, "c_decoder": cd}
-    return hd, new, mu, lv, alpha, cond
+    return hd, new, mu, lv, alpha, pooled

@@ -58,7 +58,9 @@ def tokens_to_ids(vocabulary, caption_words: Sequence[str]) -> List[int]:
 class SyntheticCaptionData:
     """feats ~ N(0,1); caption lengths ~ U{8..L}, ids ~ U{2..V-1}, 0-padded; sentiment ~ U{-1,0,1}."""
 
-    def __init__(self, num_images: int, R: int, F: int, L: int, V: int, seed: int = 1234):
+    def __init__(self, num_images: int, R: int, F: int, L: int, V: int, seed: int = 1234, obj_dim: int = 0):
+        """obj_dim > 0 (SENTIMENT_VAE = 2): also per-region attribute means `obj` (N, R, obj_dim) ~ 0.3 N(0,1), what
+        UpDownCaptioner.translate_obj_atts2obj_means would produce from detector attributes."""
         g = torch.Generator().manual_seed(seed)
         self.feats = torch.randn(num_images, R, F, generator=g)
         lens = torch.randint(min(8, L), L + 1, (num_images,), generator=g)
@@ -66,6 +68,7 @@ class SyntheticCaptionData:
         self.caps = torch.where(torch.arange(L).unsqueeze(0) < lens.unsqueeze(1), ids, torch.zeros_like(ids))
         self.senti = torch.randint(-1, 2, (num_images, 1), generator=g).float()
         self.image_id = torch.arange(num_images)
+        self.obj = torch.randn(num_images, R, obj_dim, generator=g) * 0.3 if obj_dim > 0 else None
 
     def __len__(self):
         return self.feats.size(0)
@@ -74,7 +77,8 @@ class SyntheticCaptionData:
 class TensorFileData:
     """A .pt file (loaded weights_only) with `caption_tokens` (N,L) int64, optional `sentiment` (N,1) / `image_id` (N,), and the
     region features either dense - `image_features` (N,R,F) - or ragged like the reference's h5 file - `features`
-    (sum n_i, F) f32 + `num_boxes` (N,) - in which case every batch is zero-padded to ITS largest region count."""
+    (sum n_i, F) f32 + `num_boxes` (N,) - in which case every batch is zero-padded to ITS largest region count.
+    Optional `obj_atts` (N, max boxes, Z) f32: per-region attribute means for SENTIMENT_VAE = 2 (zero rows past an image's regions)."""
 
     def __init__(self, path: str):
         d = torch.load(path, map_location="cpu", weights_only=True)
@@ -82,6 +86,7 @@ class TensorFileData:
         n = self.caps.size(0)
         self.senti = d.get("sentiment", torch.zeros(n, 1)).float().view(-1, 1)
         self.image_id = d.get("image_id", torch.arange(n))
+        self.obj = d["obj_atts"].float() if "obj_atts" in d else None
         if "image_features" in d:
             self.feats = d["image_features"].float()
             self.ragged = None
@@ -142,6 +147,11 @@ class PrefetchLoader:
                            caption_tokens=torch.empty(batch_size, L, dtype=torch.long).pin_memory(),
                            sentiment=torch.empty(batch_size, 1).pin_memory(),
                            image_id=torch.empty(batch_size, dtype=torch.long).pin_memory(), R=R) for _ in range(self.depth)]
+        self._obj = getattr(data, "obj", None)
+        if self._obj is not None:   # SENTIMENT_VAE = 2: per-region attribute means travel with the features
+            assert self._obj.size(0) == n and self._obj.size(1) == R, (self._obj.shape, n, R)
+            for h in self._host:
+                h["obj_atts"] = torch.empty(batch_size, R, self._obj.size(2)).pin_memory()
         self._dev = [{k: torch.empty_like(v, device=self.device) for k, v in h.items() if k != "R"} for h in self._host]
         self._filled = [threading.Semaphore(0) for _ in range(self.depth)]
         self._free = [threading.Semaphore(1) for _ in range(self.depth)]
@@ -197,6 +207,13 @@ class PrefetchLoader:
             np.take(d.caps.numpy(), ii, axis=0, out=h["caption_tokens"].numpy())
             np.take(d.senti.numpy(), ii, axis=0, out=h["sentiment"].numpy())
             np.take(d.image_id.numpy(), ii, axis=0, out=h["image_id"].numpy())
+            if self._obj is not None:   # the same dense (B, R, Z) block layout as the features (R = this batch's region count)
+                ho = h["obj_atts"].numpy()
+                Rb, Zo = h["R"], ho.shape[2]
+                hv = ho.reshape(-1)[: len(idx) * Rb * Zo].reshape(len(idx), Rb, Zo)
+                so = self._obj.numpy()
+                for i, r in enumerate(idx):
+                    np.copyto(hv[i], so[r, :Rb])
             self._filled[j].release()
             k += 1
             j = (j + 1) % self.depth
@@ -216,9 +233,9 @@ class PrefetchLoader:
             # includes every kernel that read it: depth >= 2 and this upload is issued one batch ahead, see __next__) must
             # finish before it is overwritten.
             self._stream.wait_stream(torch.cuda.current_stream(self.device))
-            for key in ("image_features", "caption_tokens", "sentiment", "image_id"):
+            for key in ("image_features", "caption_tokens", "sentiment", "image_id") + (("obj_atts",) if self._obj is not None else ()):
                 src, dst = h[key], dv[key]
-                if key == "image_features" and R != dst.size(1):
+                if key in ("image_features", "obj_atts") and R != dst.size(1):
                     # ragged batch narrower than the staging buffer: the producer packed it as a dense (B, R, F) block at the
                     # head of the pinned buffer; the same view of the device buffer receives it in one contiguous async copy
                     B_, F_ = dst.size(0), dst.size(2)

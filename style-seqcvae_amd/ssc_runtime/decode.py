@@ -17,9 +17,10 @@ STATE_KEYS = ("h1", "c1", "h_encoder", "c_encoder", "h_decoder", "c_decoder")
 class ImageContext:
     """Per-image terms computed once per image set (mask, avg, pv, hoisted gate term): ssc_decode_prepare."""
 
-    def __init__(self, feats: torch.Tensor, buf: torch.Tensor):
+    def __init__(self, feats: torch.Tensor, buf: torch.Tensor, obj: Optional[torch.Tensor] = None):
         self.feats = feats
         self.buf = buf
+        self.obj = obj   # SENTIMENT_VAE = 2: per-region attribute means (nimg, R, Z) of these images (updown_cell.py:160-163)
         self.nimg, self.R, _ = feats.shape
         self.att_table_ready = False   # the per-image attended-feature table is formed by the first step that uses it
 
@@ -41,10 +42,18 @@ class DecodeEngine:
         self._last_ctx = None
         self._sws = None   # workspace of search()
 
-    def prepare(self, feats: torch.Tensor) -> ImageContext:
+    def prepare(self, feats: torch.Tensor, obj_means: Optional[torch.Tensor] = None) -> ImageContext:
+        """obj_means (nimg, R, Z): the per-region attribute means of SENTIMENT_VAE = 2 (kld_mode 2), else None."""
         assert feats.is_cuda and feats.dtype == torch.float32 and feats.dim() == 3 and feats.size(2) == self.dims.F
         feats = feats.contiguous()
         nimg, R, _ = feats.shape
+        if self.dims.kld_mode == 2:
+            if obj_means is None or tuple(obj_means.shape) != (nimg, R, self.dims.Z):
+                raise ValueError(f"SENTIMENT_VAE = 2 needs the per-region attribute means obj_atts ({nimg}, {R}, {self.dims.Z}), got "
+                                 f"{None if obj_means is None else tuple(obj_means.shape)}")
+            obj_means = obj_means.to(self.device, torch.float32).contiguous()
+        else:
+            obj_means = None
         nbytes = self.lib.ssc_decode_image_bytes(C.byref(self._cfg), nimg, R)
         buf = torch.empty(nbytes // 4 + 64, dtype=torch.float32, device=self.device)
         p = self._params()
@@ -52,7 +61,7 @@ class DecodeEngine:
         self.lib.ssc_decode_prepare_from(C.byref(self._cfg), C.byref(p), _lib.ptr(feats), nimg, R, _lib.ptr(buf), buf.numel() * 4,
                                          _lib.ptr(prev.buf) if prev is not None else None, prev.nimg if prev is not None else 0,
                                          prev.R if prev is not None else 0, _lib.stream_ptr())
-        ctx = ImageContext(feats, buf)
+        ctx = ImageContext(feats, buf, obj_means)
         # (kept alive by this reference: the copy above is stream-ordered before anything that could overwrite the old buffer)
         self._last_ctx = ctx if self.weights_frozen else None
         return ctx
@@ -79,12 +88,15 @@ class DecodeEngine:
 
     def step(self, ctx: ImageContext, tokens: torch.Tensor, states: Optional[Dict[str, torch.Tensor]],
              sentiment: Optional[torch.Tensor], eps: torch.Tensor, want_log_probs: bool = True,
-             emb_table: Optional[torch.Tensor] = None, raw_logits: bool = False
+             emb_table: Optional[torch.Tensor] = None, raw_logits: bool = False, prior_mean_out: Optional[torch.Tensor] = None,
+             prior_mean: Optional[torch.Tensor] = None, prior_var: Optional[torch.Tensor] = None
              ) -> Tuple[Optional[torch.Tensor], Dict[str, torch.Tensor], torch.Tensor]:
         """One eval decode step for G rows (row g -> image g // (G / nimg)).  Returns (log_probs (G,V) or None,
         new states, alpha (G,R)).  h_encoder / c_encoder are carried through untouched (updown_cell.py:176-203).
         raw_logits: return the un-normalised vocabulary logits instead (for cbs_search(raw_logits=True), which takes the
-        log-sum-exp inside its selection kernel: one pass over the (G,V) matrix less per step)."""
+        log-sum-exp inside its selection kernel: one pass over the (G,V) matrix less per step).
+        prior_mean_out (G, Z), SENTIMENT_VAE = 2 only: receives the step's pooled prior mean (what the cell returns, updown_cell.py:231).
+        prior_mean / prior_var (G, Z): the caller's own prior instead of the one the configuration implies."""
         d = self.dims
         G = tokens.numel()
         assert G % ctx.nimg == 0, (G, ctx.nimg)
@@ -113,6 +125,10 @@ class DecodeEngine:
         new = {k: torch.empty_like(st[k]) for k in ("h1", "c1", "h_decoder", "c_decoder")}
         alpha = torch.empty(G, ctx.R, dtype=torch.float32, device=self.device)
         lp = torch.empty(G, d.V, dtype=torch.float32, device=self.device) if want_log_probs else None
+        pm_in = prior_mean.to(self.device, torch.float32).contiguous() if prior_mean is not None else None
+        pv_in = prior_var.to(self.device, torch.float32).contiguous() if prior_var is not None else None
+        assert pm_in is None or tuple(pm_in.shape) == (G, d.Z)
+        assert pv_in is None or tuple(pv_in.shape) == (G, d.Z)
         att_table = self._att_table_mode(ctx, G, rpi)
         has_parent = parent is not None and parent.numel() == G
         group = parent.shape[-1] if has_parent else 0
@@ -127,7 +143,10 @@ class DecodeEngine:
                                    lp.data_ptr() if lp is not None else None, 1 if raw_logits else 0,
                                    1 if emb_table is not None else 0,
                                    parent.data_ptr() if has_parent else None, group, att_table, 1 if ungathered else 0,
-                                   skip[0].data_ptr() if skip is not None else None, int(skip[1]) if skip is not None else 0)
+                                   skip[0].data_ptr() if skip is not None else None, int(skip[1]) if skip is not None else 0,
+                                   ctx.obj.data_ptr() if ctx.obj is not None else None,
+                                   prior_mean_out.data_ptr() if (prior_mean_out is not None and ctx.obj is not None) else None,
+                                   _lib.ptr(pm_in), _lib.ptr(pv_in))
         p = self._params()
         if emb_table is not None:  # rows of `emb_table` are the token embeddings themselves (UpDownCell.forward API)
             p.emb = emb_table.data_ptr()
@@ -175,6 +194,7 @@ class DecodeEngine:
             eps = eps.to(dev, torch.float32).contiguous()
             assert tuple(eps.shape) == (max_steps - 1, G, d.Z), (eps.shape, (max_steps - 1, G, d.Z))
         sd.sentiment, sd.eps0, sd.eps = _lib.ptr(sent), _lib.ptr(eps0), _lib.ptr(eps) if max_steps > 1 else None
+        sd.obj_atts = _lib.ptr(ctx.obj)
         mach = mach.to(dev, torch.int32).contiguous() if mach is not None else None
         sd.fsm, sd.mach = _lib.ptr(fsm), _lib.ptr(mach)
         if compiled is not None:
@@ -202,11 +222,12 @@ class DecodeEngine:
             _HOST_FLAGS.append(flag)
         return pred[:, :, :nsteps].contiguous().view(B, S, beam, nsteps), lps
 
-    def _step_from_embedding(self, ctx, token_embedding, states, sentiment, eps):
+    def _step_from_embedding(self, ctx, token_embedding, states, sentiment, eps, prior_mean_out=None, prior_mean=None, prior_var=None):
         G = token_embedding.size(0)
         table = token_embedding.to(self.device, torch.float32).contiguous()
         ids = torch.arange(G, dtype=torch.int64, device=self.device)
-        return self.step(ctx, ids, states, sentiment, eps, want_log_probs=False, emb_table=table)
+        return self.step(ctx, ids, states, sentiment, eps, want_log_probs=False, emb_table=table, prior_mean_out=prior_mean_out,
+                         prior_mean=prior_mean, prior_var=prior_var)
 
 
 DecodeEngine.step_from_embedding = DecodeEngine._step_from_embedding

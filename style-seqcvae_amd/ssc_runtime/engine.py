@@ -56,8 +56,9 @@ class ModelDims:
     A: int
     F: int
     Z: int
-    S: int = 0            # conditioning columns on the language LSTMs (updown_cell.py:47-81): 0, 1 (sentiment) or, with kld_mode 2,
-                          # 150 (SENTIMENT_VAE = 2: attention-pooled attribute means; Z must equal S)
+    S: int = 0            # conditioning columns on the language LSTMs (updown_cell.py:47-81): 0, 1 (sentiment) or, with kld_mode 2
+                          # (SENTIMENT_VAE = 2: attention-pooled attribute means, Z wide), Z (LATENT_EMBEDDING "glove": all of them) or
+                          # 1 ("senti_word_net": the first one, updown_cell.py:169-172)
     tied: bool = False    # E in {300,600}: frozen tied embedding (updown_captioner.py:75,112-119)
     kld_mode: int = 0     # 0: SENTIMENT_VAE == 0 formula, 1 otherwise (updown_captioner.py:298-303), 2: formula 1 with the prior
                           # mean of each step = the attention-pooled obj_atts (SENTIMENT_VAE = 2, updown_cell.py:160-163)
@@ -249,7 +250,7 @@ class TrainEngine:
         if sentiment is not None:
             sent = sentiment.reshape(B).to(torch.float32).contiguous()
         if self.dims.kld_mode == 2:
-            assert obj_atts is not None and tuple(obj_atts.shape) == (B, R, self.dims.S), "SENTIMENT_VAE = 2 needs obj_atts (B,R,S)"
+            assert obj_atts is not None and tuple(obj_atts.shape) == (B, R, self.dims.Z), "SENTIMENT_VAE = 2 needs obj_atts (B,R,Z)"
             obj_atts = obj_atts.to(torch.float32).contiguous()
         else:
             obj_atts = None

@@ -21,7 +21,7 @@ def diverse_decode(dec: DecodeEngine, feats: torch.Tensor, sentiment: Optional[t
                    max_steps: int, boundary_index: int, fsm: Optional[torch.Tensor] = None,
                    num_constraints: Optional[torch.Tensor] = None, min_constraints_to_satisfy: int = 0,
                    eps_steps: Optional[List[torch.Tensor]] = None, early_stop: bool = True, per_node: Optional[int] = None,
-                   skip_dead: bool = True, compiled=None):
+                   skip_dead: bool = True, compiled=None, obj_means: Optional[torch.Tensor] = None):
     """feats (nimg,R,F), sentiment (nimg,) or None -> predictions (nimg, n_samples, steps) int64 on device.
     fsm: None (trivial one-state machine, what MAX_GIVEN_CONSTRAINTS: 0 produces), or (nimg, S, S, V) uint8 - ONE machine per
     image, shared by its n_samples latent samples through an index list -, or (nimg*n_samples, S, S, V) (a copy per sample).
@@ -31,12 +31,13 @@ def diverse_decode(dec: DecodeEngine, feats: torch.Tensor, sentiment: Optional[t
     every state before its first constraint word has been decoded - and rows whose beam has ended are neither stepped nor scored from
     logits (cbs_search(skip_dead=True)).  Every caption with a finite log-prob is the exact search's; should a selected caption
     have none (its constraints were not reachable within max_steps), the call is repeated exactly, with the same noise.
-    compiled: the machines' CompiledFsm when the caller has it already."""
+    compiled: the machines' CompiledFsm when the caller has it already.
+    obj_means (nimg, R, Z): per-region attribute means, SENTIMENT_VAE = 2 only (UpDownCaptioner.translate_obj_atts2obj_means)."""
     dev = feats.device
     nimg = feats.size(0)
     d = dec.dims
     B = nimg * n_samples
-    ctx = dec.prepare(feats)
+    ctx = dec.prepare(feats, obj_means)
     trivial = fsm is None   # one-state machine: cbs_search(fsm=None) reads no mask at all
     if trivial:
         num_constraints = torch.zeros(B, dtype=torch.long)

@@ -108,7 +108,7 @@ class DecodeStepDesc(C.Structure):
                 ("tokens", vp), ("sentiment", vp), ("eps", vp), ("h1", vp), ("c1", vp), ("hd", vp), ("cd", vp),
                 ("h1_out", vp), ("c1_out", vp), ("hd_out", vp), ("cd_out", vp), ("alpha", vp), ("log_probs", vp),
                 ("raw_logits", C.c_int), ("emb_override", C.c_int), ("parent", vp), ("group", C.c_int), ("att_table", C.c_int),
-                ("ungathered", C.c_int), ("row_lp", vp), ("end_index", C.c_int)]
+                ("ungathered", C.c_int), ("row_lp", vp), ("end_index", C.c_int), ("obj_atts", vp), ("prior_mean_out", vp), ("prior_mean", vp), ("prior_var", vp)]
 
 
 class FsmDims(C.Structure):
@@ -126,7 +126,7 @@ class BeamDesc(C.Structure):
 class SearchDesc(C.Structure):
     _fields_ = [("nimg", C.c_int), ("R", C.c_int), ("n_samples", C.c_int), ("S", C.c_int), ("beam", C.c_int), ("per_node", C.c_int),
                 ("max_steps", C.c_int), ("end_index", C.c_int), ("feats", vp), ("imgbuf", vp), ("sentiment", vp), ("eps0", vp),
-                ("eps", vp), ("fsm", vp), ("tables", vp), ("dims", FsmDims), ("mach", vp), ("skip_dead", C.c_int),
+                ("eps", vp), ("obj_atts", vp), ("fsm", vp), ("tables", vp), ("dims", FsmDims), ("mach", vp), ("skip_dead", C.c_int),
                 ("early_stop", C.c_int), ("predictions", vp), ("log_probs", vp), ("ctl", vp), ("host_flag", vp),
                 ("host_flag_host", vp)]
 
@@ -155,10 +155,11 @@ SYMBOLS = {
     "ssc_attn_weights": (_i, [vp, _i, vp, vp, vp, _i, _i, _i, _i, vp, vp, vp]),
     "ssc_attn_pool": (_i, [vp, vp, _i, _i, _i, _i, vp, _i, vp]),
     "ssc_attn_fwd_pool": (_i, [vp, _i, vp, vp, vp, vp, _i, _i, _i, _i, _i, vp, vp, vp, _i, vp, _i, vp, _i, vp]),
-    "ssc_attn_bwd_pool": (_i, [vp, _i, vp, _i, vp, vp, vp, vp, _i, _i, _i, _i, vp, _i, vp, vp, vp, vp, _i, vp, _i, vp, _i, vp]),
+    "ssc_attn_bwd_pool": (_i, [vp, _i, vp, _i, vp, vp, vp, vp, _i, _i, _i, _i, vp, _i, vp, vp, vp, vp, _i, vp, _i, _i, vp, _i, vp]),
     "ssc_attn_bwd": (_i, [vp, _i, vp, _i, vp, vp, vp, vp, _i, _i, _i, _i, vp, _i, vp, vp, vp, vp]),
     "ssc_latent_fwd": (_i, [C.POINTER(LatentFwdDesc), vp]),
     "ssc_latent_prior_sample": (_i, [vp, _i, vp, _f, _f, _i, _i, vp, _i, vp]),
+    "ssc_latent_prior_sample_pm": (_i, [vp, _i, vp, _i, vp, _i, vp, _f, _f, _i, _i, vp, _i, vp]),
     "ssc_latent_bwd": (_i, [C.POINTER(LatentBwdDesc), vp]),
     "ssc_ce_fwd": (_i, [vp, _i, vp, vp, vp, _i, _i, _i, vp, vp, vp]),
     "ssc_ce_bwd": (_i, [vp, _i, vp, vp, vp, vp, vp, _i, _i, _i, vp]),

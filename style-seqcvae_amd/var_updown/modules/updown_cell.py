@@ -52,7 +52,7 @@ class UpDownCell(nn.Module):
         (updown_cell.py:231).  Runs the HIP decode step without autograd; the differentiable training path is the
         fused sequence kernel behind UpDownCaptioner.forward.  `eps` (G,Z) may be injected; default: CPU
         torch.randn as in updown_cell.py:206."""
-        if self._host is not None and self.senti_cols <= 1:
+        if self._host is not None and (self.sentiment_vae != 2 or self.simple_vae):
             return self._host._cell_forward(image_features, token_embedding, states, training, sentiment, prior_mean,
                                             prior_var, eps)
         return self._standalone_forward(image_features, obj_atts, token_embedding, states, training, sentiment, prior_mean,
@@ -80,12 +80,13 @@ class UpDownCell(nn.Module):
             eps = torch.randn(G, Z)          # CPU generator, as updown_cell.py:206
         if self.latent_embedding not in ("glove", "senti_word_net"):
             raise NotImplementedError()
-        sent = sentiment.reshape(G) if (sentiment is not None and self.senti_cols == 1) else None
-        if self.senti_cols == 1 and self.latent_embedding == "senti_word_net" and self.sentiment_vae != 1:
-            sent = prior_mean[:, 0]          # c = prior_mean[:, 0] (updown_cell.py:171-172); the cat uses `sentiment` only for mode 1
+        sv2 = self.sentiment_vae == 2 and not self.simple_vae
+        # the one conditioning column is `sentiment` in mode 1; in mode 2 with "senti_word_net" it is the pooled prior mean's first
+        # entry (updown_cell.py:160-163,171-172), which cell_train_step derives from obj_atts
+        sent = sentiment.reshape(G) if (sentiment is not None and self.senti_cols == 1 and self.sentiment_vae == 1) else None
         pm_in = None if prior_mean is None else (torch.zeros_like(prior_mean) if self.simple_vae else prior_mean)
         h_dec, new_states, mean, log_var, alpha, cond = cell_train_step(
-            dims, P, image_features.to(dev), token_embedding.to(dev), states, sent, eps, obj_atts=obj_atts, training=training,
+            dims, P, image_features.to(dev), token_embedding.to(dev), states, sent, eps, obj_atts=obj_atts if sv2 else None, training=training,
             prior_mean=pm_in, prior_var=prior_var)
         pm = cond if cond is not None else (pm_in.to(dev) if pm_in is not None else torch.zeros(G, Z, device=dev))
         if self.simple_vae:

@@ -785,10 +785,138 @@ def sv2_train_fixture(name="g14_train_sv2"):
     print(name, "loss", loss.detach().numpy(), "kld", kld.detach().numpy())
 
 
+def sv2_module_fixture(UpDownCaptioner, name="g16_sv2_module"):
+    """SENTIMENT_VAE = 2 above the kernel level, three parts:
+
+    translate/*: the reference's own ``UpDownCaptioner.translate_obj_atts2obj_means`` (updown_captioner.py:509-532) run UNMODIFIED
+      on an instance made without ``__init__`` (the constructor cannot run in this mode: it reads /path/to/*.pkl, :79), with the
+      four attributes the method reads set by hand.  Tables: the reference's own data/wordform_swd_scores.json through the
+      SentiWordNet rule of :83-86 (score[0] - score[2], z_space times), and a seeded 10-d table through the repeat rule of :79-81.
+    eval_<latent>/*: the reference ``UpDownCell`` (updown_cell.py:86-231, training=False) for LATENT_EMBEDDING "glove" (150
+      conditioning columns = the pooled attribute means) and "senti_word_net" (one column = their first entry, :171-172), driven
+      through four eval decode steps from zero states inside a thin restatement of the captioner's eval ``_decode_step``
+      (:371-455: embedding, cell, output layer, log-softmax) with plain torch modules; rows = 3 images x 4 beams (the images'
+      obj_atts repeated per row, which is what the reference's broadcast does at batch size 1).
+    train_swn/*: the training fixture of g14 (the reference cell under autograd inside the captioner's training branch) for
+      LATENT_EMBEDDING "senti_word_net" (Z = 16)."""
+    import json
+    from var_updown.modules import UpDownCell
+    data = {}
+    # ---- translate ---------------------------------------------------------------------------------------------------------
+    swn = json.load(open(os.path.join(REF, "data", "wordform_swd_scores.json")))
+    words = sorted(swn)[:40] + ["standing", "sitting", "white", "black", "wooden"]
+    swn = {w: swn[w] for w in words if w in swn}
+    g = torch.Generator().manual_seed(5)
+    tab10 = {w: torch.randn(10, generator=g).numpy().astype(np.float64) for w in list(swn)[:30]}
+    obj_atts = [
+        [["person", ["standing 0.9", "white 0.4", "not-in-table 0.8"]], ["dog", []], ["table", ["wooden 0.7"]]],
+        [["cat", ["zzz 0.9"]], ["car", ["black 0.5", "white 0.5", "standing 0.2"]]],
+        [["tree", [list(swn)[3] + " 0.3", list(swn)[7] + " 0.6"]], ["sky", [list(swn)[11]]], ["road", ["sitting 1.0"]], ["x", []]],
+    ]
+    for tag, Z, table, multip in (("swn", 16, {k: np.repeat(v[0] - v[2], 16) for k, v in swn.items()}, 1.0),
+                                  ("glove", 150, {k: np.repeat(v, int(150 / 10)) for k, v in tab10.items()}, 0.5)):
+        inst = object.__new__(UpDownCaptioner)
+        inst.__dict__.update(mean_choice=table, z_space=Z, latent_embedding_multip=multip, device=torch.device("cpu"))
+        out = UpDownCaptioner.translate_obj_atts2obj_means(inst, obj_atts)
+        data[f"translate/{tag}/out"] = out.numpy()
+        data[f"translate/{tag}/table_keys"] = np.array(json.dumps(sorted(table)))
+        data[f"translate/{tag}/table_vals"] = np.stack([table[k] for k in sorted(table)])
+        data[f"translate/{tag}/multip"] = np.array(multip)
+    data["translate/obj_atts"] = np.array(json.dumps(obj_atts))
+    data["translate/swn_scores"] = np.array(json.dumps(swn))
+    data["translate/tab10_keys"] = np.array(json.dumps(sorted(tab10)))
+    data["translate/tab10_vals"] = np.stack([tab10[k] for k in sorted(tab10)])
+    # ---- eval decode steps ------------------------------------------------------------------------------------------------
+    V, E, H, A, F, R, nimg, rpi, steps = 90, 40, 48, 32, 64, 5, 3, 4, 4
+    for latent, Z in (("glove", 150), ("senti_word_net", 16)):
+        torch.manual_seed(21)
+        emb = torch.nn.Embedding(V, E, padding_idx=0)
+        cell = UpDownCell(F, E, H, A, Z, 2, False, torch.device("cpu"), latent)
+        out = torch.nn.Linear(H, V)
+        g = torch.Generator().manual_seed(60 + Z)
+        feats = torch.randn(nimg, R, F, generator=g)
+        feats[1, R - 2:] = 0
+        obj = torch.randn(nimg, R, Z, generator=g) * 0.4
+        obj[1, R - 2:] = 0
+        obj[2, 0] = 0
+        G = nimg * rpi
+        rows = torch.arange(G) // rpi                                  # batch-major rows, as the image features are repeated (:405-413)
+        prior_var = (torch.ones(G, Z) * 0.8).pow(2)
+        tag = "eval_" + latent
+        for k, v in cell.state_dict().items():
+            data[f"{tag}/param/_updown_cell.{k}"] = v.numpy().copy()
+        data[f"{tag}/param/_embedding_layer.weight"] = emb.weight.detach().numpy().copy()
+        data[f"{tag}/param/_output_layer.weight"] = out.weight.detach().numpy().copy()
+        data[f"{tag}/param/_output_layer.bias"] = out.bias.detach().numpy().copy()
+        data[f"{tag}/in/feats"], data[f"{tag}/in/obj_atts"] = feats.numpy(), obj.numpy()
+        states = None
+        with torch.no_grad():
+            for t in range(steps):
+                tok = torch.randint(1, V, (G,), generator=g)
+                eps = torch.randn(G, Z, generator=g)
+                with EpsInjector([eps]):
+                    hd, states, mean, log_var, pm, plv, alpha = cell(feats[rows].clone(), obj[rows].clone(), emb(tok), states, False, None,
+                                                                     None, torch.zeros(G, Z), prior_var.clone())
+                lp = torch.log_softmax(out(hd), dim=1)
+                data[f"{tag}/step{t}/tok"], data[f"{tag}/step{t}/eps"] = tok.numpy(), eps.numpy()
+                data[f"{tag}/step{t}/log_probs"], data[f"{tag}/step{t}/alpha"] = lp.numpy(), alpha.numpy()
+                data[f"{tag}/step{t}/prior_mean"], data[f"{tag}/step{t}/prior_log_var"] = pm.numpy(), plv.numpy()
+                for k in ("h1", "c1", "h_decoder", "c_decoder"):
+                    data[f"{tag}/step{t}/state/{k}"] = states[k].numpy().copy()
+        print(name, tag, "lp[0,:3]", lp[0, :3].numpy())
+    # ---- training, senti_word_net --------------------------------------------------------------------------------------------
+    V, E, H, A, F, Z, L, B, R = 120, 40, 48, 32, 64, 16, 6, 4, 5
+    T = L + 1
+    torch.manual_seed(12)
+    emb = torch.nn.Embedding(V, E, padding_idx=0)
+    cell = UpDownCell(F, E, H, A, Z, 2, False, torch.device("cpu"), "senti_word_net")
+    out = torch.nn.Linear(H, V)
+    feats, caps, senti, eps = make_inputs(2025, B, R, F, L, V, Z, T, unk=True)
+    g = torch.Generator().manual_seed(78)
+    obj = torch.randn(B, R, Z, generator=g) * 0.4
+    obj[1, R - 2:] = 0
+    obj[2, 1] = 0
+    tokens, _ = oracle.add_sentence_boundary_token_ids(caps, caps != 0, 1, 1)
+    mask = tokens != 0
+    prior_mean = torch.zeros(B, Z)
+    prior_var = (torch.ones(B, Z) * 0.9).pow(2)
+    states, logits, klds = None, [], []
+    with EpsInjector([eps[t] for t in range(T)]):
+        for t in range(T):
+            hd, states, mean, log_var, prior_mean, prior_log_var, alpha = cell(
+                feats if t else feats.clone(), obj, emb(tokens[:, t]), states, True, None, None, prior_mean, prior_var)
+            kld = 1 + log_var - prior_log_var - ((mean - prior_mean).pow(2) + log_var.exp()) / (prior_var + 0.00001)
+            klds.append((-0.5 * kld.sum(1)).unsqueeze(1))
+            logits.append(out(hd).unsqueeze(1))
+    logits = torch.cat(logits, 1)
+    tmask = mask[:, 1:].contiguous()
+    klds = torch.cat(klds, 1) * tmask.float()
+    loss = tmask.sum(-1).float() * oracle.sequence_cross_entropy_with_logits(logits, tokens[:, 1:].contiguous(), tmask)
+    kld = klds.sum(1)
+    (loss.mean() + kld.mean() / 750.0).backward()
+    tag = "train_swn"
+    data.update({f"{tag}/param/_embedding_layer.weight": emb.weight.detach().numpy().copy(),
+                 f"{tag}/param/_output_layer.weight": out.weight.detach().numpy().copy(),
+                 f"{tag}/param/_output_layer.bias": out.bias.detach().numpy().copy(),
+                 f"{tag}/grad/_embedding_layer.weight": emb.weight.grad.numpy().copy(),
+                 f"{tag}/grad/_output_layer.weight": out.weight.grad.numpy().copy(),
+                 f"{tag}/grad/_output_layer.bias": out.bias.grad.numpy().copy()})
+    for k, v in cell.state_dict().items():
+        data[f"{tag}/param/_updown_cell." + k] = v.numpy().copy()
+    for n, p in cell.named_parameters():
+        data[f"{tag}/grad/_updown_cell." + n] = p.grad.numpy().copy()
+    data.update({f"{tag}/in/feats": feats.numpy(), f"{tag}/in/caps": caps.numpy(), f"{tag}/in/eps": eps.numpy(),
+                 f"{tag}/in/obj_atts": obj.numpy(), f"{tag}/out/loss": loss.detach().numpy(), f"{tag}/out/kld": kld.detach().numpy()})
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **data)
+    print(name, "train_swn loss", loss.detach().numpy(), "kld", kld.detach().numpy())
+
+
 def main():
     UpDownCaptioner = import_reference()
     if "--only-sv2" in sys.argv:
         return sv2_train_fixture()
+    if "--only-sv2-module" in sys.argv:
+        return sv2_module_fixture(UpDownCaptioner)
     if "--only-decode-large" in sys.argv:
         return decode_large_fixture(UpDownCaptioner)
     filter_fixture()
@@ -800,6 +928,7 @@ def main():
         return
     cell_fixture()
     sv2_train_fixture()
+    sv2_module_fixture(UpDownCaptioner)
     if "--full" in sys.argv or not os.path.exists(os.path.join(HERE, "g10_full_c2.npz")):
         full_size_fixture(UpDownCaptioner, "g10_full_c1", B=4, unk=False)      # BASELINE configs[0]: batch 4
         full_size_fixture(UpDownCaptioner, "g10_full_c2", B=64, unk=True)      # BASELINE configs[1]: batch 64, with in-caption UNK
