@@ -434,6 +434,68 @@ def _dense_decode(dec, feats, senti, n_z, beam, L_, fsm, ncons, kmax):
     return best.view(nimg, n_z, -1), calls["k"]
 
 
+def measure_c5_train(device, steps=5, warmup=2):
+    """BASELINE.json configs[4] (C5, the stress shape) as a driver-timed train step on ONE GPU: B = 128, R = 100 regions, L = 40
+    (T = 41), V = 30000, E / H / A = 1000 / 1200 / 768, Z = 128, SENTIMENT_VAE 1.  From 128 rows on the gate products are bound by
+    the bf16 matrix pipe (3xBF16: six passes per fp32 product), not by HBM: `roofline` is that of the per-timestep gate products
+    (M = 128 against 4H = 4800 columns, wave-specialised 128x128 kernels), from a hipEvent pair around every GEMM launch of one
+    further forward + backward."""
+    from ssc_runtime import lib as L
+    from ssc_runtime.vocab import Vocabulary
+    from var_updown.models import UpDownCaptioner
+    lib = L.load()
+    c = dict(C5)
+    torch.manual_seed(2)
+    model = UpDownCaptioner(Vocabulary.synthetic(c["V"]), image_feature_size=c["F"], embedding_size=c["E"], hidden_size=c["H"],
+                            attention_projection_size=c["A"], max_caption_length=c["L"], beam_size=5, z_space=c["Z"], prior_std=1.0,
+                            simple_vae=False, latent_embedding="glove", sentiment_vae=1, senti_prior_multip=0.5, device=device).to(device)
+    eng = model._engine()
+    batches = [synth_batch(555 + i, c["B"], c["R"], c["F"], c["L"], c["V"], c["Z"], device) for i in range(2)]
+    T = c["L"] + 1
+
+    def step(i):
+        feats, caps, senti, _ = batches[i % 2]
+        eps = torch.randn(T, c["B"], c["Z"], device=device)
+        eng.train_step(feats, caps, senti, eps, lr=0.015, kld_weight=750.0, momentum=0.9, weight_decay=0.001, max_norm=12.5,
+                       decoder_frozen=False)
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warmup + i)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    B = c["B"]
+    lib.ssc_prof_enable(1)
+    feats, caps, senti, eps = batches[0]
+    eng.forward(feats, caps, senti, eps)
+    torch.cuda.synchronize()
+    eng.backward(torch.full((B,), 1.0 / B, device=device), torch.full((B,), 1.0 / (B * 750.0), device=device))
+    buf = torch.zeros(4096 * 8, dtype=torch.float32)
+    n = lib.ssc_prof_collect(buf.data_ptr(), 4096)
+    lib.ssc_prof_enable(0)
+    rec = buf[: n * 8].view(n, 8).tolist()
+    gate = [r for r in rec if int(r[1]) == B]      # the per-timestep minibatch products (forward x W^T and backward dG W)
+    roof = None
+    if gate:
+        ms = sum(r[5] for r in gate)
+        fl = sum(r[7] for r in gate)
+        by = sum(r[6] for r in gate)
+        tf6 = 6.0 * fl / (ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "per-timestep gate products at M = 128 (gemm_x3w_kernel<128x128>, grouped; 6 bf16 MFMA passes "
+                "per fp32 product)", "achieved": tf6, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": tf6 / MFMA_BF16_PEAK_TF,
+                "traffic": None, "launches": len(gate), "avg_launch_us": ms / len(gate) * 1e3,
+                "algorithmic_GBps": by / (ms * 1e-3) / 1e9, "share_of_gemm_time": ms / sum(r[5] for r in rec)}
+    del model, eng
+    torch.cuda.empty_cache()
+    return {"metric": "captions/sec (train step)", "value": B * steps / el, "unit": "captions/s", "steps": steps, "warmup": warmup,
+            "ms_per_step": el / steps * 1e3, "dtype": "f32",
+            "config": {"workload": "C5 train step on one GPU: fwd+bwd+clip+SGD, B=128, R=100, F=2048, L=40 (T=41), Z=128, V=30000, "
+                                   "E=1000, H=1200, A=768, SENTIMENT_VAE=1"},
+            "roofline": roof}
+
+
 def bench_decode(args, model, eng, c, rank, world, device):
     import torch.distributed as dist
     if args.mode == "decode-cbs":
@@ -748,7 +810,30 @@ def main():
     if rank == 0 and dres is not None:
         result["decode_tokens_per_s"] = dres["value"]
         result["decode"] = {k: dres[k] for k in ("metric", "value", "unit", "steps", "ms_per_step", "config", "roofline", "captions_per_s",
-                                                 "row_steps_per_s", "early_stop_disabled")}
+                                                 "row_steps_per_s", "early_stop_disabled", "passes")}
+    if rank == 0 and result is not None and not args.timed_only:
+        result["dtype_detail"] = ("fp32 operands and results; products of 16-byte aligned operands via a 3 x bf16 split of every fp32 "
+                                  "operand on the bf16 matrix cores (six partial products of order <= 2, fp32 accumulate: error ~ one "
+                                  "fp32 rounding per product), everything else exact fp32; exact_fp32_mode = the same step with every "
+                                  "product on v_mfma_f32_32x32x2_f32 (ssc_model_cfg.gemm_mode 2)")
+    if rank == 0 and world == 1 and result is not None and not args.timed_only:
+        # the same train step with every product on the exact-fp32 matrix instruction (per-engine numerics mode)
+        eng._cfg.gemm_mode = 2
+        try:
+            for i in range(2):
+                step(i)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n_ex = max(3, min(args.steps, 10))
+            for i in range(n_ex):
+                step(i)
+            torch.cuda.synchronize()
+            el_ex = time.perf_counter() - t0
+            result["exact_fp32_mode"] = {"value": c["B"] * n_ex / el_ex, "unit": "captions/s", "ms_per_step": el_ex / n_ex * 1e3,
+                                         "steps": n_ex, "vs_default_mode": (c["B"] * n_ex / el_ex) / result["value"]}
+        finally:
+            eng._cfg.gemm_mode = 0
+        result["c5_train"] = measure_c5_train(device)
     if rank == 0 and cbs_res is not None:
         result["decode_cbs"] = cbs_res
     if rank == 0 and not args.timed_only:

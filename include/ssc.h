@@ -311,13 +311,17 @@ int ssc_sgd_step(float* p, const float* g, float* buf, size_t n, const float* sq
 typedef struct {
   int V, E, H, A, F, Z;
   int S;            /* conditioning columns on the language LSTMs (updown_cell.py:47-81): 0, 1 (the sentiment column) or, with
-                     * kld_mode 2, D = 150 (SENTIMENT_VAE = 2: the attention-pooled attribute means; requires Z == S) */
+                     * kld_mode 2 (SENTIMENT_VAE = 2: the attention-pooled attribute means, Z wide), Z (LATENT_EMBEDDING "glove") or
+                     * 1 ("senti_word_net": their first entry, updown_cell.py:169-172) */
   int tied;         /* 1: frozen tied embedding + Linear/Tanh projection (updown_captioner.py:112-119) */
   int kld_mode;     /* 0: SENTIMENT_VAE==0 formula; 1: otherwise (updown_captioner.py:298-303); 2: the formula of 1 with the
                      * prior mean of step t = sum_r alpha_tr obj_atts_r (SENTIMENT_VAE = 2, updown_cell.py:160-163) */
   float pm_scale;   /* prior_mean = pm_scale * sentiment (0 for SENTIMENT_VAE 0 / SIMPLE_VAE) */
   float prior_var;  /* PRIOR_STD^2 */
   int pad, boundary;
+  int gemm_mode;    /* numerics of the 16-byte aligned NT / NN / TN products issued by the sequence-level calls made with THIS cfg
+                     * (ssc_train_*, ssc_decode_*): 0 = the process default (ssc_set_gemm_mode), 1 = 3xBF16 (three bf16 pieces per
+                     * fp32 operand, six partial products on the bf16 matrix cores, fp32 accumulate), 2 = exact-fp32 MFMA */
 } ssc_model_cfg;
 
 /* Parameter (or gradient) table: device pointers + leading dimensions of 2-D weights. */

@@ -430,6 +430,7 @@ extern "C" int ssc_decode_prepare(const ssc_model_cfg* cfg, const ssc_params* p,
 extern "C" int ssc_decode_prepare_from(const ssc_model_cfg* cfg, const ssc_params* p, const float* feats, int nimg, int R,
                                        void* imgbuf, size_t imgbuf_bytes, const void* prev_imgbuf, int prev_nimg, int prev_R,
                                        void* stream) {
+  SscGemmModeScope mode_scope(cfg);   // the numerics mode of this cfg, for every product the call issues
   if (!cfg || !p || !feats || !imgbuf || nimg <= 0 || R <= 0 || R > 256) return SSC_EINVAL;
   if (prev_imgbuf && (prev_nimg <= 0 || prev_R <= 0 || prev_imgbuf == imgbuf)) return SSC_EINVAL;
   ImgLayout l = img_layout(cfg, nimg, R);
@@ -496,6 +497,7 @@ extern "C" int ssc_decode_ungathered_ok(const ssc_model_cfg* cfg, int nimg, int 
 
 extern "C" int ssc_decode_step(const ssc_model_cfg* cfg, const ssc_params* p, const ssc_decode_step_desc* d, void* workspace,
                                size_t workspace_bytes, void* stream) {
+  SscGemmModeScope mode_scope(cfg);   // the numerics mode of this cfg, for every product the call issues
   if (!cfg || !p || !d || !workspace) return SSC_EINVAL;
   const int G = d->G, R = d->R, rpi = d->rows_per_image;
   if (G <= 0 || R <= 0 || R > 256 || rpi <= 0 || G % rpi != 0) return SSC_EINVAL;

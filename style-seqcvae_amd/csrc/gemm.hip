@@ -1661,7 +1661,13 @@ gemm_fn pick_layout(const ssc_gemm_desc* d) {
 // tile choice: 128x128 (2x2 MFMA tiles per wave) when both dimensions are large, else 64x64 with a deeper prefetch
 // SSC_GEMM_MODE: "x3" (default) = 3xBF16 split kernel for NT products with 16 B/lane operands, "f32" = exact fp32 MFMA
 int g_gemm_mode = -1;  // -1: take the default from the environment on first use
+}
+// A sequence-level call (ssc_train_fwd / _bwd, ssc_decode_*) runs under the numerics mode of ITS ssc_model_cfg (gemm_mode field):
+// the calling thread's override, in force while the call issues its launches.  Two engines of one process can so differ.
+thread_local int ssc_tls_gemm_mode = -1;
+namespace {
 inline int gemm_mode() {
+  if (ssc_tls_gemm_mode >= 0) return ssc_tls_gemm_mode;
   if (g_gemm_mode < 0) {
     const char* e = ssc_env_debug() ? getenv("SSC_GEMM_MODE") : nullptr;
     g_gemm_mode = (e && e[0] == 'f') ? 0 : 1;
@@ -1774,7 +1780,12 @@ inline void group_of_one(KGroup& g, const KArgs& k, dim3 grid) {
 
 // the wave-specialised kernels need more than the default 64 KB of LDS per workgroup: raise the limit once
 int x3w_prepare() {
-  static bool done = false;
+  // per DEVICE: the attribute belongs to the function's code object on the device it is set under - a process that drives two GPUs
+  // (or a rank that changes its device) must set it on each
+  static bool done_dev[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return SSC_EHIP;
+  bool& done = done_dev[dev];
   if (done) return SSC_OK;
   group_fn big[8] = {gemm_x3w_kernel<true, true, false, 128, 128, 2>, gemm_x3w_kernel<true, false, false, 128, 128, 2>,
                      gemm_x3w_kernel<false, false, true, 128, 128, 1>, gemm_x3w_kernel<false, false, false, 128, 128, 2>,

@@ -93,6 +93,7 @@ extern "C" size_t ssc_decode_search_workspace_bytes(const ssc_model_cfg* cfg, co
 
 extern "C" int ssc_decode_search(const ssc_model_cfg* cfg, const ssc_params* p, const ssc_search_desc* d, void* workspace,
                                  size_t workspace_bytes, void* stream) {
+  SscGemmModeScope mode_scope(cfg);   // the numerics mode of this cfg, for every product the call issues
   if (!p || !workspace || !desc_ok(cfg, d)) return SSC_EINVAL;
   const SearchLayout l = search_layout(cfg, d);
   if (workspace_bytes < l.total) return SSC_EWORKSPACE;

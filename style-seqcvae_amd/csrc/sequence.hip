@@ -449,6 +449,7 @@ extern "C" void* ssc_train_workspace_view(const ssc_model_cfg* cfg, int B, int R
 
 extern "C" int ssc_train_fwd(const ssc_model_cfg* cfg, const ssc_params* p, const ssc_batch* bt, void* workspace,
                              size_t workspace_bytes, float* loss, float* kld, void* stream) {
+  SscGemmModeScope mode_scope(cfg);   // the numerics mode of this cfg, for every product the call issues
   SSC_TRY(check_cfg(cfg, p, bt));
   if (!workspace || !loss || !kld) return SSC_EINVAL;
   if (!ssc_aligned16(workspace)) return SSC_EALIGN;
@@ -701,6 +702,7 @@ __global__ void repeat_kernel(const float* __restrict__ src, int n, int reps, fl
 static int train_bwd_impl(const ssc_model_cfg* cfg, const ssc_params* p, const ssc_batch* bt, void* workspace,
                           size_t workspace_bytes, const float* gl, const float* gk, const ssc_params* g, void* stream,
                           unsigned phases) {
+  SscGemmModeScope mode_scope(cfg);   // the numerics mode of this cfg, for every product the call issues
   SSC_TRY(check_cfg(cfg, p, bt));
   if (!workspace || !gl || !gk || !g) return SSC_EINVAL;
   const Layout l = make_layout(cfg, bt->B, bt->R, bt->L);

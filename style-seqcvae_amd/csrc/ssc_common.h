@@ -96,3 +96,15 @@ int ssc_beam_merge(const float* sval, const int64_t* sidx, const float* last_lp,
                    int64_t* pred, float* lp_out, int64_t* backptr, int end_index, int* ctl, int step_index, int max_steps,
                    int* host_flag, hipStream_t st);
 int ssc_decode_att_table_enabled();   // the "dec_att_table" switch (decode.hip)
+
+// numerics mode of the calling thread's current sequence-level call (ssc_model_cfg.gemm_mode: 0 = the process default set by
+// ssc_set_gemm_mode, 1 = 3xBF16, 2 = exact-fp32 MFMA); -1 = none in force
+extern thread_local int ssc_tls_gemm_mode;
+struct SscGemmModeScope {
+  int prev;
+  explicit SscGemmModeScope(const ssc_model_cfg* c) : prev(ssc_tls_gemm_mode) {
+    if (c && c->gemm_mode == 1) ssc_tls_gemm_mode = 1;
+    else if (c && c->gemm_mode == 2) ssc_tls_gemm_mode = 0;
+  }
+  ~SscGemmModeScope() { ssc_tls_gemm_mode = prev; }
+};

@@ -66,10 +66,11 @@ class ModelDims:
     prior_var: float = 1.0
     pad: int = 0
     boundary: int = 1
+    gemm_mode: int = 0    # numerics of this engine's products: 0 = process default (ssc_set_gemm_mode), 1 = 3xBF16, 2 = exact-fp32 MFMA
 
     def cfg(self) -> _lib.ModelCfg:
         return _lib.ModelCfg(self.V, self.E, self.H, self.A, self.F, self.Z, self.S, int(self.tied), self.kld_mode,
-                             float(self.pm_scale), float(self.prior_var), self.pad, self.boundary)
+                             float(self.pm_scale), float(self.prior_var), self.pad, self.boundary, int(self.gemm_mode))
 
     def param_shapes(self) -> "Dict[str, Tuple[int, ...]]":
         V, E, H, A, F, Z, S = self.V, self.E, self.H, self.A, self.F, self.Z, self.S

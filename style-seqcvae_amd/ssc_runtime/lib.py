@@ -67,7 +67,7 @@ class LatentBwdDesc(C.Structure):
 class ModelCfg(C.Structure):
     _fields_ = [("V", C.c_int), ("E", C.c_int), ("H", C.c_int), ("A", C.c_int), ("F", C.c_int), ("Z", C.c_int),
                 ("S", C.c_int), ("tied", C.c_int), ("kld_mode", C.c_int), ("pm_scale", C.c_float),
-                ("prior_var", C.c_float), ("pad", C.c_int), ("boundary", C.c_int)]
+                ("prior_var", C.c_float), ("pad", C.c_int), ("boundary", C.c_int), ("gemm_mode", C.c_int)]
 
 
 # (field, has_ld) in the exact order of ssc_params

@@ -69,7 +69,7 @@ def test_bad_arguments_are_rejected_without_a_gpu():
         lib.ssc_gemm(C.byref(d), None)
     with pytest.raises(L.SscError, match="SSC_EINVAL"):
         lib.ssc_feat_prep(None, 1, 1, 1, None, None, None)
-    cfg = L.ModelCfg(10, 4, 4, 4, 4, 4, 0, 0, 0, 0.0, 1.0, 0, 1)
+    cfg = L.ModelCfg(10, 4, 4, 4, 4, 4, 0, 0, 0, 0.0, 1.0, 0, 1, 0)
     assert lib.ssc_train_workspace_bytes(C.byref(cfg), 2, 3, 4) > 0
     assert lib.ssc_train_workspace_bytes(C.byref(cfg), 0, 3, 4) == 0
     assert lib.ssc_gemm_auto_splits(64, 4800, 180) >= 1

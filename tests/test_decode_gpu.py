@@ -654,7 +654,8 @@ def test_image_cell_kernel_equals_float64(nimg, rpi, R, H, variant):
 
 @pytest.mark.parametrize("nimg,groups,beam,sv,R", [(8, 14, 5, 1, 36), (8, 13, 5, 1, 36), (10, 12, 5, 0, 36), (26, 4, 5, 1, 36),
                                                    (40, 3, 5, 1, 36), (8, 40, 3, 1, 36), (16, 4, 5, 1, 36), (9, 14, 5, 0, 36),
-                                                   (8, 14, 5, 1, 50), (8, 14, 5, 1, 100), (8, 14, 5, 1, 27)])
+                                                   (8, 14, 5, 1, 50), (8, 14, 5, 1, 100), (8, 14, 5, 1, 27),
+                                                   (100, 20, 5, 1, 36)])   # the last: bench.py's own call shape, 10 000 rows per step
 def test_full_size_large_call_decode_step_matches_oracle(nimg, groups, beam, sv, R):
     """C4's model size (V = 10000, E / H / A = 1000 / 1200 / 768, 36 x 2048 regions, Z = 128) at a call large enough for every
     large-call path (8 images x 14 groups x beam 5 = 560 rows: per-token gate table, per-image attended-feature table on the
