@@ -76,7 +76,18 @@ typedef struct {
    *            (single-segment TN products, a_kc = b_kc = 0) */
   const int* m_count; const int* a_rows; const int* c_rows;
   const int* k_count; const int* ka_rows; const int* kb_rows;
+  /* Optional, used by the 2xFP16 form only (ssc_model_cfg.gemm_mode 3): device scalars holding POWERS OF TWO the A / B operands are
+   * multiplied with before they are split into two fp16 pieces (the result is multiplied with the exact inverse of their product).
+   * Choose them so that the operands' largest magnitudes land near 2^6 .. 2^13 (ssc_pow2_scale): fp16 overflows at 65504, and an
+   * entry whose lo piece is below 2^-14 keeps an absolute precision of 2^-25 only.  NULL = 1. */
+  const float* a_scale; const float* b_scale;
 } ssc_gemm_desc;
+
+/* out[0] = 2^(target_log2 - ceil(log2(max |x|))) over the rows x cols block x (ld), a power of two that brings the block's largest
+ * magnitude to [2^(target_log2 - 1), 2^target_log2] (1 when the block is all zero).  combine = 1: out[0] = min(out[0], that).
+ * scratch: one float of device memory. */
+int ssc_pow2_scale(const float* x, size_t rows, int cols, size_t ld, int target_log2, float* out, int combine, float* scratch,
+                   void* stream);
 
 int ssc_gemm(const ssc_gemm_desc* d, void* stream);
 

@@ -20,7 +20,7 @@ inline size_t r4(size_t x) { return (x + 3) & ~(size_t)3; }
 inline size_t r64(size_t x) { return (x + 63) & ~(size_t)63; }
 
 struct ImgLayout {
-  size_t mask, avg, pv, ga_avg, wsum_att, wsum_dec, wz, wc, emb_gates, pd, scratch, scratch_floats, total;
+  size_t mask, avg, pv, ga_avg, wsum_att, wsum_dec, wz, wc, emb_gates, pd, scales, scratch, scratch_floats, total;
   int Fp, Hp, Zp, Sp;
   bool token_table;   // emb_gates holds the (V, 4H) table emb . W_ih^att[:, :E]^T
   bool att_table;     // pd holds P[img, r, :] = W_ih^dec[:, :F] v_{img,r} (nimg*R x 4H): the decoder gates' attended-feature term per region
@@ -62,6 +62,7 @@ ImgLayout img_layout(const ssc_model_cfg* c, int nimg, int R) {
   // step (K = F + 2H + Z = 4576) loses its K = F = 2048 segment, and the weighted feature sum itself is no longer needed.
   l.att_table = ssc_g_dec_att_table != 0 && R <= 128;
   l.pd = o; o += r64(l.att_table ? (size_t)nimg * R * 4 * c->H : 0);
+  l.scales = o; o += 64;   // power-of-two operand scales of the 2xFP16 products (ssc_model_cfg.gemm_mode 3), see DecScales
   size_t a = (size_t)nimg * R * c->A, b = (size_t)nimg * 4 * c->H;
   l.scratch_floats = 33 * (a > b ? a : b);
   l.scratch = o; o += r64(l.scratch_floats);
@@ -103,6 +104,16 @@ struct Seg {
   int K;
 };
 
+// Power-of-two operand scales for the 2xFP16 form of the large products (ssc_gemm_desc.a_scale / b_scale), kept in the image buffer:
+// recurrent states, z, the projected hidden state lie in [-1, 1] or a few units around it -> a constant 2^6; everything that comes
+// from data or from the checkpoint (weights, embedding table, region features) is measured once per image context (ssc_pow2_scale,
+// largest magnitude -> [2^12, 2^13]).  One pair per product: operands of one product that differ in scale share the smaller factor.
+enum { SC_ACT = 0, SC_ACTF, SC_ATTW, SC_Q, SC_DEC, SC_OUT, SC_PROJ, SC_EMB, SC_FEAT, SC_WV, SC_TMP, SC_COUNT };
+struct DecScales {
+  const float* base;   // nullptr: no scales (every factor 1)
+  const float* at(int i) const { return base ? base + i : nullptr; }
+};
+
 void fill_desc(ssc_gemm_desc& d, std::initializer_list<Seg> segs, int M, int N) {
   d = ssc_gemm_desc{};
   int i = 0;
@@ -115,18 +126,20 @@ void fill_desc(ssc_gemm_desc& d, std::initializer_list<Seg> segs, int M, int N) 
 }
 
 int gemm_nt(hipStream_t st, float* ws, size_t ws_floats, std::initializer_list<Seg> segs, int M, int N, float* Cc, int ldc,
-            const float* bias = nullptr) {
+            const float* bias = nullptr, const float* sa = nullptr, const float* sb = nullptr) {
   ssc_gemm_desc d;
   fill_desc(d, segs, M, N);
   d.C = Cc; d.ldc = ldc; d.bias = bias; d.splits = 0; d.workspace = ws; d.workspace_floats = ws_floats;
+  d.a_scale = sa; d.b_scale = sb;
   return ssc_gemm(&d, st);
 }
 
 int gemm_slabs(hipStream_t st, float* ws, size_t ws_floats, std::initializer_list<Seg> segs, int M, int N, int* nslab,
-               const int* m_count = nullptr, const int* a_rows = nullptr) {
+               const int* m_count = nullptr, const int* a_rows = nullptr, const float* sa = nullptr, const float* sb = nullptr) {
   ssc_gemm_desc d;
   fill_desc(d, segs, M, N);
   d.m_count = m_count; d.a_rows = a_rows;   // product over the listed A rows only, output rows compact (slab row i <-> a_rows[i])
+  d.a_scale = sa; d.b_scale = sb;
   return ssc_gemm_slabs_auto(&d, ws, ws_floats, nslab, st);
 }
 
@@ -439,9 +452,35 @@ extern "C" int ssc_decode_prepare_from(const ssc_model_cfg* cfg, const ssc_param
   hipStream_t st = (hipStream_t)stream;
   const int F = cfg->F, A = cfg->A, E = cfg->E, H4 = 4 * cfg->H;
   SSC_TRY(ssc_feat_prep(feats, nimg, R, F, W + l.mask, W + l.avg, st));
-  SSC_TRY(gemm_nt(st, W + l.scratch, l.scratch_floats, {{feats, F, p->wv, p->ld_wv, F}}, nimg * R, A, W + l.pv, A));
+  // 2xFP16 products (cfg->gemm_mode 3): the operands' power-of-two scales (DecScales), measured here once per image context.
+  // Weight groups whose blocks are also pre-summed (W_ih[:, h-block] + W_hh) get one bit of head room.
+  float* SC = W + l.scales;
+  if (cfg->gemm_mode == 3) {
+    const int H = cfg->H;
+    float* tmp = SC + SC_TMP;
+    SSC_TRY(ssc_fill(SC + SC_ACT, 1, 64.f, st));
+    SSC_TRY(ssc_fill(SC + SC_ACTF, 1, 64.f, st));
+    SSC_TRY(ssc_pow2_scale(feats, (size_t)nimg * R, F, F, 13, SC + SC_FEAT, 0, tmp, st));
+    SSC_TRY(ssc_pow2_scale(feats, (size_t)nimg * R, F, F, 13, SC + SC_ACTF, 1, tmp, st));   // products that mix states and attended features
+    SSC_TRY(ssc_pow2_scale(p->att_w_ih, H4, E + F + 2 * H, p->ld_att_w_ih, 12, SC + SC_ATTW, 0, tmp, st));
+    SSC_TRY(ssc_pow2_scale(p->att_w_hh, H4, H, p->ld_att_w_hh, 12, SC + SC_ATTW, 1, tmp, st));
+    SSC_TRY(ssc_pow2_scale(p->dec_w_ih, H4, F + 2 * H + cfg->S + cfg->Z, p->ld_dec_w_ih, 12, SC + SC_DEC, 0, tmp, st));
+    SSC_TRY(ssc_pow2_scale(p->dec_w_hh, H4, H, p->ld_dec_w_hh, 12, SC + SC_DEC, 1, tmp, st));
+    SSC_TRY(ssc_pow2_scale(p->wq, A, H, p->ld_wq, 13, SC + SC_Q, 0, tmp, st));
+    SSC_TRY(ssc_pow2_scale(p->wv, A, F, p->ld_wv, 13, SC + SC_WV, 0, tmp, st));
+    SSC_TRY(ssc_pow2_scale(p->emb, cfg->V, E, p->ld_emb, 13, SC + SC_EMB, 0, tmp, st));
+    if (cfg->tied) {
+      SSC_TRY(ssc_pow2_scale(p->emb, cfg->V, E, p->ld_emb, 13, SC + SC_OUT, 0, tmp, st));
+      SSC_TRY(ssc_pow2_scale(p->proj_w, E, H, p->ld_proj_w, 13, SC + SC_PROJ, 0, tmp, st));
+    } else {
+      SSC_TRY(ssc_pow2_scale(p->out_w, cfg->V, H, p->ld_out_w, 13, SC + SC_OUT, 0, tmp, st));
+    }
+  }
+  const DecScales sc{cfg->gemm_mode == 3 ? SC : nullptr};
+  SSC_TRY(gemm_nt(st, W + l.scratch, l.scratch_floats, {{feats, F, p->wv, p->ld_wv, F}}, nimg * R, A, W + l.pv, A, nullptr,
+                  sc.at(SC_FEAT), sc.at(SC_WV)));
   SSC_TRY(gemm_nt(st, W + l.scratch, l.scratch_floats, {{W + l.avg, F, p->att_w_ih + E, p->ld_att_w_ih, F}}, nimg, H4,
-                  W + l.ga_avg, H4));
+                  W + l.ga_avg, H4, nullptr, sc.at(SC_FEAT), sc.at(SC_ATTW)));
   if (l.token_table) {
     // the per-token gate table is a function of the weights alone (V x 4H x E: 0.6 ms at C4's sizes, 1.3 % of a 50-image call):
     // an earlier context of the same, unchanged parameters hands it over by a copy
@@ -452,7 +491,7 @@ extern "C" int ssc_decode_prepare_from(const ssc_model_cfg* cfg, const ssc_param
         return SSC_EHIP;
     } else {
       SSC_TRY(gemm_nt(st, W + l.scratch, l.scratch_floats, {{p->emb, p->ld_emb, p->att_w_ih, p->ld_att_w_ih, E}}, cfg->V, H4,
-                      W + l.emb_gates, H4));
+                      W + l.emb_gates, H4, nullptr, sc.at(SC_EMB), sc.at(SC_ATTW)));
     }
   }
   // (the attended-feature table l.pd is formed by the first decode step that asks for it: ssc_decode_step_desc.att_table = 2)
@@ -519,9 +558,10 @@ extern "C" int ssc_decode_step(const ssc_model_cfg* cfg, const ssc_params* p, co
   int ns = 0;
   if (d->att_table < 0 || d->att_table > 2 || (d->att_table && !il.att_table)) return SSC_EINVAL;
   const bool att_table = d->att_table != 0;
+  const DecScales sc{cfg->gemm_mode == 3 ? I + il.scales : nullptr};   // operand scales of the 2xFP16 products (ssc_decode_prepare)
   if (d->att_table == 2)   // P[img, r, :] = W_ih^dec[:, :F] v_{img,r}: one (nimg R) x 4H x F product per image context
     SSC_TRY(gemm_nt(st, slabs, l.slab_floats, {{d->feats, F, p->dec_w_ih, p->ld_dec_w_ih, F}}, nimg * R, H4,
-                    const_cast<float*>(I) + il.pd, H4));
+                    const_cast<float*>(I) + il.pd, H4, nullptr, sc.at(SC_FEAT), sc.at(SC_DEC)));
 
   // Beams that share their parent: the products fed only by the previous step's h1 / hd run on the distinct parents
   // (ssc_decode_step_desc.parent).  Used where the token's gate term is not part of the product (token table) and the rows are
@@ -549,11 +589,12 @@ extern "C" int ssc_decode_step(const ssc_model_cfg* cfg, const ssc_params* p, co
     if (live) { lcount = dd + 1; lrows = dd + 4 + 3 * G; }
   }
   // a product over every LIVE row, written to the rows' own places (ssc_gemm with one row list for A and C; one launch, no split)
-  auto gemm_live = [&](std::initializer_list<Seg> segs, int N, float* Cc, int ldc, const float* bias) -> int {
+  auto gemm_live = [&](std::initializer_list<Seg> segs, int N, float* Cc, int ldc, const float* bias, const float* sa, const float* sb) -> int {
     ssc_gemm_desc g;
     fill_desc(g, segs, G, N);
     g.C = Cc; g.ldc = ldc; g.bias = bias; g.splits = 1; g.workspace = nullptr; g.workspace_floats = 0;
     g.m_count = lcount; g.a_rows = lrows; g.c_rows = lrows;
+    g.a_scale = sa; g.b_scale = sb;
     return ssc_gemm(&g, st);
   };
   float* slabs_u = slabs + (size_t)G * H4;   // second product of the decoder gates (distinct parents): behind the first one's rows
@@ -564,7 +605,7 @@ extern "C" int ssc_decode_step(const ssc_model_cfg* cfg, const ssc_params* p, co
     ssc_lstm_fwd_desc f{};
     if (il.token_table && !d->emb_override) {   // the embedding's gate term comes from the per-token table, row = the beam's last token
       SSC_TRY(gemm_slabs(st, slabs, l.slab_floats, {{d->h1, H, I + il.wsum_att, il.Hp, H}, {d->hd, H, wr + H, p->ld_att_w_ih, H}}, G, H4,
-                         &ns, ucount, urows));
+                         &ns, ucount, urows, sc.at(SC_ACT), sc.at(SC_ATTW)));
       if (dedup && ns != 1) return SSC_EINVAL;   // (row lists and split-K slabs do not combine; G >= 512 never splits)
       f.slab_rows = slot;
       f.add0 = I + il.emb_gates; f.ld_add0 = H4; f.add0_rows = d->tokens;
@@ -572,7 +613,7 @@ extern "C" int ssc_decode_step(const ssc_model_cfg* cfg, const ssc_params* p, co
       SSC_TRY(ssc_embed_gather(p->emb, p->ld_emb, d->tokens, G, E, W + l.emb, l.Ep, st));
       SSC_TRY(gemm_slabs(st, slabs, l.slab_floats,
                          {{W + l.emb, l.Ep, p->att_w_ih, p->ld_att_w_ih, E}, {d->h1, H, I + il.wsum_att, il.Hp, H},
-                          {d->hd, H, wr + H, p->ld_att_w_ih, H}}, G, H4, &ns));
+                          {d->hd, H, wr + H, p->ld_att_w_ih, H}}, G, H4, &ns, nullptr, nullptr, sc.at(SC_ACT), sc.at(SC_ATTW)));
     }
     f.B = G; f.H = H;
     f.slabs = slabs; f.nslab = ns; f.slab_stride = (size_t)G * H4;
@@ -583,8 +624,8 @@ extern "C" int ssc_decode_step(const ssc_model_cfg* cfg, const ssc_params* p, co
     SSC_TRY(ssc_lstm_fwd(&f, st));
   }
   // attention over the image's regions (attention.py:69-95, updown_cell.py:151-158)
-  if (live) SSC_TRY(gemm_live({{d->h1_out, H, p->wq, p->ld_wq, H}}, A, W + l.q, l.Ap, nullptr));
-  else SSC_TRY(gemm_nt(st, slabs, l.slab_floats, {{d->h1_out, H, p->wq, p->ld_wq, H}}, G, A, W + l.q, l.Ap));
+  if (live) SSC_TRY(gemm_live({{d->h1_out, H, p->wq, p->ld_wq, H}}, A, W + l.q, l.Ap, nullptr, sc.at(SC_ACT), sc.at(SC_Q)));
+  else SSC_TRY(gemm_nt(st, slabs, l.slab_floats, {{d->h1_out, H, p->wq, p->ld_wq, H}}, G, A, W + l.q, l.Ap, nullptr, sc.at(SC_ACT), sc.at(SC_Q)));
   if (att_table)
     SSC_TRY(ssc_attn_weights(W + l.q, l.Ap, I + il.pv, p->wa, I + il.mask, G, R, A, rpi, W + l.attn_logits, d->alpha, st));
   else
@@ -610,22 +651,25 @@ extern "C" int ssc_decode_step(const ssc_model_cfg* cfg, const ssc_params* p, co
     const int KC = sv2 && S > 1 ? il.Sp : 0;   // conditioning block as a K-segment over its 16-byte padded width (a segment with K = 0 is dropped)
     const Seg cseg{W + l.pm, l.Zp, I + il.wc, il.Sp, KC};
     if (att_table && dedup) {   // hd' segment on the distinct parents, [h1 | z] on every row
-      SSC_TRY(gemm_slabs(st, slabs_u, l.slab_floats - (size_t)G * H4, {{d->hd, H, I + il.wsum_dec, il.Hp, H}}, G, H4, &ns_u, ucount, urows));
+      SSC_TRY(gemm_slabs(st, slabs_u, l.slab_floats - (size_t)G * H4, {{d->hd, H, I + il.wsum_dec, il.Hp, H}}, G, H4, &ns_u, ucount, urows,
+                         sc.at(SC_ACT), sc.at(SC_DEC)));
       if (ns_u != 1) return SSC_EINVAL;
       if (live) {
-        SSC_TRY(gemm_live({{d->h1_out, H, p->dec_w_ih + F, p->ld_dec_w_ih, H}, {W + l.z, l.Zp, I + il.wz, il.Zp, l.Zp}, cseg}, H4, slabs, H4, nullptr));
+        SSC_TRY(gemm_live({{d->h1_out, H, p->dec_w_ih + F, p->ld_dec_w_ih, H}, {W + l.z, l.Zp, I + il.wz, il.Zp, l.Zp}, cseg}, H4, slabs, H4, nullptr,
+                          sc.at(SC_ACT), sc.at(SC_DEC)));
         ns = 1;
       } else
         SSC_TRY(gemm_slabs(st, slabs, (size_t)G * H4, {{d->h1_out, H, p->dec_w_ih + F, p->ld_dec_w_ih, H}, {W + l.z, l.Zp, I + il.wz, il.Zp, l.Zp}, cseg},
-                           G, H4, &ns));
+                           G, H4, &ns, nullptr, nullptr, sc.at(SC_ACT), sc.at(SC_DEC)));
     } else if (att_table)   // the attended-feature segment comes from the per-image table inside the cell kernel
       SSC_TRY(gemm_slabs(st, slabs, l.slab_floats,
                          {{d->h1_out, H, p->dec_w_ih + F, p->ld_dec_w_ih, H}, {d->hd, H, I + il.wsum_dec, il.Hp, H},
-                          {W + l.z, l.Zp, I + il.wz, il.Zp, l.Zp}, cseg}, G, H4, &ns));
+                          {W + l.z, l.Zp, I + il.wz, il.Zp, l.Zp}, cseg}, G, H4, &ns, nullptr, nullptr, sc.at(SC_ACT), sc.at(SC_DEC)));
     else
       SSC_TRY(gemm_slabs(st, slabs, l.slab_floats,
                          {{W + l.att, l.Fp, p->dec_w_ih, p->ld_dec_w_ih, F}, {d->h1_out, H, p->dec_w_ih + F, p->ld_dec_w_ih, H},
-                          {d->hd, H, I + il.wsum_dec, il.Hp, H}, {W + l.z, l.Zp, I + il.wz, il.Zp, l.Zp}, cseg}, G, H4, &ns));
+                          {d->hd, H, I + il.wsum_dec, il.Hp, H}, {W + l.z, l.Zp, I + il.wz, il.Zp, l.Zp}, cseg}, G, H4, &ns, nullptr, nullptr,
+                         sc.at(SC_ACTF), sc.at(SC_DEC)));
     ssc_lstm_fwd_desc f{};
     f.B = G; f.H = H;
     f.slabs = slabs; f.nslab = ns; f.slab_stride = (size_t)G * H4;
@@ -643,13 +687,16 @@ extern "C" int ssc_decode_step(const ssc_model_cfg* cfg, const ssc_params* p, co
   // vocabulary log-probabilities (updown_captioner.py:444-450); skipped when only the cell output is wanted
   if (!d->log_probs) return SSC_OK;
   if (cfg->tied) {
-    SSC_TRY(gemm_nt(st, slabs, l.slab_floats, {{d->hd_out, H, p->proj_w, p->ld_proj_w, H}}, G, E, W + l.proj, l.Ep));
+    SSC_TRY(gemm_nt(st, slabs, l.slab_floats, {{d->hd_out, H, p->proj_w, p->ld_proj_w, H}}, G, E, W + l.proj, l.Ep, nullptr,
+                    sc.at(SC_ACT), sc.at(SC_PROJ)));
     SSC_TRY(ssc_bias_tanh(W + l.proj, l.Ep, G, E, p->proj_b, st));
-    SSC_TRY(gemm_nt(st, slabs, l.slab_floats, {{W + l.proj, l.Ep, p->emb, p->ld_emb, E}}, G, V, d->log_probs, V));
+    SSC_TRY(gemm_nt(st, slabs, l.slab_floats, {{W + l.proj, l.Ep, p->emb, p->ld_emb, E}}, G, V, d->log_probs, V, nullptr,
+                    sc.at(SC_ACT), sc.at(SC_OUT)));
   } else if (live) {
-    SSC_TRY(gemm_live({{d->hd_out, H, p->out_w, p->ld_out_w, H}}, V, d->log_probs, V, p->out_b));
+    SSC_TRY(gemm_live({{d->hd_out, H, p->out_w, p->ld_out_w, H}}, V, d->log_probs, V, p->out_b, sc.at(SC_ACT), sc.at(SC_OUT)));
   } else {
-    SSC_TRY(gemm_nt(st, slabs, l.slab_floats, {{d->hd_out, H, p->out_w, p->ld_out_w, H}}, G, V, d->log_probs, V, p->out_b));
+    SSC_TRY(gemm_nt(st, slabs, l.slab_floats, {{d->hd_out, H, p->out_w, p->ld_out_w, H}}, G, V, d->log_probs, V, p->out_b,
+                    sc.at(SC_ACT), sc.at(SC_OUT)));
   }
   if (!d->raw_logits) SSC_TRY(ssc_log_softmax(d->log_probs, V, G, V, d->log_probs, V, st));
   return SSC_OK;

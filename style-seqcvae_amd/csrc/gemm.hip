@@ -61,6 +61,8 @@ struct KArgs {
   int store_wt;       // x3w epilogue: 1 = write-through (sc1) stores of the output tile (split-K slabs: nothing left dirty in L2
                       // for the kernel boundary to write back)
   int member;         // index of this product inside a grouped launch (address-audit build: which record it reports to)
+  const float* a_scale;   // 2xFP16 form only: power-of-two factors (device scalars, optional) the A / B operands are multiplied with
+  const float* b_scale;   // before the fp16 split; the result is multiplied with the exact inverse of their product
 };
 
 // Tile order of a launch (speed only; a bijection for any grid).  Workgroups are dealt round-robin over the 8 XCDs, each
@@ -595,6 +597,21 @@ __device__ __forceinline__ void split4(const f32x4& v, u32x2& hi, u32x2& mid, u3
   }
 }
 
+// 2xFP16 (ssc_model_cfg.gemm_mode 3): 4 consecutive fp32 into TWO fp16 planes, hi = x truncated to fp16, lo = (x - hi) truncated
+// to fp16 (x - hi is exact in fp32) - 21-22 significant bits of x, two v_cvt_pkrtz + two conversions back + two subtractions per
+// pair instead of the 3xBF16 split's masks, subtractions and byte permutes.  |x| must stay below 65504 (fp16 range).
+typedef __fp16 h16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split4_f16(const f32x4& v, u32x2& hi, u32x2& lo) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const h16x2 h = __builtin_amdgcn_cvt_pkrtz(v[2 * j], v[2 * j + 1]);
+    const float r0 = v[2 * j] - (float)h[0], r1 = v[2 * j + 1] - (float)h[1];
+    const h16x2 l = __builtin_amdgcn_cvt_pkrtz(r0, r1);
+    hi[j] = __builtin_bit_cast(unsigned, h);
+    lo[j] = __builtin_bit_cast(unsigned, l);
+  }
+}
+
 // WN = 32x32 MFMA tiles per wave along N: block tile 64 x (64*WN).  WN = 2 halves the A re-reads per streamed weight
 // byte (the CU-side load path, ~24 GB/s per CU, is what the skinny products saturate) at one workgroup per CU.
 // NBUF = LDS stages: 2 = one barrier per k-step (61 KB: two workgroups per CU); 1 = two barriers per k-step but half the
@@ -1113,7 +1130,10 @@ template <int R> struct X3wPlane {   // one bf16 plane of an R-row operand tile:
 };
 template <int TM, int TN> constexpr int x3w_lds_bytes() { return 2 * 3 * (X3wPlane<TM>::BYTES + X3wPlane<TN>::BYTES) + X3W_STAMP_BYTES; }
 
-template <bool A_KC, bool B_KC, bool KG, int TM, int TN, int PF, int NPW>
+// F16: the operands are split into two fp16 planes and multiplied with THREE partial products (lo*hi, hi*lo, hi*hi) on
+// v_mfma_f32_32x32x16_f16 instead of three bf16 planes and six products - half the matrix-pipe work of a product that is bound by
+// it (the decode's 10000-row products: DESIGN.md).  LDS layout unchanged (plane 2 of each operand stays unused).
+template <bool A_KC, bool B_KC, bool KG, int TM, int TN, int PF, int NPW, bool F16 = false>
 __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const int blk_y, const int blk_z, const int grid_x,
                                          const int grid_y, const int grid_z) {
   static_assert((TM == 128 && TN == 128) || (TM == 64 && TN == 256), "unsupported tile");
@@ -1155,6 +1175,13 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
   if (s_hi > steps_total) s_hi = steps_total;
   const int s_last = s_hi - 1;
   constexpr int CT_LD = TN + 4;   // epilogue C tile in LDS
+  // 2xFP16: operands are brought into the middle of the fp16 range by exact power-of-two factors (scalar loads: they do not touch
+  // the vector-memory counter of the staged loads) so that the lo pieces of all but negligibly small entries are normal fp16 numbers
+  float f16_sa = 1.f, f16_sb = 1.f;
+  if constexpr (F16) {
+    if (a.a_scale) f16_sa = *a.a_scale;
+    if (a.b_scale) f16_sb = *a.b_scale;
+  }
 #ifdef SSC_X3W_STAMP
   const bool stamp_on = (int)blockIdx.x == g_stamp_wg && (wave == 0 || wave == 4);
   unsigned long long* stamp_lds = reinterpret_cast<unsigned long long*>(lds + 2 * STAGE) + (wave == 4 ? 0 : 128);
@@ -1313,24 +1340,32 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
       s_ld = min(s_ld + 1, s_last);
       step_ptrs(how, buf);
     };
-    auto put_chunk = [&](unsigned char* p, int plane, f32x4 v, bool ok) __attribute__((always_inline)) {
+    auto put_chunk = [&](unsigned char* p, int plane, f32x4 v, bool ok, float scale) __attribute__((always_inline)) {
       if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
-      u32x2 hi, mid, lo;
-      split4(v, hi, mid, lo);
-      *reinterpret_cast<u32x2*>(p) = hi;
-      *reinterpret_cast<u32x2*>(p + plane) = mid;
-      *reinterpret_cast<u32x2*>(p + 2 * plane) = lo;
+      if constexpr (F16) {
+        u32x2 hi, lo;
+        v = v * scale;
+        split4_f16(v, hi, lo);
+        *reinterpret_cast<u32x2*>(p) = hi;
+        *reinterpret_cast<u32x2*>(p + plane) = lo;
+      } else {
+        u32x2 hi, mid, lo;
+        split4(v, hi, mid, lo);
+        *reinterpret_cast<u32x2*>(p) = hi;
+        *reinterpret_cast<u32x2*>(p + plane) = mid;
+        *reinterpret_cast<u32x2*>(p + 2 * plane) = lo;
+      }
     };
     auto put_planes_impl = [&](unsigned char* st, const f32x4 (&xa)[NA], const f32x4 (&xb)[NB], unsigned ma, unsigned mb, const bool all) __attribute__((always_inline)) {
 #pragma unroll
       for (int u = 0; u < NA; ++u) {
         const int idx = tid + NPT * u;
-        put_chunk(st + (A_KC ? (idx >> 3) * PL_ROW_B + (idx & 7) * 8 : (idx / QA) * MCA + (idx % QA) * 8), PLA, xa[u], all || ((ma >> u) & 1u));
+        put_chunk(st + (A_KC ? (idx >> 3) * PL_ROW_B + (idx & 7) * 8 : (idx / QA) * MCA + (idx % QA) * 8), PLA, xa[u], all || ((ma >> u) & 1u), f16_sa);
       }
 #pragma unroll
       for (int u = 0; u < NB; ++u) {
         const int idx = tid + NPT * u;
-        put_chunk(st + 3 * PLA + (B_KC ? (idx >> 3) * PL_ROW_B + (idx & 7) * 8 : (idx / QB) * MCB + (idx % QB) * 8), PLB, xb[u], all || ((mb >> u) & 1u));
+        put_chunk(st + 3 * PLA + (B_KC ? (idx >> 3) * PL_ROW_B + (idx & 7) * 8 : (idx / QB) * MCB + (idx % QB) * 8), PLB, xb[u], all || ((mb >> u) & 1u), f16_sb);
       }
     };
     // a k-step inside its segment (uniform test: a scalar branch around VALU + LDS work only) needs no per-chunk select
@@ -1423,7 +1458,39 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
 #define SSC_X3W_MFMA(FA, FB, PA, PB)                                                                                 \
   _Pragma("unroll") for (int mi = 0; mi < 2; ++mi) _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = \
       __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[mi][PA], FB[ni][PB], acc[mi][ni], 0, 0, 0);
+  typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+#define SSC_X3W_MFMA_H(FA, FB, PA, PB)                                                                               \
+  _Pragma("unroll") for (int mi = 0; mi < 2; ++mi) _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = \
+      __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, FA[mi][PA]), __builtin_bit_cast(f16x8, FB[ni][PB]), acc[mi][ni], 0, 0, 0);
   auto compute = [&](const unsigned char* st) __attribute__((always_inline)) {
+    if constexpr (F16) {
+      // planes: 0 = hi, 1 = lo.  Three partial products per accumulator, smallest first (lo*hi, hi*lo, hi*hi); the second k-half's
+      // fragments are requested under the first half's MFMAs
+      bf16x8 fa[2][2][2], fb[2][2][2];  // [kk][tile][plane] (bit patterns of fp16 pairs)
+      auto rda = [&](int kk, int pl) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) fa[kk][t][pl] = frag(st + pl * PLA, A_KC, MCA, wm * 64 + t * 32, kk);
+      };
+      auto rdb = [&](int kk, int pl) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) fb[kk][t][pl] = frag(st + 3 * PLA + pl * PLB, B_KC, MCB, wn * 64 + t * 32, kk);
+      };
+      rda(0, 1); rdb(0, 0); rda(0, 0); rdb(0, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      SSC_X3W_MFMA_H(fa[0], fb[0], 1, 0)
+      __builtin_amdgcn_sched_barrier(0);
+      rda(1, 1); rdb(1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      SSC_X3W_MFMA_H(fa[0], fb[0], 0, 1)
+      __builtin_amdgcn_sched_barrier(0);
+      rda(1, 0); rdb(1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      SSC_X3W_MFMA_H(fa[0], fb[0], 0, 0)
+      SSC_X3W_MFMA_H(fa[1], fb[1], 1, 0)
+      SSC_X3W_MFMA_H(fa[1], fb[1], 0, 1)
+      SSC_X3W_MFMA_H(fa[1], fb[1], 0, 0)
+      return;
+    }
     bf16x8 fa[2][2][3], fb[2][2][3];  // [kk][tile][plane]
     auto rda = [&](int kk, int pl) __attribute__((always_inline)) {
 #pragma unroll
@@ -1469,6 +1536,7 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
     }
   }
 #undef SSC_X3W_MFMA
+#undef SSC_X3W_MFMA_H
 
   // accumulators -> fp32 C tile in LDS (the operand stages are free after the last barrier): row-major [TM][TN + 4]
   float* ct = reinterpret_cast<float*>(lds);
@@ -1499,6 +1567,7 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
       if (grow >= Meff || gcol >= a.N) continue;
       const int rr = (RL && a.crows) ? a.crows[grow] : grow;
       float4 v = *reinterpret_cast<const float4*>(&ct[row * CT_LD + col]);
+      if constexpr (F16) { const float inv = 1.0f / (f16_sa * f16_sb); v.x *= inv; v.y *= inv; v.z *= inv; v.w *= inv; }
       float* dst = out + (size_t)rr * a.ldo + gcol;
       if (wide) {
         if (a.bias) { const float4 b4 = *reinterpret_cast<const float4*>(a.bias + gcol); v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w; }
@@ -1542,7 +1611,7 @@ struct KGroup {
   int first[SSC_GROUP_MAX + 1];
   int gx[SSC_GROUP_MAX], gy[SSC_GROUP_MAX], gz[SSC_GROUP_MAX];
 };
-template <bool A_KC, bool B_KC, bool KG, int TM, int TN, int PF, int NPW = 4>
+template <bool A_KC, bool B_KC, bool KG, int TM, int TN, int PF, int NPW = 4, bool F16 = false>
 __global__ __launch_bounds__(256 + 64 * NPW) void gemm_x3w_kernel(const KGroup g) {
   const int w = blockIdx.x;
   int p = 0;
@@ -1552,7 +1621,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void gemm_x3w_kernel(const KGroup g
   const int local = w - g.first[p];
   const int gx = g.gx[p], gy = g.gy[p], gz = g.gz[p];
   const int x = local % gx, yz = local / gx;
-  x3w_body<A_KC, B_KC, KG, TM, TN, PF, NPW>(g.a[p], x, yz % gy, yz / gy, gx, gy, gz);
+  x3w_body<A_KC, B_KC, KG, TM, TN, PF, NPW, F16>(g.a[p], x, yz % gy, yz / gy, gx, gy, gz);
 }
 
 __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int nslab, size_t slab_stride, int M, int N,
@@ -1630,6 +1699,7 @@ int build_args(const ssc_gemm_desc* d, KArgs& k) {
   k.N = d->N;
   k.mcount = d->m_count; k.arows = d->a_rows; k.crows = d->c_rows;
   k.kcount = d->k_count; k.karows = d->ka_rows; k.kbrows = d->kb_rows;
+  k.a_scale = d->a_scale; k.b_scale = d->b_scale;
   k.steps_total = 0;
   for (int i = 0; i < d->nseg; ++i) {
     const ssc_gemm_seg& s = d->seg[i];
@@ -1665,6 +1735,7 @@ int g_gemm_mode = -1;  // -1: take the default from the environment on first use
 // A sequence-level call (ssc_train_fwd / _bwd, ssc_decode_*) runs under the numerics mode of ITS ssc_model_cfg (gemm_mode field):
 // the calling thread's override, in force while the call issues its launches.  Two engines of one process can so differ.
 thread_local int ssc_tls_gemm_mode = -1;
+thread_local int ssc_tls_gemm_f16 = -1;   // ssc_model_cfg.gemm_mode 3: the wave-specialised 128x128 NT products of this call take the 2xFP16 form
 namespace {
 inline int gemm_mode() {
   if (ssc_tls_gemm_mode >= 0) return ssc_tls_gemm_mode;
@@ -1793,6 +1864,9 @@ int x3w_prepare() {
                      gemm_x3w_kernel<false, false, true, 128, 128, 1, 8>, gemm_x3w_kernel<false, false, false, 128, 128, 2, 8>};
   for (group_fn f : big)
     if (hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, x3w_lds_bytes<128, 128>()) != hipSuccess) return SSC_EHIP;
+  if (hipFuncSetAttribute((const void*)gemm_x3w_kernel<true, true, false, 128, 128, 2, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                          x3w_lds_bytes<128, 128>()) != hipSuccess)
+    return SSC_EHIP;
   group_fn skinny[6] = {gemm_x3w_kernel<true, true, false, 64, 256, 2>, gemm_x3w_kernel<true, false, false, 64, 256, 2>,
                         gemm_x3w_kernel<true, true, false, 64, 256, 3>, gemm_x3w_kernel<true, false, false, 64, 256, 3>,
                         gemm_x3w_kernel<true, true, false, 64, 256, 2, 8>, gemm_x3w_kernel<true, false, false, 64, 256, 2, 8>};
@@ -1801,6 +1875,7 @@ int x3w_prepare() {
   done = true;
   return SSC_OK;
 }
+int g_gemm_f16 = ssc_env_int("SSC_GEMM_F16", 0);   // process default of the 2xFP16 form when no sequence-level call's cfg is in force
 int g_x3w_skinny = ssc_env_int("SSC_X3W_SKINNY", 1);  // 0 off, 1 NT and NN, 2 NN only (hook -11 / -12 / -13)
 int g_x3w_min_n = ssc_env_int("SSC_X3W_MIN_N", 1024);   // narrower products do not fill the chip with 256-column tiles (rocprof: slower than the 64-wide kernels)
 int g_gemm_group = ssc_env_int("SSC_GEMM_GROUP", 1);   // grouped launches of independent minibatch products
@@ -1908,6 +1983,7 @@ int launch(const ssc_gemm_desc* d, KArgs& k, int splits, hipStream_t st) {
     // (below 512 rows - one to four tile rows, split-K - the wave-specialised form wins at every grid size: 59 vs 71 us at 128 x 4800 x 5648)
     if ((g_x3b == 2 || (g_x3b == 1 && (wgs >= 768 || (d->M < 512 && big_tile(d->M, d->N))))) && x3w_span_ok(d) && (!kg || kg_both)) {  // wave-specialised form: 12 waves, 120 KB of dynamic LDS
       group_fn fn = x3w_big_fn(d->a_kc, d->b_kc, kg);
+      if ((ssc_tls_gemm_f16 >= 0 ? ssc_tls_gemm_f16 : g_gemm_f16) && d->a_kc && d->b_kc && !kg && g_x3w_big_npw == 8) fn = gemm_x3w_kernel<true, true, false, 128, 128, 2, 8, true>;
       SSC_TRY(x3w_prepare());
       KGroup g1;
       group_of_one(g1, k, grid);
@@ -2348,6 +2424,7 @@ const DebugKey g_debug_keys[] = {
     {"img_mfma", &ssc_g_img_mfma},             // decode: the image cell's table contraction on the fp32 matrix cores (1 | 0 = VALU form)   (SSC_IMG_MFMA)
     {"dec_ungathered", &ssc_g_dec_ungathered}, // decode: states left in the previous step's row order, read through the parent lists (1 | 0)   (SSC_DEC_UNGATHERED)
     {"dec_att_table", &ssc_g_dec_att_table},   // decode: attended-feature term of the decoder gates from a per-image table (1 | 0)   (SSC_DEC_ATT_TABLE)
+    {"gemm_f16", &g_gemm_f16},       // op-level products (ssc_gemm outside a sequence-level call): 1 = the wave-specialised 128x128 NT form takes the 2xFP16 split (what ssc_model_cfg.gemm_mode 3 selects per call)
     {"big_min_m", &g_big_min_m},     // rows from which a product with N >= 512 takes 128x128 tiles (65; 512 = the behaviour until late in round 2)   (SSC_BIG_MIN_M)
 };
 }  // namespace

@@ -3,6 +3,8 @@
 // axis and 64-lane shuffle reductions.  Reference citations are on the C entry points in ssc.h.
 #include <type_traits>
 
+#include <algorithm>
+
 #include "ssc_common.h"
 
 thread_local int ssc_tls_hip_error = 0;
@@ -1446,6 +1448,44 @@ extern "C" int ssc_colsum2(const float* X, int ldx, int rows, int N, const float
 extern "C" int ssc_colsum(const float* X, int ldx, int rows, int N, const float* wrow, float* out, int out_stride,
                           int accumulate, void* stream) {
   return ssc_colsum2(X, ldx, rows, N, wrow, out, out_stride, nullptr, accumulate, nullptr, stream);
+}
+
+namespace {
+// |x| maxima as unsigned bit patterns (non-negative floats order like their bit patterns): one atomicMax per wave
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, size_t rows, int cols, size_t ld,
+                                                     unsigned* __restrict__ out) {
+  float m = 0.f;
+  const size_t n = rows * (size_t)cols;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = i / cols;
+    m = fmaxf(m, fabsf(x[r * ld + (i - r * cols)]));
+  }
+  m = ssc_wave_max(m);
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
+}
+__global__ void pow2_scale_kernel(const unsigned* __restrict__ mx, int target_log2, float* __restrict__ out, int combine) {
+  const float m = __uint_as_float(*mx);
+  float sc = 1.f;
+  if (m > 0.f && m < INFINITY) {
+    int e;
+    (void)frexpf(m, &e);           // m = f 2^e, f in [0.5, 1): m <= 2^e
+    sc = ldexpf(1.f, target_log2 - e);
+  }
+  *out = combine ? fminf(*out, sc) : sc;
+}
+}  // namespace
+
+extern "C" int ssc_pow2_scale(const float* x, size_t rows, int cols, size_t ld, int target_log2, float* out, int combine,
+                              float* scratch, void* stream) {
+  if (!x || !out || !scratch || rows == 0 || cols <= 0 || ld < (size_t)cols) return SSC_EINVAL;
+  if (hipMemsetAsync(scratch, 0, sizeof(float), S(stream)) != hipSuccess) return SSC_EHIP;
+  const size_t n = rows * (size_t)cols;
+  const int grid = (int)std::min<size_t>((n + 1023) / 1024, 2048);
+  SSC_LAUNCH(absmax_kernel, dim3(grid < 1 ? 1 : grid), dim3(256), 0, S(stream), x, rows, cols, ld, reinterpret_cast<unsigned*>(scratch));
+  SSC_CHECK_LAUNCH();
+  SSC_LAUNCH(pow2_scale_kernel, dim3(1), dim3(1), 0, S(stream), reinterpret_cast<const unsigned*>(scratch), target_log2, out, combine);
+  SSC_CHECK_LAUNCH();
+  return SSC_OK;
 }
 
 extern "C" int ssc_copy_strided(const float* src, size_t stride, int n, float* dst, void* stream) {

@@ -100,11 +100,13 @@ int ssc_decode_att_table_enabled();   // the "dec_att_table" switch (decode.hip)
 // numerics mode of the calling thread's current sequence-level call (ssc_model_cfg.gemm_mode: 0 = the process default set by
 // ssc_set_gemm_mode, 1 = 3xBF16, 2 = exact-fp32 MFMA); -1 = none in force
 extern thread_local int ssc_tls_gemm_mode;
+extern thread_local int ssc_tls_gemm_f16;
 struct SscGemmModeScope {
-  int prev;
-  explicit SscGemmModeScope(const ssc_model_cfg* c) : prev(ssc_tls_gemm_mode) {
-    if (c && c->gemm_mode == 1) ssc_tls_gemm_mode = 1;
+  int prev, prev16;
+  explicit SscGemmModeScope(const ssc_model_cfg* c) : prev(ssc_tls_gemm_mode), prev16(ssc_tls_gemm_f16) {
+    if (c && (c->gemm_mode == 1 || c->gemm_mode == 3)) ssc_tls_gemm_mode = 1;
     else if (c && c->gemm_mode == 2) ssc_tls_gemm_mode = 0;
+    if (c && c->gemm_mode != 0) ssc_tls_gemm_f16 = c->gemm_mode == 3 ? 1 : 0;   // (0: the process default stays in force)
   }
-  ~SscGemmModeScope() { ssc_tls_gemm_mode = prev; }
+  ~SscGemmModeScope() { ssc_tls_gemm_mode = prev; ssc_tls_gemm_f16 = prev16; }
 };

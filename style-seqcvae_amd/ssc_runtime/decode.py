@@ -26,11 +26,21 @@ class ImageContext:
 
 
 class DecodeEngine:
+    DEFAULT_GEMM_MODE = 3
+
     def __init__(self, dims: ModelDims, params_struct_fn: Callable[[], "_lib.Params"], device):
         self.lib = _lib.load()
         self.dims = dims
         self.device = torch.device(device)
         self._cfg = dims.cfg()
+        # numerics of the decode's products (ssc_model_cfg.gemm_mode).  Default 3: 3xBF16 everywhere except the large (>= 768
+        # workgroups of 128x128) NT products - the per-step gate / vocabulary products of a 10000-row call, 80 % of its time -, which
+        # take the 2xFP16 form: two fp16 pieces per fp32 operand (scaled by powers of two measured per image context), three
+        # partial products instead of six on the matrix cores, 21-22 significant bits per operand instead of 24 (within 2e-6 of
+        # sum|a||b| against float64, tests/test_gemm_gpu.py; the reference fixtures of the eval path hold at 1e-4 / identical
+        # captions).  1 = 3xBF16 only, 2 = exact-fp32 MFMA; an engine-wide dims.gemm_mode other than 0 wins.
+        if self._cfg.gemm_mode == 0:
+            self._cfg.gemm_mode = self.DEFAULT_GEMM_MODE
         self._params = params_struct_fn
         self._ws = None
         self._ws_key = None

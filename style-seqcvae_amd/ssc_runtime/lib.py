@@ -30,7 +30,7 @@ class GemmDesc(C.Structure):
     _fields_ = [("seg", GemmSeg * SSC_MAX_SEG), ("nseg", C.c_int), ("M", C.c_int), ("N", C.c_int), ("a_kc", C.c_int),
                 ("b_kc", C.c_int), ("C", vp), ("ldc", C.c_int), ("bias", vp), ("accumulate", C.c_int),
                 ("splits", C.c_int), ("workspace", vp), ("workspace_floats", C.c_size_t), ("m_count", vp), ("a_rows", vp),
-                ("c_rows", vp), ("k_count", vp), ("ka_rows", vp), ("kb_rows", vp)]
+                ("c_rows", vp), ("k_count", vp), ("ka_rows", vp), ("kb_rows", vp), ("a_scale", vp), ("b_scale", vp)]
 
 
 class LstmFwdDesc(C.Structure):
@@ -139,6 +139,7 @@ SYMBOLS = {
     "ssc_arch": (C.c_char_p, []),
     "ssc_gemm": (_i, [C.POINTER(GemmDesc), vp]),
     "ssc_gemm_auto_splits": (_i, [_i, _i, _i]),
+    "ssc_pow2_scale": (_i, [vp, _sz, _i, _sz, _i, vp, _i, vp, vp]),
     "ssc_set_gemm_mode": (_i, [_i]),
     "ssc_feat_prep": (_i, [vp, _i, _i, _i, vp, vp, vp]),
     "ssc_prep_tokens": (_i, [vp, _i, _i, _i, _i, vp, vp, vp, vp]),

@@ -285,3 +285,60 @@ def test_minibatch_products_wave_specialised(kind, N, Ks, splits, form):
         assert err <= (2e-6 if (form != 0 or kind == "NT") else 4e-6), err
     finally:
         lib.ssc_debug_set(b"x3w_skinny", 1)
+
+
+@pytest.mark.parametrize("M,N,Ks,scale_a,scale_b", [(2560, 4800, [1200, 1200], 1.0, 0.03), (5000, 10000, [1200], 0.5, 0.03),
+                                                     (2048, 2048, [520, 128], 4.0, 1e-3), (1536, 1536, [1000], 1e-3, 1e-4),
+                                                     (1280, 1024, [64], 30.0, 30.0)])
+def test_nt_split_fp16_form_is_fp32_accurate(M, N, Ks, scale_a, scale_b):
+    """The 2xFP16 form of the wave-specialised 128x128 NT kernel (ssc_model_cfg.gemm_mode 3; op level: ssc_debug_set("gemm_f16")):
+    two fp16 pieces per fp32 operand (hi, lo by truncation: 21-22 significant bits), three partial products on
+    v_mfma_f32_32x32x16_f16, fp32 accumulate, operands scaled by powers of two into the middle of the fp16 range
+    (ssc_pow2_scale; without it an operand of magnitude 1e-3 keeps 2^-25 ABSOLUTE precision in its lo piece: 1e-5 of sum|a||b|).
+    Against float64: within 2e-6 of sum|a||b|, the bound the 3xBF16 kernel is held to, over operand magnitudes from 1e-4 to 30;
+    exact on small integers."""
+    lib = L.load()
+    g = torch.Generator().manual_seed(M + N)
+    As = [torch.randn(M, K, generator=g) * scale_a for K in Ks]
+    Bs = [torch.randn(N, K, generator=g) * scale_b for K in Ks]
+    want = ref(As, Bs, 1, 1)
+    bound = sum(a.abs().double() @ b.abs().double().t() for a, b in zip(As, Bs))
+    dA, dB = [dev(a) for a in As], [dev(b) for b in Bs]
+    # the operands' power-of-two scales (largest magnitude -> [2^12, 2^13]), as ssc_decode_prepare measures them
+    sc = torch.zeros(3, device="cuda")
+    for i, ts in ((0, dA), (1, dB)):
+        for j, t in enumerate(ts):
+            lib.ssc_pow2_scale(L.ptr(t), t.size(0), t.size(1), t.stride(0), 13, L.ptr(sc[i:i + 1]), 1 if j else 0, L.ptr(sc[2:3]), L.stream_ptr())
+    sa, sb = float(sc[0]), float(sc[1])
+    for v, ts in ((sa, As), (sb, Bs)):
+        top = max(float(t.abs().max()) for t in ts) * v
+        assert 4096.0 <= top <= 8192.0 and v == 2.0 ** round(torch.log2(torch.tensor(v)).item())
+    outs = {}
+    for f16 in (0, 1):
+        lib.ssc_debug_set(b"gemm_f16", f16)
+        lib.ssc_debug_set(b"large_form", 2)      # always the wave-specialised form
+        try:
+            out = torch.full((M, N), float("nan"), device="cuda")
+            gemm([(a, a.stride(0), b, b.stride(0), K) for a, b, K in zip(dA, dB, Ks)], M, N, 1, 1, out, splits=1,
+                 compact={"a_scale": sc[0:1], "b_scale": sc[1:2]})
+            torch.cuda.synchronize()
+            outs[f16] = out.cpu().double()
+        finally:
+            lib.ssc_debug_set(b"gemm_f16", 0)
+            lib.ssc_debug_set(b"large_form", 1)
+    e16 = ((outs[1] - want).abs() / bound).max().item()
+    e3 = ((outs[0] - want).abs() / bound).max().item()
+    assert e3 < 2e-6 and e16 < 2e-6, (e3, e16)
+    assert not torch.equal(outs[0], outs[1]) or max(Ks) <= 64      # (the two forms really are different kernels)
+    # small integers: every piece and partial sum exact
+    Ai = torch.randint(-5, 6, (M, Ks[0]), generator=g).float()
+    Bi = torch.randint(-5, 6, (N, Ks[0]), generator=g).float()
+    lib.ssc_debug_set(b"gemm_f16", 1)
+    lib.ssc_debug_set(b"large_form", 2)
+    try:
+        out = torch.empty(M, N, device="cuda")
+        gemm([(dev(Ai), Ks[0], dev(Bi), Ks[0], Ks[0])], M, N, 1, 1, out, splits=1)
+        assert torch.equal(out.cpu(), Ai @ Bi.t())
+    finally:
+        lib.ssc_debug_set(b"gemm_f16", 0)
+        lib.ssc_debug_set(b"large_form", 1)
