@@ -90,7 +90,7 @@ def sq(sq_csv, grbm_csv, stats_csv, out):
     for r in csv.DictReader(open(stats_csv)):
         dur[short(r["Name"])] = (float(r["TotalDurationNs"]), int(r["Calls"]))
     with open(out, "w") as f:
-        f.write("kernel,dispatches,avg_us,bf16_mfma_TFLOPs,frac_of_2500TF_bf16_peak,f32_mfma_TFLOPs,mfma_busy_cycles_per_wave_cycle,"
+        f.write("kernel,dispatches,avg_us,bf16_or_f16_mfma_TFLOPs,frac_of_2500TF_16bit_peak,f32_mfma_TFLOPs,mfma_busy_cycles_per_wave_cycle,"
                 "valu_insts_per_dispatch,effective_clock_GHz\n")
         rows = []
         for k, c in acc.items():
@@ -98,7 +98,8 @@ def sq(sq_csv, grbm_csv, stats_csv, out):
                 continue
             disp = max(n[k].values())
             t_ns = dur[k][0] / dur[k][1] * disp          # time of `disp` dispatches at the stats pass's average duration
-            bf = c.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0.0) * 512.0 / t_ns / 1e3
+            # (16-bit matrix work: bf16 and, for the 2xFP16 form of round 4, fp16 - the same pipe and the same 2.5 PFLOP/s dense peak)
+            bf = (c.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0.0) + c.get("SQ_INSTS_VALU_MFMA_MOPS_F16", 0.0)) * 512.0 / t_ns / 1e3
             f32 = c.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0.0) * 512.0 / t_ns / 1e3
             wave = c.get("SQ_WAVE_CYCLES", 0.0) * 4.0    # quad-cycles -> cycles (MI355X_MICROARCH.md cycle-constants table)
             busy = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / wave if wave else 0.0

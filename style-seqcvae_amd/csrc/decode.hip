@@ -108,7 +108,7 @@ struct Seg {
 // recurrent states, z, the projected hidden state lie in [-1, 1] or a few units around it -> a constant 2^6; everything that comes
 // from data or from the checkpoint (weights, embedding table, region features) is measured once per image context (ssc_pow2_scale,
 // largest magnitude -> [2^12, 2^13]).  One pair per product: operands of one product that differ in scale share the smaller factor.
-enum { SC_ACT = 0, SC_ACTF, SC_ATTW, SC_Q, SC_DEC, SC_OUT, SC_PROJ, SC_EMB, SC_FEAT, SC_WV, SC_TMP, SC_COUNT };
+enum { SC_ACT = 0, SC_ACTF, SC_ATTW, SC_Q, SC_DEC, SC_OUT, SC_PROJ, SC_EMB, SC_WV, SC_FEAT, SC_TMP, SC_COUNT };   // (SC_ATTW .. SC_WV: functions of the parameters alone)
 struct DecScales {
   const float* base;   // nullptr: no scales (every factor 1)
   const float* at(int i) const { return base ? base + i : nullptr; }
@@ -462,6 +462,17 @@ extern "C" int ssc_decode_prepare_from(const ssc_model_cfg* cfg, const ssc_param
     SSC_TRY(ssc_fill(SC + SC_ACTF, 1, 64.f, st));
     SSC_TRY(ssc_pow2_scale(feats, (size_t)nimg * R, F, F, 13, SC + SC_FEAT, 0, tmp, st));
     SSC_TRY(ssc_pow2_scale(feats, (size_t)nimg * R, F, F, 13, SC + SC_ACTF, 1, tmp, st));   // products that mix states and attended features
+  }
+  if (cfg->gemm_mode == 3 && prev_imgbuf) {
+    // the weights' scales depend on the parameters alone: an earlier context of the same, unchanged parameters hands them over
+    // (the caller's promise, as for the per-token gate table below) - measuring them reads every weight once, ~1 ms at C4's sizes
+    const ImgLayout pl0 = img_layout(cfg, prev_nimg, prev_R);
+    if (hipMemcpyAsync(SC + SC_ATTW, (const float*)prev_imgbuf + pl0.scales + SC_ATTW, (size_t)(SC_FEAT - SC_ATTW) * sizeof(float),
+                       hipMemcpyDeviceToDevice, st) != hipSuccess)
+      return SSC_EHIP;
+  } else if (cfg->gemm_mode == 3) {
+    const int H = cfg->H;
+    float* tmp = SC + SC_TMP;
     SSC_TRY(ssc_pow2_scale(p->att_w_ih, H4, E + F + 2 * H, p->ld_att_w_ih, 12, SC + SC_ATTW, 0, tmp, st));
     SSC_TRY(ssc_pow2_scale(p->att_w_hh, H4, H, p->ld_att_w_hh, 12, SC + SC_ATTW, 1, tmp, st));
     SSC_TRY(ssc_pow2_scale(p->dec_w_ih, H4, F + 2 * H + cfg->S + cfg->Z, p->ld_dec_w_ih, 12, SC + SC_DEC, 0, tmp, st));

@@ -1151,6 +1151,10 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
   constexpr int NTHR = 256 + NPT;                // workgroup size: 4 consumer waves + NPW producer waves
   constexpr int NA = TM * 8 / NPT, NB = TN * 8 / NPT;   // float4 chunks per producer thread and k-step
   constexpr int QA = TM / 4, QB = TN / 4;        // float4 per k-row of an m/n-contiguous tile
+  // (Tried in round 4: dealing a half-wave the plane rows {r, r+4, r+8, r+12} - 16 banks apart, so that a ds_write_b64 of the
+  // 80-byte plane rows touches every bank once instead of wrapping the fourth consecutive row onto the first - made the 128x128
+  // products 5-18 % SLOWER (10000 x 10000 x 1200, 2xFP16 form: 846 -> 1003 us): consecutive rows per wave stay.)
+  auto kc_row = [&](int t, int u, int) __attribute__((always_inline)) -> int { return (t + NPT * u) >> 3; };
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int wave = threadIdx.x >> 6;
   const bool producer = wave >= 4;
@@ -1211,7 +1215,7 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
       for (int u = 0; u < NA; ++u) {
         const int idx = tid + NPT * u;
         if constexpr (A_KC) {
-          int r = min(m0 + (idx >> 3), Meff - 1);
+          int r = min(m0 + kc_row(tid, u, NA), Meff - 1);
           if constexpr (RL) { if (a.arows) r = a.arows[r]; }
           za[u] = (unsigned)r * lda4;
           oa[u] = za[u] + 16u * (idx & 7);
@@ -1230,7 +1234,7 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
       for (int u = 0; u < NB; ++u) {
         const int idx = tid + NPT * u;
         if constexpr (B_KC) {
-          zb[u] = (unsigned)min(n0 + (idx >> 3), a.N - 1) * ldb4;
+          zb[u] = (unsigned)min(n0 + kc_row(tid, u, NB), a.N - 1) * ldb4;
           ob[u] = zb[u] + 16u * (idx & 7);
         } else {
           zb[u] = 4u * (unsigned)min(n0 + 4 * (idx % QB), a.N - 4);
@@ -1360,12 +1364,12 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
 #pragma unroll
       for (int u = 0; u < NA; ++u) {
         const int idx = tid + NPT * u;
-        put_chunk(st + (A_KC ? (idx >> 3) * PL_ROW_B + (idx & 7) * 8 : (idx / QA) * MCA + (idx % QA) * 8), PLA, xa[u], all || ((ma >> u) & 1u), f16_sa);
+        put_chunk(st + (A_KC ? kc_row(tid, u, NA) * PL_ROW_B + (idx & 7) * 8 : (idx / QA) * MCA + (idx % QA) * 8), PLA, xa[u], all || ((ma >> u) & 1u), f16_sa);
       }
 #pragma unroll
       for (int u = 0; u < NB; ++u) {
         const int idx = tid + NPT * u;
-        put_chunk(st + 3 * PLA + (B_KC ? (idx >> 3) * PL_ROW_B + (idx & 7) * 8 : (idx / QB) * MCB + (idx % QB) * 8), PLB, xb[u], all || ((mb >> u) & 1u), f16_sb);
+        put_chunk(st + 3 * PLA + (B_KC ? kc_row(tid, u, NB) * PL_ROW_B + (idx & 7) * 8 : (idx / QB) * MCB + (idx % QB) * 8), PLB, xb[u], all || ((mb >> u) & 1u), f16_sb);
       }
     };
     // a k-step inside its segment (uniform test: a scalar branch around VALU + LDS work only) needs no per-chunk select
@@ -1981,9 +1985,12 @@ int launch(const ssc_gemm_desc* d, KArgs& k, int splits, hipStream_t st) {
     // 1520 tiles, +10 % tokens/s).  g_x3b: 1 = choose by grid size, 2 = always wave-specialised, 3 = always 4-wave.
     const long wgs = (long)grid.x * grid.y * grid.z;
     // (below 512 rows - one to four tile rows, split-K - the wave-specialised form wins at every grid size: 59 vs 71 us at 128 x 4800 x 5648)
-    if ((g_x3b == 2 || (g_x3b == 1 && (wgs >= 768 || (d->M < 512 && big_tile(d->M, d->N))))) && x3w_span_ok(d) && (!kg || kg_both)) {  // wave-specialised form: 12 waves, 120 KB of dynamic LDS
+    // (2xFP16 numerics requested and applicable: the wave-specialised form at every grid size - its F16 variant is 1.5x the 3xBF16
+    // one, which outweighs what the 4-wave kernel gains on grids below three rounds)
+    const bool f16 = (ssc_tls_gemm_f16 >= 0 ? ssc_tls_gemm_f16 : g_gemm_f16) && d->a_kc && d->b_kc && !kg && g_x3w_big_npw == 8 && g_x3b != 3;
+    if ((g_x3b == 2 || (g_x3b == 1 && (f16 || wgs >= 768 || (d->M < 512 && big_tile(d->M, d->N))))) && x3w_span_ok(d) && (!kg || kg_both)) {  // wave-specialised form: 12 waves, 120 KB of dynamic LDS
       group_fn fn = x3w_big_fn(d->a_kc, d->b_kc, kg);
-      if ((ssc_tls_gemm_f16 >= 0 ? ssc_tls_gemm_f16 : g_gemm_f16) && d->a_kc && d->b_kc && !kg && g_x3w_big_npw == 8) fn = gemm_x3w_kernel<true, true, false, 128, 128, 2, 8, true>;
+      if (f16) fn = gemm_x3w_kernel<true, true, false, 128, 128, 2, 8, true>;
       SSC_TRY(x3w_prepare());
       KGroup g1;
       group_of_one(g1, k, grid);
