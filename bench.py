@@ -159,10 +159,11 @@ def attention_roofline(device):
 
 
 def decode_roofline(dec, feats, senti, c):
-    """bf16-MFMA roofline of ONE beam-search call (100 images x 20 samples x beam 5 = 10000 rows, early stop off): a hipEvent pair
+    """16-bit-MFMA roofline of ONE beam-search call (100 images x 20 samples x beam 5 = 10000 rows, early stop off): a hipEvent pair
     around every GEMM launch (ssc_prof_enable); the large products (M >= 512 rows: attention-LSTM gates, decoder gates,
-    vocabulary head of every step + the per-call tables) run 6 bf16 MFMA passes per fp32 product (3xBF16), so
-    achieved = 6 * sum 2MNK / sum duration against the 2.5 PFLOP/s dense bf16 peak."""
+    vocabulary head of every step + the per-call tables) run `passes` matrix passes per fp32 product - 3 in the decode's default
+    2xFP16 form (two fp16 pieces per operand, three partial products), 6 in the 3xBF16 form -, so
+    achieved = passes * sum 2MNK / sum duration against the 2.5 PFLOP/s dense 16-bit (bf16 = fp16) peak."""
     from ssc_runtime import lib as L
     from ssc_runtime.inference import diverse_decode
     lib = L.load()
@@ -182,7 +183,8 @@ def decode_roofline(dec, feats, senti, c):
         return None
     ms = sum(r[5] for r in big)
     flops = sum(r[7] for r in big)
-    tf6 = 6.0 * flops / (ms * 1e-3) / 1e12
+    passes = 3.0 if dec._cfg.gemm_mode == 3 else 6.0
+    tf6 = passes * flops / (ms * 1e-3) / 1e12
     top = {}
     for r in big:
         e = top.setdefault((int(r[1]), int(r[2]), int(r[3])), [0, 0.0, 0.0])
@@ -190,9 +192,11 @@ def decode_roofline(dec, feats, senti, c):
         e[1] += r[5]
         e[2] += r[7]
     shapes = [{"M": k[0], "N": k[1], "K": k[2], "launches": v[0], "avg_us": v[1] / v[0] * 1e3,
-               "bf16_TFLOPs": 6.0 * v[2] / (v[1] * 1e-3) / 1e12} for k, v in sorted(top.items(), key=lambda kv: -kv[1][1])[:4]]
-    return {"bound": "mfma", "kernel": "large 3xBF16 GEMMs of one beam-search call (gemm_x3w_kernel<128x128> / gemm_x3b_kernel<128x128>; "
-            "6 bf16 MFMA passes per fp32 product)", "achieved": tf6, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
+               "mfma_TFLOPs": passes * v[2] / (v[1] * 1e-3) / 1e12} for k, v in sorted(top.items(), key=lambda kv: -kv[1][1])[:4]]
+    return {"bound": "mfma", "kernel": ("large products of one beam-search call, 2xFP16 form (gemm_x3w_kernel<NT,128x128,F16>: 3 fp16 MFMA passes "
+            "per fp32 product)" if passes == 3.0 else "large 3xBF16 GEMMs of one beam-search call (gemm_x3w_kernel<128x128> / "
+            "gemm_x3b_kernel<128x128>; 6 bf16 MFMA passes per fp32 product)"), "passes_per_fp32_product": passes,
+            "achieved": tf6, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
             "frac": tf6 / MFMA_BF16_PEAK_TF, "traffic": None, "fp32_equivalent_TFLOPs": flops / (ms * 1e-3) / 1e12,
             "launches_per_call": len(big), "gemm_ms_per_call": ms, "call_ms_with_event_overhead": call_ms,
             "share_of_call_time": ms / call_ms, "top_shapes": shapes}
@@ -252,6 +256,25 @@ def measure_decode(model, c, rank, world, device, images, warmup):
             results[early][k] += v
         passes.append({"early_stop": early, "tokens_per_s": tokens / el})
     droof = decode_roofline(dec, feats[0], senti, c) if rank == 0 else None
+    # the same calls with every product in the 3xBF16 form (the decode's numerics until round 4): one pass, rank 0's own rate
+    bf16x3 = None
+    if rank == 0:
+        mode0 = dec._cfg.gemm_mode
+        dec._cfg.gemm_mode = 1
+        dec._last_ctx = None
+        try:
+            diverse_decode(dec, feats[0], senti, 20, 5, c["L"], 1, early_stop=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            tk = 0
+            for i in range(n_chunks):
+                pred, _ = diverse_decode(dec, feats[i % len(feats)], senti, 20, 5, c["L"], 1, early_stop=True)
+                tk += count_tokens(pred, 1)
+            torch.cuda.synchronize()
+            bf16x3 = {"tokens_per_s_one_gpu": tk / (time.perf_counter() - t0)}
+        finally:
+            dec._cfg.gemm_mode = mode0
+            dec._last_ctx = None
     dec.weights_frozen = False       # (the train leg that may follow changes the weights)
     dec._last_ctx = None
     if was_training:
@@ -264,6 +287,11 @@ def measure_decode(model, c, rank, world, device, images, warmup):
     return {"metric": "decode tokens/sec (beam 5 x 20 latent samples per image)", "value": tokens / el, "unit": "tokens/s",
             "n_gpus": world, "steps": n_timed, "warmup": warmup, "ms_per_step": el / n_timed * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "dtype_detail": "fp32 operands and results; the large per-step products (>= 512 rows) via a 2 x fp16 split of every fp32 operand "
+                            "(power-of-two scaled per image context, 21-22 significant bits, three partial products on the fp16 matrix "
+                            "cores, fp32 accumulate; ssc_model_cfg.gemm_mode 3), smaller products 3 x bf16 split (24 bits, six products), "
+                            "pointwise exact fp32; reference fixtures hold at 1e-4.  bf16x3_mode = the same calls with gemm_mode 1",
+            "bf16x3_mode": bf16x3,
             "config": {"workload": "C4 diverse decode: %d images (decoded twice: two alternating passes per leg), 36x2048 feats, beam 5 "
                                    "(per-node 2), N_Z=20, max 20 steps, trivial FSM, random-init weights" % (n_chunks * chunk * world),
                        "images_per_call": chunk, "rows_per_call": chunk * 100},
@@ -810,7 +838,7 @@ def main():
     if rank == 0 and dres is not None:
         result["decode_tokens_per_s"] = dres["value"]
         result["decode"] = {k: dres[k] for k in ("metric", "value", "unit", "steps", "ms_per_step", "config", "roofline", "captions_per_s",
-                                                 "row_steps_per_s", "early_stop_disabled", "passes")}
+                                                 "row_steps_per_s", "early_stop_disabled", "passes", "dtype_detail", "bf16x3_mode")}
     if rank == 0 and result is not None and not args.timed_only:
         result["dtype_detail"] = ("fp32 operands and results; products of 16-byte aligned operands via a 3 x bf16 split of every fp32 "
                                   "operand on the bf16 matrix cores (six partial products of order <= 2, fp32 accumulate: error ~ one "

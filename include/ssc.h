@@ -81,6 +81,12 @@ typedef struct {
    * Choose them so that the operands' largest magnitudes land near 2^6 .. 2^13 (ssc_pow2_scale): fp16 overflows at 65504, and an
    * entry whose lo piece is below 2^-14 keeps an absolute precision of 2^-25 only.  NULL = 1. */
   const float* a_scale; const float* b_scale;
+  /* Optional: instead of C (which may then be NULL), every (row, 128-column tile) leaves a record of 6 floats at
+   * topk_part[(row * ceil(N / 128) + tile) * 6]: the tile's maximum, sum of exp(x - maximum), best value, its column (int bits),
+   * second best, its column; x includes the bias; ties go to the lower column; c_rows applies to the record's row.  The
+   * vocabulary head of a decode step then never writes its (rows, V) logits: ssc_beam_step_parts selects from the records.
+   * NT products with 16-byte aligned operands under the 3xBF16 / 2xFP16 numerics only (SSC_EINVAL otherwise). */
+  float* topk_part;
 } ssc_gemm_desc;
 
 /* out[0] = 2^(target_log2 - ceil(log2(max |x|))) over the rows x cols block x (ld), a power of two that brings the block's largest
@@ -477,6 +483,9 @@ typedef struct {
   const float* prior_mean;   /* optional (G, Z) ld Z: the caller's own prior mean instead of pm_scale * sentiment (_decode_step's
                               * prior_mean argument, updown_captioner.py:371-381); ignored with kld_mode 2, whose cell replaces it */
   const float* prior_var;    /* optional (G, Z) ld Z: the caller's own prior variance instead of cfg->prior_var */
+  float* topk_part;          /* optional (G, ceil(V / 128), 6): the vocabulary head leaves per-tile records (ssc_gemm_desc.topk_part) here INSTEAD
+                              * of writing log_probs (which may then be NULL); untied head, 16-byte aligned H, not under the exact-fp32
+                              * numerics (SSC_EINVAL otherwise).  For ssc_beam_step_parts */
 } ssc_decode_step_desc;
 /* 1 if a step of G rows in groups of `group` (0: group size not known yet - any divisor of G above 1 will do) over an image context of
  * nimg images with this att_table mode can take un-gathered states */
@@ -572,6 +581,12 @@ typedef struct {
 } ssc_beam_desc;
 int ssc_beam_first_fsm(const ssc_beam_desc* d, void* stream);
 int ssc_beam_step_fsm(const ssc_beam_desc* d, void* stream);
+/* ssc_beam_step_fsm for the trivial machine (S = 1, fsm NULL) and per_node <= 2 from the RECORDS a vocabulary head launched with
+ * ssc_gemm_desc.topk_part left (rows B*beam, ceil(V / 128) tiles of 6 floats each) instead of from the (rows, V) logits: the
+ * row's log-sum-exp is combined from the tiles' partials, its best tokens from the tiles' best two.  Same selections as
+ * ssc_beam_step_fsm on the logits unless two candidates collide after the subtraction of the log-sum-exp (which here is
+ * summed in tile order); log-probs agree to rounding (~1e-6).  d->scores is not read. */
+int ssc_beam_step_parts(const ssc_beam_desc* d, const float* parts, void* stream);
 /* back-trace with the step count taken from ctl[0] on the device: out (B,SB,max_steps); columns >= ctl[0] are filled with end_index */
 int ssc_beam_backtrace_ctl(const int64_t* preds, const int64_t* backptrs, const int* ctl, int max_steps, int B, int SB,
                            int end_index, int64_t* out, void* stream);

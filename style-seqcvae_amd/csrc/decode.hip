@@ -429,6 +429,8 @@ __global__ void dec_add2d_kernel(const float* __restrict__ a, int lda, const flo
 }  // namespace
 
 int ssc_decode_att_table_enabled() { return ssc_g_dec_att_table != 0; }
+int ssc_g_dec_parts = ssc_env_int("SSC_DEC_PARTS", 1);   // ssc_debug_set("dec_parts"): 0 = the searches of ssc_decode_search always write logits
+int ssc_decode_parts_enabled() { return ssc_g_dec_parts != 0; }
 
 extern "C" size_t ssc_decode_image_bytes(const ssc_model_cfg* cfg, int nimg, int R) {
   if (!cfg || nimg <= 0 || R <= 0) return 0;
@@ -696,6 +698,15 @@ extern "C" int ssc_decode_step(const ssc_model_cfg* cfg, const ssc_params* p, co
     else SSC_TRY(ssc_lstm_fwd(&f, st));
   }
   // vocabulary log-probabilities (updown_captioner.py:444-450); skipped when only the cell output is wanted
+  if (d->topk_part) {   // records per (row, 128-column tile) instead of the (G, V) logits (ssc_beam_step_parts selects from them)
+    if (cfg->tied || cfg->gemm_mode == 2) return SSC_EINVAL;
+    ssc_gemm_desc g;
+    fill_desc(g, {{d->hd_out, H, p->out_w, p->ld_out_w, H}}, G, V);
+    g.bias = p->out_b; g.splits = 1; g.topk_part = d->topk_part;
+    g.a_scale = sc.at(SC_ACT); g.b_scale = sc.at(SC_OUT);
+    if (live) { g.m_count = lcount; g.a_rows = lrows; g.c_rows = lrows; }
+    return ssc_gemm(&g, st);
+  }
   if (!d->log_probs) return SSC_OK;
   if (cfg->tied) {
     SSC_TRY(gemm_nt(st, slabs, l.slab_floats, {{d->hd_out, H, p->proj_w, p->ld_proj_w, H}}, G, E, W + l.proj, l.Ep, nullptr,

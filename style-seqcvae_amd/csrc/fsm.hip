@@ -312,6 +312,47 @@ __global__ __launch_bounds__(256) void beam_row_fsm_kernel(const float* __restri
   }
 }
 
+// later steps, part A for the trivial machine when the vocabulary head left RECORDS instead of logits (ssc_gemm_desc.topk_part: per
+// row and 128-column tile the maximum, sum exp(x - maximum) and the two best columns): one wave per row combines the tiles' partials
+// into the row's log-sum-exp and picks the per_node (<= 2) best columns - the top-k of a row is the top-k of its tiles' top-k.
+// Same order as everywhere: value descending, token ascending.  (cbs.py:177-209 with an all-ones mask.)
+__global__ __launch_bounds__(256) void beam_rows_parts_kernel(const float* __restrict__ parts, int ntn,
+                                                              const int64_t* __restrict__ last_pred, int G, int per_node,
+                                                              int end_index, float* __restrict__ sval, int64_t* __restrict__ sidx) {
+  const int g = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (g >= G) return;
+  const size_t base = (size_t)g * per_node;   // scratch layout (b, i, s, k, n) with S = 1
+  if (last_pred[g] == end_index) {   // an ended beam emits END at +0; everything else is -inf (lowest tokens first)
+    if (lane < per_node) {
+      int tok = end_index;
+      if (lane > 0) { tok = lane - 1; if (tok >= end_index) ++tok; }
+      sval[base + lane] = lane == 0 ? 0.f : -INFINITY;
+      sidx[base + lane] = tok;
+    }
+    return;
+  }
+  const float* p = parts + (size_t)g * ntn * 6;
+  float mx = -INFINITY;
+  for (int t = lane; t < ntn; t += 64) mx = fmaxf(mx, p[t * 6]);
+  mx = ssc_wave_max(mx);
+  float se = 0.f;
+  for (int t = lane; t < ntn; t += 64) se += p[t * 6 + 1] * expf(p[t * 6] - mx);
+  se = ssc_wave_sum(se);
+  const float lse = mx + logf(se);
+  Cand prev{INFINITY, -1};
+  for (int n = 0; n < per_node; ++n) {
+    Cand best{-INFINITY, -1};
+    for (int c = lane; c < 2 * ntn; c += 64) {
+      const float v = p[(c >> 1) * 6 + 2 + 2 * (c & 1)];
+      const int i = __float_as_int(p[(c >> 1) * 6 + 3 + 2 * (c & 1)]);
+      if (i >= 0 && after(v, i, prev) && (best.i < 0 || better(v, i, best))) best = Cand{v, i};
+    }
+    best = wave_best(best);
+    if (lane == 0) { sval[base + n] = best.v - lse; sidx[base + n] = best.i; }
+    prev = best;
+  }
+}
+
 // part B: per (b, target state i): top-`beam` over the S*beam*per_node summed candidates      cbs.py:210-234
 // ctl (optional): early stop without a host round trip, see ssc_beam_desc.
 __global__ __launch_bounds__(64) void beam_merge_kernel(const float* __restrict__ sval, const int64_t* __restrict__ sidx,
@@ -477,6 +518,23 @@ extern "C" int ssc_beam_step_fsm(const ssc_beam_desc* d, void* stream) {
                                 d->scratch_val, d->scratch_idx, st));
   }
   return ssc_beam_merge(d->scratch_val, d->scratch_idx, d->last_lp, B, S, beam, per_node, d->pred, d->lp_out, d->backptr,
+                        d->end_index, d->ctl, d->step_index, d->max_steps, d->host_flag, st);
+}
+
+extern "C" int ssc_beam_step_parts(const ssc_beam_desc* d, const float* parts, void* stream) {
+  if (!d || !parts || !d->last_pred || !d->last_lp || !d->pred || !d->lp_out || !d->backptr || !d->scratch_val || !d->scratch_idx)
+    return SSC_EINVAL;
+  const int B = d->B, V = d->dims.V, beam = d->beam, per_node = d->per_node;
+  if (d->dims.S != 1 || d->fsm || d->tables || B <= 0 || V <= 0 || beam <= 0 || per_node <= 0 || per_node > 2 || d->end_index < 0 ||
+      d->end_index >= V || beam > beam * per_node)
+    return SSC_EINVAL;
+  if (d->ctl && (d->max_steps <= 0 || d->step_index <= 0 || d->step_index >= d->max_steps)) return SSC_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int G = B * beam, ntn = ssc_cdiv(V, 128);
+  SSC_LAUNCH(beam_rows_parts_kernel, dim3(ssc_cdiv(G, 4)), dim3(256), 0, st, parts, ntn, d->last_pred, G, per_node, d->end_index,
+             d->scratch_val, d->scratch_idx);
+  SSC_CHECK_LAUNCH();
+  return ssc_beam_merge(d->scratch_val, d->scratch_idx, d->last_lp, B, 1, beam, per_node, d->pred, d->lp_out, d->backptr,
                         d->end_index, d->ctl, d->step_index, d->max_steps, d->host_flag, st);
 }
 

@@ -61,6 +61,9 @@ struct KArgs {
   int store_wt;       // x3w epilogue: 1 = write-through (sc1) stores of the output tile (split-K slabs: nothing left dirty in L2
                       // for the kernel boundary to write back)
   int member;         // index of this product inside a grouped launch (address-audit build: which record it reports to)
+  float* topk;            // wave-specialised 128x128 form only: instead of storing C, every (row, 128-column tile) leaves a record of 6
+                          // floats at topk[(row * ntn + tile) * 6]: max, sum exp(x - max), best value, its column, second best, its column
+                          // (columns as int bits; ties to the lower column) - ssc_gemm_desc.topk_part
   const float* a_scale;   // 2xFP16 form only: power-of-two factors (device scalars, optional) the A / B operands are multiplied with
   const float* b_scale;   // before the fp16 split; the result is multiplied with the exact inverse of their product
 };
@@ -1556,6 +1559,77 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
   // ---- epilogue, all 8 waves: C tile rows leave LDS as 16-byte stores, 1 KB contiguous per 64 lanes (the accumulator
   // layout itself would give 64 four-byte stores per lane in two 128-B pieces each: store-issue-bound, ~8 us per launch)
   __syncthreads();
+  if constexpr (TM == 128 && TN == 128 && A_KC && B_KC && !KG) {
+    if (a.topk) {
+      // Vocabulary head of a decode step without the logits: per (row, this 128-column tile) the log-sum-exp partials and the two
+      // best columns.  Four threads per tile row, 32 columns each, combined by shuffles; order: value descending, column ascending.
+      const float* ct = reinterpret_cast<const float*>(lds);
+      const int t = (int)threadIdx.x;
+      if (t < 512) {
+        const int row = t >> 2, part = t & 3;
+        const int grow = m0 + row;
+        const int ntn = (a.N + TN - 1) / TN;
+        float mx = -INFINITY, v0 = -INFINITY, v1 = -INFINITY;
+        int i0 = -1, i1 = -1;
+        const float inv = F16 ? 1.0f / (f16_sa * f16_sb) : 1.0f;
+        // this thread's 32 columns: eight 16-byte LDS reads, kept in registers for both passes
+        float x[32];
+        const bool wide_b = a.bias && !(reinterpret_cast<uintptr_t>(a.bias) & 15) && n0 + TN <= a.N;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float4 c4 = *reinterpret_cast<const float4*>(&ct[row * CT_LD + part * 32 + 4 * j]);
+          float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+          const int gc = n0 + part * 32 + 4 * j;
+          if (wide_b) b4 = *reinterpret_cast<const float4*>(a.bias + gc);
+          else if (a.bias) { b4.x = gc < a.N ? a.bias[gc] : 0.f; b4.y = gc + 1 < a.N ? a.bias[gc + 1] : 0.f; b4.z = gc + 2 < a.N ? a.bias[gc + 2] : 0.f; b4.w = gc + 3 < a.N ? a.bias[gc + 3] : 0.f; }
+          x[4 * j] = c4.x * inv + b4.x; x[4 * j + 1] = c4.y * inv + b4.y; x[4 * j + 2] = c4.z * inv + b4.z; x[4 * j + 3] = c4.w * inv + b4.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+          const int gcol = n0 + part * 32 + j;
+          if (gcol < a.N) {
+            mx = fmaxf(mx, x[j]);
+            if (x[j] > v0) { v1 = v0; i1 = i0; v0 = x[j]; i0 = gcol; }
+            else if (x[j] > v1) { v1 = x[j]; i1 = gcol; }
+          }
+        }
+        // the row's maximum over the four parts, then the sum of exp(x - max) with that common maximum (hardware exp2: the sum only
+        // feeds the row's log-sum-exp, ~1e-7 relative)
+#pragma unroll
+        for (int o = 1; o <= 2; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        float se = 0.f;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+          const int gcol = n0 + part * 32 + j;
+          if (gcol < a.N) se += __builtin_amdgcn_exp2f((x[j] - mx) * 1.4426950408889634f);
+        }
+#pragma unroll
+        for (int o = 1; o <= 2; o <<= 1) se += __shfl_xor(se, o, 64);
+        // merge the parts' pairs (each sorted; a lower part holds lower columns)
+#pragma unroll
+        for (int o = 1; o <= 2; o <<= 1) {
+          const float w0 = __shfl_xor(v0, o, 64), w1 = __shfl_xor(v1, o, 64);
+          const int j0 = __shfl_xor(i0, o, 64), j1 = __shfl_xor(i1, o, 64);
+          auto before = [](float xa, int ia, float xb, int ib) { return ib < 0 || (ia >= 0 && (xa > xb || (xa == xb && ia < ib))); };
+          float r0, r1; int k0, k1;
+          if (before(v0, i0, w0, j0)) {
+            r0 = v0; k0 = i0;
+            if (before(v1, i1, w0, j0)) { r1 = v1; k1 = i1; } else { r1 = w0; k1 = j0; }
+          } else {
+            r0 = w0; k0 = j0;
+            if (before(v0, i0, w1, j1)) { r1 = v0; k1 = i0; } else { r1 = w1; k1 = j1; }
+          }
+          v0 = r0; i0 = k0; v1 = r1; i1 = k1;
+        }
+        if (part == 0 && grow < Meff) {
+          const int rr = (RL && a.crows) ? a.crows[grow] : grow;
+          float* rec = a.topk + ((size_t)rr * ntn + bx) * 6;
+          rec[0] = mx; rec[1] = se; rec[2] = v0; rec[3] = __int_as_float(i0); rec[4] = v1; rec[5] = __int_as_float(i1);
+        }
+      }
+      return;
+    }
+  }
   {
     const float* ct = reinterpret_cast<const float*>(lds);
     float* out = a.out + (size_t)z * a.slab_stride;
@@ -1704,6 +1778,7 @@ int build_args(const ssc_gemm_desc* d, KArgs& k) {
   k.mcount = d->m_count; k.arows = d->a_rows; k.crows = d->c_rows;
   k.kcount = d->k_count; k.karows = d->ka_rows; k.kbrows = d->kb_rows;
   k.a_scale = d->a_scale; k.b_scale = d->b_scale;
+  k.topk = d->topk_part;
   k.steps_total = 0;
   for (int i = 0; i < d->nseg; ++i) {
     const ssc_gemm_seg& s = d->seg[i];
@@ -1988,7 +2063,8 @@ int launch(const ssc_gemm_desc* d, KArgs& k, int splits, hipStream_t st) {
     // (2xFP16 numerics requested and applicable: the wave-specialised form at every grid size - its F16 variant is 1.5x the 3xBF16
     // one, which outweighs what the 4-wave kernel gains on grids below three rounds)
     const bool f16 = (ssc_tls_gemm_f16 >= 0 ? ssc_tls_gemm_f16 : g_gemm_f16) && d->a_kc && d->b_kc && !kg && g_x3w_big_npw == 8 && g_x3b != 3;
-    if ((g_x3b == 2 || (g_x3b == 1 && (f16 || wgs >= 768 || (d->M < 512 && big_tile(d->M, d->N))))) && x3w_span_ok(d) && (!kg || kg_both)) {  // wave-specialised form: 12 waves, 120 KB of dynamic LDS
+    if (k.topk && !(d->a_kc && d->b_kc && !kg && splits == 1 && x3w_span_ok(d))) return SSC_EINVAL;   // the records exist in this form's epilogue only
+    if ((k.topk || g_x3b == 2 || (g_x3b == 1 && (f16 || wgs >= 768 || (d->M < 512 && big_tile(d->M, d->N))))) && x3w_span_ok(d) && (!kg || kg_both)) {  // wave-specialised form: 12 waves, 120 KB of dynamic LDS
       group_fn fn = x3w_big_fn(d->a_kc, d->b_kc, kg);
       if (f16) fn = gemm_x3w_kernel<true, true, false, 128, 128, 2, 8, true>;
       SSC_TRY(x3w_prepare());
@@ -2320,6 +2396,12 @@ extern "C" int ssc_gemm(const ssc_gemm_desc* d, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   KArgs k;
   SSC_TRY(build_args(d, k));
+  if (d->topk_part) {   // records instead of C: one pass, wave-specialised 128x128 NT form (launch() refuses anything else)
+    k.out = nullptr; k.ldo = d->N; k.slab_stride = 0; k.bias = d->bias; k.accumulate = 0;
+    const bool vec_all = [&] { for (int i = 0; i < k.nseg; ++i) if (!k.seg[i].avec || !k.seg[i].bvec) return false; return true; }();
+    if (!vec_all || gemm_mode() != 1 || !d->a_kc || !d->b_kc) return SSC_EINVAL;
+    return launch(d, k, 1, st);
+  }
   if (!d->C || d->ldc < d->N) return SSC_EINVAL;
   int splits = d->splits;
   if (splits <= 0) splits = ssc_gemm_auto_splits(d->M, d->N, k.steps_total);
@@ -2407,7 +2489,7 @@ extern "C" int ssc_set_gemm_mode(int mode) {
 }
 
 // ---- include/ssc_debug.h -----------------------------------------------------------------------------------------
-extern int ssc_g_dec_att_table, ssc_g_dec_dedup, ssc_g_beam_reg, ssc_g_dec_ungathered;   // decode.hip
+extern int ssc_g_dec_att_table, ssc_g_dec_dedup, ssc_g_beam_reg, ssc_g_dec_ungathered, ssc_g_dec_parts;   // decode.hip
 extern int ssc_g_img_mfma;   // pointwise.hip
 namespace {
 struct DebugKey { const char* name; int* var; };
@@ -2430,6 +2512,7 @@ const DebugKey g_debug_keys[] = {
     {"beam_reg", &ssc_g_beam_reg},             // decode: beam selection with the vocabulary row in registers (1 | 0)              (SSC_BEAM_REG)
     {"img_mfma", &ssc_g_img_mfma},             // decode: the image cell's table contraction on the fp32 matrix cores (1 | 0 = VALU form)   (SSC_IMG_MFMA)
     {"dec_ungathered", &ssc_g_dec_ungathered}, // decode: states left in the previous step's row order, read through the parent lists (1 | 0)   (SSC_DEC_UNGATHERED)
+    {"dec_parts", &ssc_g_dec_parts},           // decode: the vocabulary head of a one-state search leaves per-tile records instead of logits (1 | 0)   (SSC_DEC_PARTS)
     {"dec_att_table", &ssc_g_dec_att_table},   // decode: attended-feature term of the decoder gates from a per-image table (1 | 0)   (SSC_DEC_ATT_TABLE)
     {"gemm_f16", &g_gemm_f16},       // op-level products (ssc_gemm outside a sequence-level call): 1 = the wave-specialised 128x128 NT form takes the 2xFP16 split (what ssc_model_cfg.gemm_mode 3 selects per call)
     {"big_min_m", &g_big_min_m},     // rows from which a product with N >= 512 takes 128x128 tiles (65; 512 = the behaviour until late in round 2)   (SSC_BIG_MIN_M)

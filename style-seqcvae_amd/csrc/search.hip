@@ -14,6 +14,14 @@ namespace {
 
 inline size_t a256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// The vocabulary head of the later steps leaves per-tile records instead of logits (ssc_decode_step_desc.topk_part) when the machine
+// is the trivial one, at most two candidates per row are wanted and the head is one aligned 3xBF16 / 2xFP16 product.
+bool search_uses_parts(const ssc_model_cfg* cfg, const ssc_search_desc* d) {
+  const long G = (long)d->nimg * d->n_samples * d->S * d->beam;
+  return d->S == 1 && !d->fsm && !d->tables && d->per_node <= 2 && !cfg->tied && cfg->gemm_mode != 2 && cfg->H % 4 == 0 && G >= 512 &&
+         ssc_decode_parts_enabled();
+}
+
 struct SearchLayout {
   size_t st[2][4];     // h1, c1, hd, cd: two generations of (G,H)
   size_t tokens0;      // (B) int64 start tokens
@@ -24,7 +32,8 @@ struct SearchLayout {
   size_t lp[2];        // (B, S, beam) float
   size_t sval, sidx;   // B*S*SB*per_node
   size_t alpha;        // (G, R)
-  size_t logits;       // (G, V)
+  size_t logits;       // (G, V); (B, V) when the later steps leave records
+  size_t parts;        // (G, ceil(V / 128), 6) records
   size_t stepws;       // ssc_decode_step workspace
   size_t stepws_bytes;
   size_t total;
@@ -46,7 +55,9 @@ SearchLayout search_layout(const ssc_model_cfg* cfg, const ssc_search_desc* d) {
   l.sval = o; o += a256(B * d->S * SB * d->per_node * 4);
   l.sidx = o; o += a256(B * d->S * SB * d->per_node * 8);
   l.alpha = o; o += a256(G * (size_t)d->R * 4);
-  l.logits = o; o += a256(G * (size_t)cfg->V * 4);
+  const bool parts = search_uses_parts(cfg, d);
+  l.logits = o; o += a256((parts ? B : G) * (size_t)cfg->V * 4);
+  l.parts = o; o += a256(parts ? G * (size_t)ssc_cdiv(cfg->V, 128) * 6 * 4 : 0);
   l.stepws_bytes = ssc_decode_step_workspace_bytes(cfg, (int)G, d->R);
   l.stepws = o; o += a256(l.stepws_bytes);
   l.total = o;
@@ -111,6 +122,8 @@ extern "C" int ssc_decode_search(const ssc_model_cfg* cfg, const ssc_params* p, 
   float* lp[2] = {(float*)(W + l.lp[0]), (float*)(W + l.lp[1])};
   float* alpha = (float*)(W + l.alpha);
   float* logits = (float*)(W + l.logits);
+  float* parts = (float*)(W + l.parts);
+  const bool use_parts = search_uses_parts(cfg, d);
   const size_t plane = (size_t)G;
   const int nctl = 2 + 2 * d->max_steps;
 
@@ -176,10 +189,12 @@ extern "C" int ssc_decode_search(const ssc_model_cfg* cfg, const ssc_params* p, 
     table_ready = table_ready || tmode;
     sd.ungathered = ungathered ? 1 : 0;
     sd.row_lp = d->skip_dead ? lp[a] : nullptr; sd.end_index = d->end_index;
+    if (use_parts) { sd.log_probs = nullptr; sd.topk_part = parts; }
     SSC_TRY(ssc_decode_step(cfg, p, &sd, W + l.stepws, l.stepws_bytes, st));
     bd.last_pred = last; bd.last_lp = lp[a]; bd.pred = preds + (size_t)t * plane; bd.lp_out = lp[1 - a];
     bd.backptr = backs + (size_t)(t - 1) * plane; bd.step_index = t;
-    SSC_TRY(ssc_beam_step_fsm(&bd, st));
+    if (use_parts) SSC_TRY(ssc_beam_step_parts(&bd, parts, st));
+    else SSC_TRY(ssc_beam_step_fsm(&bd, st));
     a = 1 - a;
     if (ung) {   // the next step reads these outputs through the back-pointers (ssc_decode_step_desc.ungathered)
       cur = 1 - cur;

@@ -110,3 +110,4 @@ struct SscGemmModeScope {
   }
   ~SscGemmModeScope() { ssc_tls_gemm_mode = prev; ssc_tls_gemm_f16 = prev16; }
 };
+int ssc_decode_parts_enabled();        // the "dec_parts" switch (decode.hip): vocabulary head records instead of logits

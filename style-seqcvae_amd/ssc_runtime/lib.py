@@ -30,7 +30,7 @@ class GemmDesc(C.Structure):
     _fields_ = [("seg", GemmSeg * SSC_MAX_SEG), ("nseg", C.c_int), ("M", C.c_int), ("N", C.c_int), ("a_kc", C.c_int),
                 ("b_kc", C.c_int), ("C", vp), ("ldc", C.c_int), ("bias", vp), ("accumulate", C.c_int),
                 ("splits", C.c_int), ("workspace", vp), ("workspace_floats", C.c_size_t), ("m_count", vp), ("a_rows", vp),
-                ("c_rows", vp), ("k_count", vp), ("ka_rows", vp), ("kb_rows", vp), ("a_scale", vp), ("b_scale", vp)]
+                ("c_rows", vp), ("k_count", vp), ("ka_rows", vp), ("kb_rows", vp), ("a_scale", vp), ("b_scale", vp), ("topk_part", vp)]
 
 
 class LstmFwdDesc(C.Structure):
@@ -108,7 +108,7 @@ class DecodeStepDesc(C.Structure):
                 ("tokens", vp), ("sentiment", vp), ("eps", vp), ("h1", vp), ("c1", vp), ("hd", vp), ("cd", vp),
                 ("h1_out", vp), ("c1_out", vp), ("hd_out", vp), ("cd_out", vp), ("alpha", vp), ("log_probs", vp),
                 ("raw_logits", C.c_int), ("emb_override", C.c_int), ("parent", vp), ("group", C.c_int), ("att_table", C.c_int),
-                ("ungathered", C.c_int), ("row_lp", vp), ("end_index", C.c_int), ("obj_atts", vp), ("prior_mean_out", vp), ("prior_mean", vp), ("prior_var", vp)]
+                ("ungathered", C.c_int), ("row_lp", vp), ("end_index", C.c_int), ("obj_atts", vp), ("prior_mean_out", vp), ("prior_mean", vp), ("prior_var", vp), ("topk_part", vp)]
 
 
 class FsmDims(C.Structure):
@@ -201,6 +201,7 @@ SYMBOLS = {
     "ssc_fsm_compile": (_i, [vp, C.POINTER(FsmDims), vp, _sz, vp]),
     "ssc_beam_first_fsm": (_i, [C.POINTER(BeamDesc), vp]),
     "ssc_beam_step_fsm": (_i, [C.POINTER(BeamDesc), vp]),
+    "ssc_beam_step_parts": (_i, [C.POINTER(BeamDesc), vp, vp]),
     "ssc_beam_backtrace_ctl": (_i, [vp, vp, vp, _i, _i, _i, _i, vp, vp]),
     "ssc_host_device_ptr": (_i, [vp, C.POINTER(vp)]),
     "ssc_decode_search_workspace_bytes": (_sz, [C.POINTER(ModelCfg), C.POINTER(SearchDesc)]),

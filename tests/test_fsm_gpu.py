@@ -350,3 +350,80 @@ def test_one_call_search_equals_the_step_by_step_search(tmp_path, nimg, ns, beam
     assert torch.equal(got_p, want_p) and torch.equal(got_lp, want_lp)
     if early and end_bias > 0 and not machines:   # (with machines the beams that hold only fills never all end: cbs.py:167 does not fire)
         assert got_p.shape[-1] < steps
+
+
+@pytest.mark.parametrize("M,N,K,f16", [(700, 1000, 96, 0), (1300, 10000, 200, 1), (640, 333 * 4, 64, 1)])
+def test_vocabulary_head_records_describe_the_logits(M, N, K, f16):
+    """ssc_gemm_desc.topk_part: per (row, 128-column tile) the maximum, sum exp(x - max) and the two best columns of x = a W^T + bias,
+    against the same product written out (same kernel form, so the values are the same bits): maxima and columns exact, the
+    exponential sums to rounding; with a device-side row list (c_rows) the records land on the listed rows."""
+    import ctypes as C
+    from gpuutil import gemm
+    from ssc_runtime import lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(M + N)
+    A = torch.randn(M, K, generator=g).cuda()
+    Wt = (torch.randn(N, K, generator=g) * 0.3).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    ntn = (N + 127) // 128
+    lib.ssc_debug_set(b"gemm_f16", f16)
+    lib.ssc_debug_set(b"large_form", 2)
+    try:
+        full = torch.empty(M, N, device="cuda")
+        gemm([(A, K, Wt, K, K)], M, N, 1, 1, full, bias=bias, splits=1)
+        parts = torch.full((M, ntn, 6), float("nan"), device="cuda")
+        gemm([(A, K, Wt, K, K)], M, N, 1, 1, full, bias=bias, splits=1, compact={"topk_part": parts})
+        # with a row list: every second row, records scattered to those rows
+        rows = torch.arange(0, M, 2, dtype=torch.int32, device="cuda")
+        cnt = torch.tensor([rows.numel()], dtype=torch.int32, device="cuda")
+        parts2 = torch.full((M, ntn, 6), float("nan"), device="cuda")
+        gemm([(A, K, Wt, K, K)], M, N, 1, 1, full, bias=bias, splits=1,
+             compact={"topk_part": parts2, "m_count": cnt, "a_rows": rows, "c_rows": rows})
+    finally:
+        lib.ssc_debug_set(b"gemm_f16", 0)
+        lib.ssc_debug_set(b"large_form", 1)
+    torch.cuda.synchronize()
+    pad = ntn * 128 - N
+    x = torch.cat([full, torch.full((M, pad), float("-inf"), device="cuda")], 1).view(M, ntn, 128)
+    mx = x.max(-1).values
+    assert torch.equal(parts[..., 0], mx)
+    se = torch.exp(x - mx.unsqueeze(-1)).sum(-1)
+    assert float(((parts[..., 1] - se).abs() / se).max()) < 1e-5
+    top = x.topk(2, dim=-1)      # (ties: torch's order is unspecified - compare values, and columns where the values differ)
+    assert torch.equal(parts[..., 2], top.values[..., 0]) and torch.equal(parts[..., 4].nan_to_num(neginf=-1e30), top.values[..., 1].nan_to_num(neginf=-1e30))
+    col0 = parts[..., 3].view(torch.int32).long()
+    base = (torch.arange(ntn, device="cuda") * 128).view(1, ntn)
+    assert torch.equal(torch.gather(x, 2, (col0 - base).unsqueeze(-1)).squeeze(-1), top.values[..., 0])
+    assert torch.equal(parts2[::2], parts[::2]) and bool(torch.isnan(parts2[1::2]).all())
+
+
+@pytest.mark.parametrize("end_bias,early", [(0.0, False), (6.0, True)])
+def test_search_from_records_equals_search_from_logits(end_bias, early):
+    """ssc_decode_search with the vocabulary head leaving records (the one-state machine, per-node 2, >= 512 rows: bench.py's decode
+    leg) against the same search on written-out logits: identical captions and back-pointers; log-probs to rounding (the
+    log-sum-exp is summed per tile instead of per thread stride)."""
+    from ssc_runtime import lib as L
+    lib = L.load()
+    V, R, Z, steps, nimg, ns, beam = 1000, 6, 8, 9, 8, 16, 5
+    m = _small_captioner(V, end_bias)
+    dec = m._dec
+    g = torch.Generator().manual_seed(2)
+    feats = torch.randn(nimg, R, 64, generator=g).cuda()
+    senti = torch.randint(-1, 2, (nimg,), generator=g).float().cuda()
+    B = nimg * ns
+    sent_b = senti.view(nimg, 1).expand(nimg, ns).reshape(B)
+    eps0 = torch.randn(B, Z, generator=g).cuda()
+    eps = torch.randn(steps - 1, B * beam, Z, generator=g).cuda()
+    outs = []
+    for on in (1, 0):
+        lib.ssc_debug_set(b"dec_parts", on)
+        try:
+            ctx = dec.prepare(feats)
+            outs.append(dec.search(ctx, sent_b, ns, beam, 2, steps, 1, eps0, eps, early_stop=early))
+        finally:
+            lib.ssc_debug_set(b"dec_parts", 1)
+    (p1, l1), (p0, l0) = outs
+    assert p1.shape == p0.shape and torch.equal(p1, p0)
+    assert float((l1 - l0).abs().max()) < 2e-5
+    if early:
+        assert p1.shape[-1] < steps
