@@ -27,11 +27,11 @@ def short(name):
         a, b, kg = m.groups()
         kind = {("true", "true"): "NT", ("true", "false"): "NN", ("false", "false"): "TN"}[(a, b)]
         return f"gemm_x3b_kernel<{kind},128x128{',rowgather' if kg == 'true' else ''}>"
-    m = re.search(r"gemm_x3w_kernel<(\w+), (\w+), (\w+), (\d+), (\d+), (\d)(?:, \d)?>", name)   # (+ producer waves since r02_b)
+    m = re.search(r"gemm_x3w_kernel<(\w+), (\w+), (\w+), (\d+), (\d+), (\d)(?:, \d)?(?:, (\w+))?>", name)   # (+ producer waves since r02_b, + 2xFP16 flag since r04)
     if m:
-        a, b, kg, tm, tn, pf = m.groups()
+        a, b, kg, tm, tn, pf, f16 = m.groups()
         kind = {("true", "true"): "NT", ("true", "false"): "NN", ("false", "false"): "TN"}[(a, b)]
-        return f"gemm_x3w_kernel<{kind},{tm}x{tn}{',rowgather' if kg == 'true' else ''}>"
+        return f"gemm_x3w_kernel<{kind},{tm}x{tn}{',rowgather' if kg == 'true' else ''}{',f16x2' if f16 == 'true' else ''}>"
     m = re.search(r"gemm_x3_kernel<(\d), (\d), (\d)>", name)
     if m:
         return f"gemm_x3_kernel<NT,64x{64 * int(m.group(2))},lds{m.group(3)}>"

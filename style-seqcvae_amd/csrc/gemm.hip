@@ -2019,7 +2019,9 @@ int launch(const ssc_gemm_desc* d, KArgs& k, int splits, hipStream_t st) {
     if ((k.kcount || k.karows || k.kbrows) && (k.nseg != 1 || d->a_kc || d->b_kc)) return SSC_EINVAL;
     if ((k.mcount || k.arows || k.crows) && !d->a_kc) return SSC_EINVAL;
   }
-  if (x3w_skinny(d, vec) && !compact && x3w_span_ok(d)) {  // M = minibatch against a wide weight matrix: 64 x 256 wave-specialised tile
+  if (k.topk && !(gemm_mode() == 1 && vec && d->a_kc && d->b_kc && splits == 1 && x3w_span_ok(d) && !k.kcount && !k.karows && !k.kbrows))
+    return SSC_EINVAL;   // records instead of C exist in the wave-specialised 128x128 NT form only: never fall through to a form that would store C
+  if (x3w_skinny(d, vec) && !compact && !k.topk && x3w_span_ok(d)) {  // M = minibatch against a wide weight matrix: 64 x 256 wave-specialised tile
     dim3 grid(ssc_cdiv(d->N, 256), ssc_cdiv(d->M, 64), splits);
     ProfRec* rec = nullptr;
     if (g_prof_on && g_prof && g_prof_n < PROF_MAX) {
@@ -2041,7 +2043,7 @@ int launch(const ssc_gemm_desc* d, KArgs& k, int splits, hipStream_t st) {
     SSC_CHECK_LAUNCH();
     return SSC_OK;
   }
-  if (gemm_mode() == 1 && vec && !(!d->a_kc && d->b_kc) && (compact || (g_x3b && big_tile(d->M, d->N)))) {
+  if (gemm_mode() == 1 && vec && !(!d->a_kc && d->b_kc) && (compact || k.topk || (g_x3b && big_tile(d->M, d->N)))) {
     dim3 grid(ssc_cdiv(d->N, 128), ssc_cdiv(d->M, 128), splits);
     ProfRec* rec = nullptr;
     if (g_prof_on && g_prof && g_prof_n < PROF_MAX) {

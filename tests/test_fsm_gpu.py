@@ -352,7 +352,8 @@ def test_one_call_search_equals_the_step_by_step_search(tmp_path, nimg, ns, beam
         assert got_p.shape[-1] < steps
 
 
-@pytest.mark.parametrize("M,N,K,f16", [(700, 1000, 96, 0), (1300, 10000, 200, 1), (640, 333 * 4, 64, 1)])
+@pytest.mark.parametrize("M,N,K,f16", [(700, 1000, 96, 0), (1300, 10000, 200, 1), (640, 333 * 4, 64, 1), (640, 400, 64, 0), (48, 2048, 64, 1),
+                                       (5, 60, 32, 0)])
 def test_vocabulary_head_records_describe_the_logits(M, N, K, f16):
     """ssc_gemm_desc.topk_part: per (row, 128-column tile) the maximum, sum exp(x - max) and the two best columns of x = a W^T + bias,
     against the same product written out (same kernel form, so the values are the same bits): maxima and columns exact, the
@@ -367,12 +368,19 @@ def test_vocabulary_head_records_describe_the_logits(M, N, K, f16):
     bias = torch.randn(N, generator=g).cuda()
     ntn = (N + 127) // 128
     lib.ssc_debug_set(b"gemm_f16", f16)
-    lib.ssc_debug_set(b"large_form", 2)
     try:
+        # (no kernel form is forced for the record launches: shapes the form heuristics would send to the 64-wide / 64x256 kernels -
+        # narrow N, a minibatch-sized M - must still take the one form that has the records epilogue; round 4 had them fall through
+        # to a kernel that stores C, with C = NULL)
+        parts = torch.full((M, ntn, 6), float("nan"), device="cuda")
+        gemm([(A, K, Wt, K, K)], M, N, 1, 1, torch.empty(1, N, device="cuda"), bias=bias, splits=1, compact={"topk_part": parts})
+        torch.cuda.synchronize()
+        lib.ssc_debug_set(b"large_form", 2)
         full = torch.empty(M, N, device="cuda")
         gemm([(A, K, Wt, K, K)], M, N, 1, 1, full, bias=bias, splits=1)
-        parts = torch.full((M, ntn, 6), float("nan"), device="cuda")
-        gemm([(A, K, Wt, K, K)], M, N, 1, 1, full, bias=bias, splits=1, compact={"topk_part": parts})
+        parts_b = torch.full((M, ntn, 6), float("nan"), device="cuda")
+        gemm([(A, K, Wt, K, K)], M, N, 1, 1, full, bias=bias, splits=1, compact={"topk_part": parts_b})
+        assert torch.equal(parts_b, parts)
         # with a row list: every second row, records scattered to those rows
         rows = torch.arange(0, M, 2, dtype=torch.int32, device="cuda")
         cnt = torch.tensor([rows.numel()], dtype=torch.int32, device="cuda")
@@ -386,14 +394,19 @@ def test_vocabulary_head_records_describe_the_logits(M, N, K, f16):
     pad = ntn * 128 - N
     x = torch.cat([full, torch.full((M, pad), float("-inf"), device="cuda")], 1).view(M, ntn, 128)
     mx = x.max(-1).values
-    assert torch.equal(parts[..., 0], mx)
     se = torch.exp(x - mx.unsqueeze(-1)).sum(-1)
-    assert float(((parts[..., 1] - se).abs() / se).max()) < 1e-5
     top = x.topk(2, dim=-1)      # (ties: torch's order is unspecified - compare values, and columns where the values differ)
-    assert torch.equal(parts[..., 2], top.values[..., 0]) and torch.equal(parts[..., 4].nan_to_num(neginf=-1e30), top.values[..., 1].nan_to_num(neginf=-1e30))
     col0 = parts[..., 3].view(torch.int32).long()
     base = (torch.arange(ntn, device="cuda") * 128).view(1, ntn)
-    assert torch.equal(torch.gather(x, 2, (col0 - base).unsqueeze(-1)).squeeze(-1), top.values[..., 0])
+    at_col0 = torch.gather(x, 2, (col0 - base).clamp(0, 127).unsqueeze(-1)).squeeze(-1)
+    if M > 64:   # the written-out product took the same kernel form: same bits
+        assert torch.equal(parts[..., 0], mx)
+        assert torch.equal(parts[..., 2], top.values[..., 0]) and torch.equal(parts[..., 4].nan_to_num(neginf=-1e30), top.values[..., 1].nan_to_num(neginf=-1e30))
+        assert torch.equal(at_col0, top.values[..., 0])
+    else:        # (a minibatch-sized product is written out by the 64x256 kernel in 3xBF16: the same numbers to fp32 rounding)
+        assert float((parts[..., 0] - mx).abs().max()) < 1e-4 and float((parts[..., 2] - top.values[..., 0]).abs().max()) < 1e-4
+        assert float((at_col0 - top.values[..., 0]).abs().max()) < 1e-4
+    assert float(((parts[..., 1] - se).abs() / se).max()) < 1e-4
     assert torch.equal(parts2[::2], parts[::2]) and bool(torch.isnan(parts2[1::2]).all())
 
 
