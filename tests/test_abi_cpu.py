@@ -95,3 +95,10 @@ def test_staged_load_hazard_checker_flags_copies_of_inflight_registers(tmp_path)
     good.write_text(body.format(A="", B="\ts_waitcnt vmcnt(1)\n\tv_mov_b32_e32 v20, v3\n\ts_waitcnt vmcnt(0)\n\tv_mov_b32_e32 v21, v7\n"))
     assert subprocess.call([sys.executable, tool, str(bad)], stdout=subprocess.DEVNULL) == 1
     assert subprocess.call([sys.executable, tool, str(good)], stdout=subprocess.DEVNULL) == 0
+
+
+def test_graft_entry_build_passes():
+    """__graft_entry__.build() - what the driver runs on a CPU box every round: the library is current (or rebuilt), loads,
+    reports the ABI version this header declares, and the host package imports."""
+    import __graft_entry__ as ge
+    ge.build()
