@@ -151,6 +151,8 @@ typedef struct {
   const float* slabs2; int nslab2; size_t slab2_stride; const int* slab2_rows;
   const int* c_prev_rows;      /* optional: row b's previous cell state is row c_prev_rows[b] of c_prev (decode: states left in the
                                 * previous step's row order, ssc_decode_step_desc.ungathered) */
+  const int* rows; const int* row_count;   /* optional (ssc_lstm_fwd only): a device-side list of the rows to compute, *row_count of them
+                                * (decode: the rows that hold a finite, unfinished beam); the other rows' outputs are left as they are */
 } ssc_lstm_fwd_desc;
 int ssc_lstm_fwd(const ssc_lstm_fwd_desc* d, void* stream);
 /* The same with one more addend formed inside the kernel: pre[b,n] += z[b,:Z] . wz[n,:Z]  (z (B,Z) ld ldz; wz (4H,Z) ld ldwz;

@@ -24,10 +24,16 @@ __global__ __launch_bounds__(256) void attn_logits_kernel(const float* __restric
                                                           float* __restrict__ q_out, int ldqo,
                                                           const float* __restrict__ pv, const float* __restrict__ wa,
                                                           int G, int R, int A, int rows_per_image,
-                                                          float* __restrict__ logits) {
+                                                          float* __restrict__ logits, const int* __restrict__ rows,
+                                                          const int* __restrict__ row_count) {
   __shared__ __attribute__((aligned(16))) float sq[ATTN_MAXA];
   const int groups = (R + ATTN_RG - 1) / ATTN_RG;
-  const int g = blockIdx.x / groups, grp = blockIdx.x - g * groups;
+  int g = blockIdx.x / groups;
+  const int grp = blockIdx.x - g * groups;
+  if (rows) {   // decode: only the listed rows (a device-side list of the rows that are read at all: ssc_decode_step_desc.row_lp)
+    if (g >= *row_count) return;
+    g = rows[g];
+  }
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int img = g / rows_per_image;
   const float* qp = q + (size_t)g * ldq;
@@ -365,7 +371,22 @@ extern "C" int ssc_attn_logits(const float* q, int ldq, const float* pv, const f
                                int rows_per_image, float* logits, void* stream) {
   if (!q || !pv || !wa || !logits || G <= 0 || R <= 0 || A <= 0 || A > ATTN_MAXA || rows_per_image <= 0 || ldq < A) return SSC_EINVAL;
   SSC_LAUNCH(attn_logits_kernel, dim3(G * ssc_cdiv(R, ATTN_RG)), dim3(256), 0, (hipStream_t)stream, q, ldq, 1, (size_t)0,
-                     (float*)nullptr, 0, pv, wa, G, R, A, rows_per_image, logits);
+                     (float*)nullptr, 0, pv, wa, G, R, A, rows_per_image, logits, (const int*)nullptr, (const int*)nullptr);
+  SSC_CHECK_LAUNCH();
+  return SSC_OK;
+}
+
+// ssc_attn_weights over a device-side row list (internal: the decode step's live rows); rows outside the list keep stale logits / weights
+int ssc_attn_weights_rows(const float* q, int ldq, const float* pv, const float* wa, const float* mask, int G, int R, int A,
+                          int rows_per_image, float* logits, float* alpha, const int* rows, const int* row_count, hipStream_t st) {
+  if (!q || !pv || !wa || !mask || !alpha || !logits || !rows || !row_count || G <= 0 || R <= 0 || A <= 0 || A > ATTN_MAXA ||
+      rows_per_image <= 0 || ldq < A || R > 64 * MAXR_LANE)
+    return SSC_EINVAL;
+  SSC_LAUNCH(attn_logits_kernel, dim3(G * ssc_cdiv(R, ATTN_RG)), dim3(256), 0, st, q, ldq, 1, (size_t)0, (float*)nullptr, 0, pv, wa,
+             G, R, A, rows_per_image, logits, rows, row_count);
+  SSC_CHECK_LAUNCH();
+  SSC_LAUNCH(attn_apply_kernel, dim3(1, G), dim3(64), 0, st, logits, mask, (const float*)nullptr, G, R, 4, rows_per_image, alpha,
+             (float*)nullptr, 0, (const float*)nullptr, 0, (float*)nullptr, 0);
   SSC_CHECK_LAUNCH();
   return SSC_OK;
 }
@@ -423,7 +444,7 @@ int ssc_attn_fwd_qslabs(const float* qslabs, int nslab, size_t slab_stride, floa
   if (obj && (!pool || D <= 0 || ldpool < D)) return SSC_EINVAL;
   if (G <= 0 || R <= 0 || A <= 0 || A > ATTN_MAXA || F <= 0 || ldatt < F || ldqo < A || R > 64 * MAXR_LANE) return SSC_EINVAL;
   SSC_LAUNCH(attn_logits_kernel, dim3(G * ssc_cdiv(R, ATTN_RG)), dim3(256), 0, st, qslabs, A, nslab, slab_stride, q_out,
-                     ldqo, pv, wa, G, R, A, rows_per_image, logits);
+                     ldqo, pv, wa, G, R, A, rows_per_image, logits, (const int*)nullptr, (const int*)nullptr);
   SSC_CHECK_LAUNCH();
   SSC_LAUNCH(attn_apply_kernel, dim3(ssc_cdiv(F, 256) + (obj ? ssc_cdiv(ldpool, 256) : 0), G), dim3(64), 0, st, logits, mask, feats,
              G, R, F, rows_per_image, alpha, att, ldatt, obj, D, pool, ldpool);

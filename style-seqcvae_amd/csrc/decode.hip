@@ -634,12 +634,15 @@ extern "C" int ssc_decode_step(const ssc_model_cfg* cfg, const ssc_params* p, co
     f.b_ih = p->att_b_ih; f.b_hh = p->att_b_hh;
     f.c_prev = d->c1; f.ld_cprev = H; f.c_prev_rows = prow;
     f.c_out = d->c1_out; f.ld_cout = H; f.h_out = d->h1_out; f.ld_hout = H;
+    if (live) { f.rows = lrows; f.row_count = lcount; }   // (rows nobody reads are not computed: their h1 / c1 stay stale)
     SSC_TRY(ssc_lstm_fwd(&f, st));
   }
   // attention over the image's regions (attention.py:69-95, updown_cell.py:151-158)
   if (live) SSC_TRY(gemm_live({{d->h1_out, H, p->wq, p->ld_wq, H}}, A, W + l.q, l.Ap, nullptr, sc.at(SC_ACT), sc.at(SC_Q)));
   else SSC_TRY(gemm_nt(st, slabs, l.slab_floats, {{d->h1_out, H, p->wq, p->ld_wq, H}}, G, A, W + l.q, l.Ap, nullptr, sc.at(SC_ACT), sc.at(SC_Q)));
-  if (att_table)
+  if (att_table && live)
+    SSC_TRY(ssc_attn_weights_rows(W + l.q, l.Ap, I + il.pv, p->wa, I + il.mask, G, R, A, rpi, W + l.attn_logits, d->alpha, lrows, lcount, st));
+  else if (att_table)
     SSC_TRY(ssc_attn_weights(W + l.q, l.Ap, I + il.pv, p->wa, I + il.mask, G, R, A, rpi, W + l.attn_logits, d->alpha, st));
   else
     SSC_TRY(ssc_attn_fwd(W + l.q, l.Ap, I + il.pv, p->wa, I + il.mask, d->feats, G, R, A, F, rpi, W + l.attn_logits, d->alpha,

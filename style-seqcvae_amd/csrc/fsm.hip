@@ -21,6 +21,7 @@ namespace {
 struct FsmT {
   const int* ok;           // (M*S) 1: default + exceptions describes this from-state
   const uint32_t* dflt;    // (M*S) default target set
+  const uint32_t* reach;   // (M*S) default target set | every exception's target set: the states this from-state can reach at all
   const int* nexc;         // (M*S)
   const int* etok;         // (M*S, E) ascending
   const uint32_t* emask;   // (M*S, E)
@@ -30,7 +31,7 @@ struct FsmT {
   int E, P, NW;
 };
 struct FsmLayout {
-  size_t ok, dflt, nexc, etok, emask, fill, bits, total;   // in 4-byte words
+  size_t ok, dflt, reach, nexc, etok, emask, fill, bits, total;   // in 4-byte words
   int NW;
 };
 inline size_t r64w(size_t x) { return (x + 63) & ~(size_t)63; }
@@ -41,6 +42,7 @@ FsmLayout fsm_layout(const ssc_fsm_dims& d) {
   size_t o = 0;
   l.ok = o; o += r64w(ms);
   l.dflt = o; o += r64w(ms);
+  l.reach = o; o += r64w(ms);
   l.nexc = o; o += r64w(ms);
   l.etok = o; o += r64w(ms * d.E);
   l.emask = o; o += r64w(ms * d.E);
@@ -56,7 +58,7 @@ FsmT fsm_view(const void* tables, const ssc_fsm_dims& d) {
   const FsmLayout l = fsm_layout(d);
   const int* w = (const int*)tables;
   FsmT t;
-  t.ok = w + l.ok; t.dflt = (const uint32_t*)(w + l.dflt); t.nexc = w + l.nexc; t.etok = w + l.etok;
+  t.ok = w + l.ok; t.dflt = (const uint32_t*)(w + l.dflt); t.reach = (const uint32_t*)(w + l.reach); t.nexc = w + l.nexc; t.etok = w + l.etok;
   t.emask = (const uint32_t*)(w + l.emask); t.fill = w + l.fill; t.bits = (const uint32_t*)(w + l.bits);
   t.E = d.E; t.P = d.P; t.NW = l.NW;
   return t;
@@ -77,7 +79,8 @@ __device__ __forceinline__ int block_sum_int(int v, int* sh) {
 // one workgroup per (machine, from-state): fsm[m, s, :, :] (S target rows of V bytes) -> the compiled form
 __global__ __launch_bounds__(256) void fsm_compile_kernel(const uint8_t* __restrict__ fsm, int S, int V, int E, int P, int NW,
                                                           int* __restrict__ ok, uint32_t* __restrict__ dflt,
-                                                          int* __restrict__ nexc, int* __restrict__ etok,
+                                                          uint32_t* __restrict__ reach, int* __restrict__ nexc,
+                                                          int* __restrict__ etok,
                                                           uint32_t* __restrict__ emask, int* __restrict__ fill,
                                                           uint32_t* __restrict__ bits) {
   __shared__ int sh[4];
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(256) void fsm_compile_kernel(const uint8_t* __restr
     if (total <= E) chosen = k;
   }
   if (chosen < 0) {
-    if (t == 0) { ok[ms] = 0; dflt[ms] = 0u; nexc[ms] = 0; }
+    if (t == 0) { ok[ms] = 0; dflt[ms] = 0u; reach[ms] = 0xffffffffu; nexc[ms] = 0; }   // (dense scans: no shortcut)
     for (int j = t; j < P; j += 256) fill[(size_t)ms * P + j] = -1;
     return;
   }
@@ -124,9 +127,14 @@ __global__ __launch_bounds__(256) void fsm_compile_kernel(const uint8_t* __restr
     __syncthreads();
   }
   int pos = scan[t] - cnt;
+  __shared__ uint32_t s_reach;
+  if (t == 0) s_reach = c;
+  __syncthreads();
+  uint32_t my_reach = 0u;
   for (int w = lo; w < hi; ++w) {
     const uint32_t tw = T(w);
     if (tw != c) {
+      my_reach |= tw;
       etok[(size_t)ms * E + pos] = w;
       emask[(size_t)ms * E + pos] = tw;
       const int u = w >> 8;
@@ -134,9 +142,10 @@ __global__ __launch_bounds__(256) void fsm_compile_kernel(const uint8_t* __restr
       ++pos;
     }
   }
+  if (my_reach) atomicOr(&s_reach, my_reach);
   __syncthreads();
   if (t == 0) {
-    ok[ms] = 1; dflt[ms] = c; nexc[ms] = total;
+    ok[ms] = 1; dflt[ms] = c; reach[ms] = s_reach; nexc[ms] = total;
     int e = 0, f = 0;
     for (int w = 0; w < V && f < P; ++w) {
       if (e < total && etok[(size_t)ms * E + e] == w) ++e;
@@ -249,6 +258,7 @@ __global__ __launch_bounds__(256) void beam_row_fsm_kernel(const float* __restri
     emask_s[e] = T.emask[ms * E + e];
     xe[e] = xval(tok);
   }
+  const uint32_t reach = T.reach[ms];
   if (junk) {   // all-zero row: the best non-exception tokens are the smallest ones
     if (t < per_node) { ntv[t] = 0.f; nti[t] = fill[t]; }
   } else {
@@ -284,9 +294,15 @@ __global__ __launch_bounds__(256) void beam_row_fsm_kernel(const float* __restri
   const uint32_t D = T.dflt[ms];
   const int lane = t & 63, wave = t >> 6;
   const int ncand = nx + per_node;
+  // A state this from-state cannot reach at all (no token leads there: most of the S targets of a constraint machine) sees an
+  // all-forbidden row, every token worth -1e20: its answer is the first per_node tokens - no selection
   for (int i = wave; i < S; i += 4) {
     const bool in_d = (D >> i) & 1u;
     const size_t base = ((((size_t)b * S + i) * S + s) * beam + k) * per_node;   // scratch layout (b, i, s, k, n)
+    if (!((reach >> i) & 1u)) {
+      if (lane < per_node) { sval[base + lane] = -1e20f; sidx[base + lane] = lane; }
+      continue;
+    }
     Cand prev{INFINITY, -1};
     for (int n = 0; n < per_node; ++n) {
       Cand best{-INFINITY, -1};
@@ -465,7 +481,7 @@ extern "C" int ssc_fsm_compile(const uint8_t* fsm, const ssc_fsm_dims* d, void* 
   if (tables_bytes < l.total * sizeof(int)) return SSC_EWORKSPACE;
   int* w = (int*)tables;
   SSC_LAUNCH(fsm_compile_kernel, dim3(d->M * d->S), dim3(256), 0, (hipStream_t)stream, fsm, d->S, d->V, d->E, d->P, l.NW,
-             w + l.ok, (uint32_t*)(w + l.dflt), w + l.nexc, w + l.etok, (uint32_t*)(w + l.emask), w + l.fill,
+             w + l.ok, (uint32_t*)(w + l.dflt), (uint32_t*)(w + l.reach), w + l.nexc, w + l.etok, (uint32_t*)(w + l.emask), w + l.fill,
              (uint32_t*)(w + l.bits));
   SSC_CHECK_LAUNCH();
   return SSC_OK;

@@ -90,6 +90,10 @@ __global__ void lstm_fwd_kernel(const ssc_lstm_fwd_desc d) {
   int j = blockIdx.x * blockDim.x + threadIdx.x;
   int b = blockIdx.y;
   if (j >= d.H) return;
+  if (d.rows) {   // only the listed rows (decode: the rows that are read at all)
+    if (b >= *d.row_count) return;
+    b = d.rows[b];
+  }
   const int H = d.H, H4 = 4 * d.H;
   // The kernel moves ~20 MB: it is bound by memory latency, not bandwidth.  Every operand that does not depend on the
   // slab sums is requested first and all slabs (up to 16) in one batch, so about one latency is exposed in total.
@@ -1246,6 +1250,7 @@ extern "C" int ssc_lstm_fwd(const ssc_lstm_fwd_desc* d, void* stream) {
   if (d->nslab > 0 && !d->slabs) return SSC_EINVAL;
   if (d->sent && !d->wcol) return SSC_EINVAL;
   if (d->add1 && d->rows_per_add1 <= 0) return SSC_EINVAL;
+  if ((d->rows != nullptr) != (d->row_count != nullptr)) return SSC_EINVAL;
   SSC_LAUNCH(lstm_fwd_kernel, dim3(ssc_cdiv(d->H, 128), d->B), dim3(128), 0, S(stream), *d);
   SSC_CHECK_LAUNCH();
   return SSC_OK;

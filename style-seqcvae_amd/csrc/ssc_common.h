@@ -111,3 +111,5 @@ struct SscGemmModeScope {
   ~SscGemmModeScope() { ssc_tls_gemm_mode = prev; ssc_tls_gemm_f16 = prev16; }
 };
 int ssc_decode_parts_enabled();        // the "dec_parts" switch (decode.hip): vocabulary head records instead of logits
+int ssc_attn_weights_rows(const float* q, int ldq, const float* pv, const float* wa, const float* mask, int G, int R, int A,
+                          int rows_per_image, float* logits, float* alpha, const int* rows, const int* row_count, hipStream_t st);

@@ -39,7 +39,7 @@ class LstmFwdDesc(C.Structure):
                 ("b_ih", vp), ("b_hh", vp), ("sent", vp), ("wcol", vp), ("ldwcol", C.c_int), ("c_prev", vp),
                 ("ld_cprev", C.c_int), ("gates_out", vp), ("c_out", vp), ("ld_cout", C.c_int), ("h_out", vp),
                 ("ld_hout", C.c_int), ("add0_rows", vp), ("slab_rows", vp), ("slabs2", vp), ("nslab2", C.c_int),
-                ("slab2_stride", C.c_size_t), ("slab2_rows", vp), ("c_prev_rows", vp)]
+                ("slab2_stride", C.c_size_t), ("slab2_rows", vp), ("c_prev_rows", vp), ("rows", vp), ("row_count", vp)]
 
 
 class LstmBwdDesc(C.Structure):

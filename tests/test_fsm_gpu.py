@@ -52,7 +52,7 @@ def _read_tables(c: CompiledFsm):
     t = c.tables.cpu()
     o = 0
     out = {}
-    for name, n in (("ok", M * S), ("dflt", M * S), ("nexc", M * S), ("etok", M * S * E), ("emask", M * S * E), ("fill", M * S * P),
+    for name, n in (("ok", M * S), ("dflt", M * S), ("reach", M * S), ("nexc", M * S), ("etok", M * S * E), ("emask", M * S * E), ("fill", M * S * P),
                     ("bits", M * S * 256 * NW)):
         out[name] = t[o:o + n]
         o += r(n)
@@ -84,6 +84,10 @@ def test_compiled_tables_describe_the_dense_machine(tmp_path, V, E):
         rebuilt = torch.full((V,), int(t["dflt"][ms]) & 0xFFFFFFFF, dtype=torch.long)
         rebuilt[tok] = t["emask"][ms * E: ms * E + n].long() & 0xFFFFFFFF
         assert torch.equal(rebuilt, want), (m, s)
+        reach = 0
+        for v in want.unique().tolist():
+            reach |= v
+        assert (int(t["reach"][ms]) & 0xFFFFFFFF) == reach
         is_exc = torch.zeros(V, dtype=torch.bool)
         is_exc[tok] = True
         nonexc = (~is_exc).nonzero().view(-1)[:4]
