@@ -616,7 +616,9 @@ typedef struct {
   const void* tables;            /* ssc_fsm_compile of `fsm`, or NULL: dense scans */
   ssc_fsm_dims dims;             /* of `tables` */
   const int* mach;               /* (B) machine of every batch entry, or NULL: machine b */
-  int skip_dead;                 /* ssc_beam_desc.skip_dead + ssc_decode_step_desc.row_lp (needs `tables`) */
+  int skip_dead;                 /* ssc_beam_desc.skip_dead + ssc_decode_step_desc.row_lp: rows without a finite beam (needs `tables`) and rows
+                                  * whose beam has ended (any machine; with the trivial machine these are the only ones) are neither
+                                  * stepped nor scored from logits */
   int early_stop;                /* cbs.py:167 */
   int64_t* predictions;          /* out (B, S*beam, max_steps): columns [0, ctl[0]) are the search's; the rest holds end_index */
   float* log_probs;              /* out (B, S, beam) */

@@ -73,7 +73,7 @@ bool desc_ok(const ssc_model_cfg* cfg, const ssc_search_desc* d) {
   if (G <= 0 || G > (1L << 24)) return false;
   if (!d->feats || !d->imgbuf || !d->eps0 || (d->max_steps > 1 && !d->eps) || !d->predictions || !d->log_probs || !d->ctl) return false;
   if (d->S > 1 && !d->fsm) return false;
-  if (d->skip_dead && !d->tables) return false;
+  if (d->skip_dead && !d->tables && (d->S != 1 || d->fsm)) return false;   // (the one-state machine has no fill-only rows: skip_dead then only leaves ENDED beams out of the steps)
   if (cfg->kld_mode == 2 ? !d->obj_atts : ((cfg->S || cfg->pm_scale != 0.f) && !d->sentiment)) return false;
   return true;
 }
@@ -175,7 +175,7 @@ extern "C" int ssc_decode_search(const ssc_model_cfg* cfg, const ssc_params* p, 
   const bool ung = SB > 1 && ssc_decode_ungathered_ok(cfg, d->nimg, G, SB, tmode) != 0;
   bool ungathered = false;
   sd.G = G; sd.rows_per_image = rpi; sd.sentiment = d->sentiment ? sent_rows : nullptr; sd.group = SB;
-  bd.skip_dead = d->skip_dead;
+  bd.skip_dead = d->skip_dead && d->tables ? 1 : 0;
   for (int t = 1; t < d->max_steps; ++t) {
     // cbs.py:167: the device notes the step after which every beam had ended and turns later steps into no-ops (ssc_beam_desc.ctl);
     // here the host only stops QUEUEING once it sees the flag the device wrote - a plain read of pinned memory, no wait

@@ -210,7 +210,7 @@ class DecodeEngine:
         if compiled is not None:
             assert compiled.dims.S == S and compiled.dims.P >= per_node
             sd.tables, sd.dims = _lib.ptr(compiled.tables), compiled.dims
-        sd.skip_dead = 1 if (skip_dead and compiled is not None) else 0
+        sd.skip_dead = 1 if (skip_dead and (compiled is not None or fsm is None)) else 0
         sd.early_stop = 1 if early_stop else 0
         pred = torch.empty(B, S * beam, max_steps, dtype=torch.int64, device=dev)
         lps = torch.empty(B, S, beam, dtype=torch.float32, device=dev)

@@ -27,7 +27,7 @@ def diverse_decode(dec: DecodeEngine, feats: torch.Tensor, sentiment: Optional[t
     image, shared by its n_samples latent samples through an index list -, or (nimg*n_samples, S, S, V) (a copy per sample).
     eps_steps: optional explicit noise per step call [(rows_k, Z)]; default: a generator of this call's own, seeded by ONE draw
     from the global CPU generator - the global random state a call consumes does not depend on how many steps it ran.
-    skip_dead (machines with more than one state): rows that hold no finite beam - the states an image's constraints never reach,
+    skip_dead: rows that hold no finite beam - the states an image's constraints never reach,
     every state before its first constraint word has been decoded - and rows whose beam has ended are neither stepped nor scored from
     logits (cbs_search(skip_dead=True)).  Every caption with a finite log-prob is the exact search's; should a selected caption
     have none (its constraints were not reachable within max_steps), the call is repeated exactly, with the same noise.
@@ -48,7 +48,7 @@ def diverse_decode(dec: DecodeEngine, feats: torch.Tensor, sentiment: Optional[t
         assert fsm.size(0) == nimg, (fsm.shape, nimg, n_samples)
         mach = torch.arange(nimg, dtype=torch.int32, device=dev).repeat_interleave(n_samples)
     seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if eps_steps is None else None
-    skip = bool(skip_dead) and not trivial and fsm.size(1) > 1
+    skip = bool(skip_dead) and (trivial or fsm.size(1) > 1)   # (trivial machine: only ended beams are left out of the steps)
     if not trivial and fsm.size(1) > 1 and compiled is None:
         from .decode import CompiledFsm
         compiled = CompiledFsm(fsm, fill=max(8, per_node or (beam // 2) or beam))

@@ -444,3 +444,23 @@ def test_search_from_records_equals_search_from_logits(end_bias, early):
     assert float((l1 - l0).abs().max()) < 2e-5
     if early:
         assert p1.shape[-1] < steps
+
+
+def test_ended_beams_are_not_stepped_in_a_one_state_search():
+    """skip_dead with the trivial machine: a beam that has emitted END re-emits END whatever its logits are (cbs.py:177-181), so
+    its row is left out of every product of the later steps - same captions as the search that steps every row (most beams end
+    early here; the search itself only stops when ALL have)."""
+    from ssc_runtime.inference import diverse_decode
+    V, R, Z, steps, nimg, ns, beam = 600, 6, 8, 9, 8, 16, 5
+    m = _small_captioner(V, end_bias=4.0)
+    dec = m._dec
+    g = torch.Generator().manual_seed(9)
+    feats = torch.randn(nimg, R, 64, generator=g).cuda()
+    senti = torch.randint(-1, 2, (nimg,), generator=g).float().cuda()
+    B = nimg * ns
+    eps = [torch.randn(B, Z, generator=g).cuda()] + [torch.randn(B * beam, Z, generator=g).cuda() for _ in range(steps - 1)]
+    outs = [diverse_decode(dec, feats, senti, ns, beam, steps, 1, eps_steps=[e.clone() for e in eps], early_stop=False, skip_dead=sk)[0].clone()
+            for sk in (False, True)]
+    assert torch.equal(outs[0], outs[1])
+    ended = (outs[0] == 1).any(-1).float().mean()
+    assert 0.3 < float(ended)          # the case does have ended beams
