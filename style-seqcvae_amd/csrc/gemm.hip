@@ -1132,6 +1132,8 @@ template <int R> struct X3wPlane {   // one bf16 plane of an R-row operand tile:
   static constexpr int BYTES = KC_BYTES > MC_BYTES ? KC_BYTES : MC_BYTES;
 };
 template <int TM, int TN> constexpr int x3w_lds_bytes() { return 2 * 3 * (X3wPlane<TM>::BYTES + X3wPlane<TN>::BYTES) + X3W_STAMP_BYTES; }
+// the 2xFP16 form keeps two planes per operand: 80 KB for a 128x128 tile - TWO workgroups per CU (160 KB of LDS) when they have 8 waves
+template <int TM, int TN> constexpr int x3w_lds_bytes_f16() { return 2 * 2 * (X3wPlane<TM>::BYTES + X3wPlane<TN>::BYTES) + X3W_STAMP_BYTES; }
 
 // F16: the operands are split into two fp16 planes and multiplied with THREE partial products (lo*hi, hi*lo, hi*hi) on
 // v_mfma_f32_32x32x16_f16 instead of three bf16 planes and six products - half the matrix-pipe work of a product that is bound by
@@ -1147,7 +1149,9 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
   // K-segment change (base_ptrs), which drains the hand-staged prefetch too.
   constexpr bool RL = TM == 128;
   static_assert(!KG || PF == 1, "the gather lists' own loads share the vector-memory counter");
-  constexpr int PLA = X3wPlane<TM>::BYTES, PLB = X3wPlane<TN>::BYTES, STAGE = 3 * (PLA + PLB);
+  constexpr int NPL = F16 ? 2 : 3;   // planes per operand
+  constexpr int PLA = X3wPlane<TM>::BYTES, PLB = X3wPlane<TN>::BYTES, STAGE = NPL * (PLA + PLB);
+  static_assert(TM * (TN + 4) * 4 <= 2 * STAGE, "the epilogue's C tile reuses the operand stages");
   constexpr int MCA = X3wPlane<TM>::MC_ROW_B, MCB = X3wPlane<TN>::MC_ROW_B;
   static_assert(NPW == 4 || NPW == 8, "producer waves");
   constexpr int NPT = 64 * NPW;                  // producer threads
@@ -1372,7 +1376,7 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
 #pragma unroll
       for (int u = 0; u < NB; ++u) {
         const int idx = tid + NPT * u;
-        put_chunk(st + 3 * PLA + (B_KC ? kc_row(tid, u, NB) * PL_ROW_B + (idx & 7) * 8 : (idx / QB) * MCB + (idx % QB) * 8), PLB, xb[u], all || ((mb >> u) & 1u), f16_sb);
+        put_chunk(st + NPL * PLA + (B_KC ? kc_row(tid, u, NB) * PL_ROW_B + (idx & 7) * 8 : (idx / QB) * MCB + (idx % QB) * 8), PLB, xb[u], all || ((mb >> u) & 1u), f16_sb);
       }
     };
     // a k-step inside its segment (uniform test: a scalar branch around VALU + LDS work only) needs no per-chunk select
@@ -1480,7 +1484,7 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
       };
       auto rdb = [&](int kk, int pl) __attribute__((always_inline)) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) fb[kk][t][pl] = frag(st + 3 * PLA + pl * PLB, B_KC, MCB, wn * 64 + t * 32, kk);
+        for (int t = 0; t < 2; ++t) fb[kk][t][pl] = frag(st + NPL * PLA + pl * PLB, B_KC, MCB, wn * 64 + t * 32, kk);
       };
       rda(0, 1); rdb(0, 0); rda(0, 0); rdb(0, 1);
       __builtin_amdgcn_sched_barrier(0);
@@ -1505,7 +1509,7 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
     };
     auto rdb = [&](int kk, int pl) __attribute__((always_inline)) {
 #pragma unroll
-      for (int t = 0; t < 2; ++t) fb[kk][t][pl] = frag(st + 3 * PLA + pl * PLB, B_KC, MCB, wn * 64 + t * 32, kk);
+      for (int t = 0; t < 2; ++t) fb[kk][t][pl] = frag(st + NPL * PLA + pl * PLB, B_KC, MCB, wn * 64 + t * 32, kk);
     };
     // six partial products per accumulator, smallest first (lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi); the reads are
     // ordered by first use and the first fragments of the second k-half are requested under the first half's MFMAs
@@ -1690,7 +1694,7 @@ struct KGroup {
   int gx[SSC_GROUP_MAX], gy[SSC_GROUP_MAX], gz[SSC_GROUP_MAX];
 };
 template <bool A_KC, bool B_KC, bool KG, int TM, int TN, int PF, int NPW = 4, bool F16 = false>
-__global__ __launch_bounds__(256 + 64 * NPW) void gemm_x3w_kernel(const KGroup g) {
+__global__ __launch_bounds__(256 + 64 * NPW, (F16 && NPW == 4) ? 4 : 1) void gemm_x3w_kernel(const KGroup g) {
   const int w = blockIdx.x;
   int p = 0;
 #pragma unroll
@@ -1944,7 +1948,10 @@ int x3w_prepare() {
   for (group_fn f : big)
     if (hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, x3w_lds_bytes<128, 128>()) != hipSuccess) return SSC_EHIP;
   if (hipFuncSetAttribute((const void*)gemm_x3w_kernel<true, true, false, 128, 128, 2, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                          x3w_lds_bytes<128, 128>()) != hipSuccess)
+                          x3w_lds_bytes_f16<128, 128>()) != hipSuccess)
+    return SSC_EHIP;
+  if (hipFuncSetAttribute((const void*)gemm_x3w_kernel<true, true, false, 128, 128, 2, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                          x3w_lds_bytes_f16<128, 128>()) != hipSuccess)
     return SSC_EHIP;
   group_fn skinny[6] = {gemm_x3w_kernel<true, true, false, 64, 256, 2>, gemm_x3w_kernel<true, false, false, 64, 256, 2>,
                         gemm_x3w_kernel<true, true, false, 64, 256, 3>, gemm_x3w_kernel<true, false, false, 64, 256, 3>,
@@ -1954,6 +1961,7 @@ int x3w_prepare() {
   done = true;
   return SSC_OK;
 }
+int g_f16_npw = ssc_env_int("SSC_F16_NPW", 4);   // producer waves of the 2xFP16 kernel: 4 (default: two 8-wave workgroups per CU - 80 KB of LDS each - so that one's pipeline fill and epilogue run under the other's k-loop: 10000 x 4800 x 2400 843 -> 750 us, same box) | 8 (one 12-wave workgroup per CU)
 int g_gemm_f16 = ssc_env_int("SSC_GEMM_F16", 0);   // process default of the 2xFP16 form when no sequence-level call's cfg is in force
 int g_x3w_skinny = ssc_env_int("SSC_X3W_SKINNY", 1);  // 0 off, 1 NT and NN, 2 NN only (hook -11 / -12 / -13)
 int g_x3w_min_n = ssc_env_int("SSC_X3W_MIN_N", 1024);   // narrower products do not fill the chip with 256-column tiles (rocprof: slower than the 64-wide kernels)
@@ -2064,16 +2072,23 @@ int launch(const ssc_gemm_desc* d, KArgs& k, int splits, hipStream_t st) {
     // (below 512 rows - one to four tile rows, split-K - the wave-specialised form wins at every grid size: 59 vs 71 us at 128 x 4800 x 5648)
     // (2xFP16 numerics requested and applicable: the wave-specialised form at every grid size - its F16 variant is 1.5x the 3xBF16
     // one, which outweighs what the 4-wave kernel gains on grids below three rounds)
+    // (NT only.  The NN / TN / TN-with-row-lists forms were instantiated and measured in round 4 for the TRAIN step's large products -
+    // weight gradients 4800 x 5448 x 1344 with k-row lists 355 -> 266 us, vocabulary-head input gradient 328 -> 267 us, error against
+    // float64 6-8e-7 of sum|a||b| with measured scales, as good as 3xBF16 - but 1.23-1.33x on 20 % of a step, minus the per-step
+    // absmax passes over the gradient operands, is ~3 % of the train step: not taken, the training numerics stay 3xBF16.)
     const bool f16 = (ssc_tls_gemm_f16 >= 0 ? ssc_tls_gemm_f16 : g_gemm_f16) && d->a_kc && d->b_kc && !kg && g_x3w_big_npw == 8 && g_x3b != 3;
     if (k.topk && !(d->a_kc && d->b_kc && !kg && splits == 1 && x3w_span_ok(d))) return SSC_EINVAL;   // the records exist in this form's epilogue only
     if ((k.topk || g_x3b == 2 || (g_x3b == 1 && (f16 || wgs >= 768 || (d->M < 512 && big_tile(d->M, d->N))))) && x3w_span_ok(d) && (!kg || kg_both)) {  // wave-specialised form: 12 waves, 120 KB of dynamic LDS
       group_fn fn = x3w_big_fn(d->a_kc, d->b_kc, kg);
-      if (f16) fn = gemm_x3w_kernel<true, true, false, 128, 128, 2, 8, true>;
+      // 2xFP16: two planes per operand = 80 KB per workgroup; with 4 producer waves (8 waves per workgroup) TWO workgroups share a
+      // CU, so one's pipeline fill / epilogue runs under the other's k-loop (g_f16_npw = 4)
+      if (f16) fn = g_f16_npw == 4 ? gemm_x3w_kernel<true, true, false, 128, 128, 2, 4, true> : gemm_x3w_kernel<true, true, false, 128, 128, 2, 8, true>;
       SSC_TRY(x3w_prepare());
       KGroup g1;
       group_of_one(g1, k, grid);
       SSC_AUDIT_BEGIN();
-      SSC_LAUNCH(fn, dim3(g1.first[1]), dim3(x3w_big_threads()), (x3w_lds_bytes<128, 128>()), st, g1);
+      if (f16) SSC_LAUNCH(fn, dim3(g1.first[1]), dim3(g_f16_npw == 4 ? 512 : 768), (x3w_lds_bytes_f16<128, 128>()), st, g1);
+      else SSC_LAUNCH(fn, dim3(g1.first[1]), dim3(x3w_big_threads()), (x3w_lds_bytes<128, 128>()), st, g1);
       SSC_AUDIT_END(g1, d->a_kc != 0, d->b_kc != 0, "128x128", st);
     } else
     if (d->a_kc && d->b_kc) SSC_LAUNCH((gemm_x3b_kernel<true, true, false>), grid, dim3(256), 0, st, k);
@@ -2516,6 +2531,7 @@ const DebugKey g_debug_keys[] = {
     {"dec_ungathered", &ssc_g_dec_ungathered}, // decode: states left in the previous step's row order, read through the parent lists (1 | 0)   (SSC_DEC_UNGATHERED)
     {"dec_parts", &ssc_g_dec_parts},           // decode: the vocabulary head of a one-state search leaves per-tile records instead of logits (1 | 0)   (SSC_DEC_PARTS)
     {"dec_att_table", &ssc_g_dec_att_table},   // decode: attended-feature term of the decoder gates from a per-image table (1 | 0)   (SSC_DEC_ATT_TABLE)
+    {"f16_npw", &g_f16_npw},         // 2xFP16 kernel: producer waves (8 | 4 = two workgroups per CU)   (SSC_F16_NPW)
     {"gemm_f16", &g_gemm_f16},       // op-level products (ssc_gemm outside a sequence-level call): 1 = the wave-specialised 128x128 NT form takes the 2xFP16 split (what ssc_model_cfg.gemm_mode 3 selects per call)
     {"big_min_m", &g_big_min_m},     // rows from which a product with N >= 512 takes 128x128 tiles (65; 512 = the behaviour until late in round 2)   (SSC_BIG_MIN_M)
 };
