@@ -55,6 +55,12 @@ const char* ssc_arch(void);         /* "gfx950" */
 typedef struct {
   const float* A; const float* B;
   int lda, ldb, K;
+  /* Optional, read by the 2xFP16 form only (k-contiguous operands): the SAME operand already split into its two fp16 pieces by
+   * ssc_split_f16 with the product's a_scale / b_scale ("planes"; ld in 4-byte words, >= K rounded up to 32, a multiple of 4;
+   * 16-byte aligned).  The kernel then copies the pieces instead of forming them once per tile that reads the operand - bit-identical
+   * results.  A / B stay mandatory: every other form of the product reads them.  NULL = split inside the kernel. */
+  const void* A16; const void* B16;
+  int lda16, ldb16;
 } ssc_gemm_seg;
 
 typedef struct {
@@ -94,6 +100,13 @@ typedef struct {
  * scratch: one float of device memory. */
 int ssc_pow2_scale(const float* x, size_t rows, int cols, size_t ld, int target_log2, float* out, int combine, float* scratch,
                    void* stream);
+
+/* The two fp16 pieces of x * scale[0] (rows x K, ld ldx; scale: device scalar, a power of two, NULL = 1) in the plane layout of
+ * ssc_gemm_seg.A16 / B16: row r occupies ldo 4-byte words; per 32-k block 32 hi halfs (x truncated to fp16) then 32 lo halfs
+ * (x - hi truncated); columns K .. roundup(K, 32) are zero.  ldo >= roundup(K, 32), ldo % 4 == 0, out 16-byte aligned.
+ * rows / row_count (optional, device): only the listed rows. */
+int ssc_split_f16(const float* x, int rows, int K, int ldx, const float* scale, void* out, int ldo, const int* row_list,
+                  const int* row_count, void* stream);
 
 int ssc_gemm(const ssc_gemm_desc* d, void* stream);
 

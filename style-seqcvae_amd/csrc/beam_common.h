@@ -37,6 +37,29 @@ __device__ __forceinline__ Cand block_best(Cand c, Cand* sh) {
   return r;
 }
 
+// One-barrier forms for kernels that run several reductions in a row: consecutive reductions alternate between two LDS slots
+// (`par` = 0, 1, 0, ...), so the write of reduction n + 1 cannot overtake a slow wave's read of reduction n - 1's slot (there is a
+// barrier of reduction n in between), and the leading barrier of the two-barrier forms is not needed.  Same arithmetic and order.
+__device__ __forceinline__ Cand block_best1(Cand c, Cand (*sh)[4], int par) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  c = wave_best(c);
+  if (lane == 0) sh[par][wv] = c;
+  __syncthreads();
+  Cand r = sh[par][0];
+  for (int k = 1; k < nw; ++k)
+    if (sh[par][k].i >= 0 && (r.i < 0 || better(sh[par][k].v, sh[par][k].i, r))) r = sh[par][k];
+  return r;
+}
+__device__ __forceinline__ float dec_block_reduce1(float v, float (*sh)[4], int par, bool is_max) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  v = is_max ? ssc_wave_max(v) : ssc_wave_sum(v);
+  if (lane == 0) sh[par][wv] = v;
+  __syncthreads();
+  float r = sh[par][0];
+  for (int i = 1; i < nw; ++i) r = is_max ? fmaxf(r, sh[par][i]) : r + sh[par][i];
+  return r;
+}
+
 // block reduction with exactly the arithmetic of log_softmax_kernel (256 threads, strided partials, this order)
 __device__ __forceinline__ float dec_block_reduce(float v, float* sh, bool is_max) {
   int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;

@@ -21,6 +21,12 @@ inline size_t r64(size_t x) { return (x + 63) & ~(size_t)63; }
 
 struct ImgLayout {
   size_t mask, avg, pv, ga_avg, wsum_att, wsum_dec, wz, wc, emb_gates, pd, scales, scratch, scratch_floats, total;
+  // 2xFP16 products of the large calls: the weights that meet a recurrent state, already split into their fp16 pieces with the scale
+  // of their product (ssc_split_f16; Hk = H rounded up to 32 four-byte words per row) - the product kernels then copy the pieces
+  // instead of forming them in each of the 40-150 row tiles that read a weight tile (ssc_gemm_seg.B16)
+  size_t pw_att_h1, pw_att_hd, pw_dec_hd, pw_dec_h1, pw_q, pw_out;
+  int Hk;
+  bool planes;
   int Fp, Hp, Zp, Sp;
   bool token_table;   // emb_gates holds the (V, 4H) table emb . W_ih^att[:, :E]^T
   bool att_table;     // pd holds P[img, r, :] = W_ih^dec[:, :F] v_{img,r} (nimg*R x 4H): the decoder gates' attended-feature term per region
@@ -62,6 +68,15 @@ ImgLayout img_layout(const ssc_model_cfg* c, int nimg, int R) {
   // step (K = F + 2H + Z = 4576) loses its K = F = 2048 segment, and the weighted feature sum itself is no longer needed.
   l.att_table = ssc_g_dec_att_table != 0 && R <= 128;
   l.pd = o; o += r64(l.att_table ? (size_t)nimg * R * 4 * c->H : 0);
+  l.Hk = (c->H + 31) / 32 * 32;
+  l.planes = c->gemm_mode == 3 && l.token_table && !c->tied;
+  const size_t wrow = l.planes ? (size_t)l.Hk : 0;
+  l.pw_att_h1 = o; o += r64((size_t)4 * c->H * wrow);
+  l.pw_att_hd = o; o += r64((size_t)4 * c->H * wrow);
+  l.pw_dec_hd = o; o += r64((size_t)4 * c->H * wrow);
+  l.pw_dec_h1 = o; o += r64((size_t)4 * c->H * wrow);
+  l.pw_q = o; o += r64((size_t)c->A * wrow);
+  l.pw_out = o; o += r64((size_t)c->V * wrow);
   l.scales = o; o += 64;   // power-of-two operand scales of the 2xFP16 products (ssc_model_cfg.gemm_mode 3), see DecScales
   size_t a = (size_t)nimg * R * c->A, b = (size_t)nimg * 4 * c->H;
   l.scratch_floats = 33 * (a > b ? a : b);
@@ -72,6 +87,8 @@ ImgLayout img_layout(const ssc_model_cfg* c, int nimg, int R) {
 
 struct StepLayout {
   size_t emb, q, att, z, pm, c1, attn_logits, proj, wcol, slabs, slab_floats, total;
+  size_t p_h1, p_hd, p_h1o, p_hdo;   // gemm_mode 3: the recurrent states (previous h1, hd; new h1, hd) split into their fp16 pieces (ssc_gemm_seg.A16), G x Hk words
+  int Hk;
   size_t dedup;   // int32: [0] = number of distinct parents, [1] = number of live rows, [4 .. 4+G) = the parents' representative rows (ascending),
                   // [4+G .. 4+2G) = slot of every row, [4+2G ..) = previous-state row of every row, [4+3G ..) = live rows (ascending)
   int Ep, Ap, Fp, Zp;
@@ -89,6 +106,12 @@ StepLayout step_layout(const ssc_model_cfg* c, int G, int R) {
   l.attn_logits = o; o += r64((size_t)G * R);
   l.proj = o; o += r64(c->tied ? (size_t)G * l.Ep : 0);
   l.wcol = o; o += r64((size_t)4 * c->H);
+  l.Hk = (c->H + 31) / 32 * 32;
+  const size_t prow = c->gemm_mode == 3 && !c->tied && G >= 512 ? (size_t)l.Hk : 0;
+  l.p_h1 = o; o += r64((size_t)G * prow);
+  l.p_hd = o; o += r64((size_t)G * prow);
+  l.p_h1o = o; o += r64((size_t)G * prow);
+  l.p_hdo = o; o += r64((size_t)G * prow);
   l.dedup = o; o += r64((size_t)6 * G + 8);   // (+ two counts per workgroup of the list kernels)
   size_t skinny = (size_t)33 * G * 4 * c->H;
   size_t full = (size_t)16 * 1024 * 1024;  // 64 MB: split-K slabs of the large GEMMs
@@ -102,6 +125,8 @@ struct Seg {
   const float* A; int lda;
   const float* B; int ldb;
   int K;
+  const float* A16 = nullptr; const float* B16 = nullptr;   // the operands' pre-split fp16 pieces (ld16 words per row), or nullptr
+  int ld16 = 0;
 };
 
 // Power-of-two operand scales for the 2xFP16 form of the large products (ssc_gemm_desc.a_scale / b_scale), kept in the image buffer:
@@ -120,6 +145,7 @@ void fill_desc(ssc_gemm_desc& d, std::initializer_list<Seg> segs, int M, int N) 
   for (const Seg& s : segs) {
     if (s.K <= 0) continue;
     d.seg[i].A = s.A; d.seg[i].lda = s.lda; d.seg[i].B = s.B; d.seg[i].ldb = s.ldb; d.seg[i].K = s.K;
+    d.seg[i].A16 = s.A16; d.seg[i].lda16 = s.A16 ? s.ld16 : 0; d.seg[i].B16 = s.B16; d.seg[i].ldb16 = s.B16 ? s.ld16 : 0;
     ++i;
   }
   d.nseg = i; d.M = M; d.N = N; d.a_kc = 1; d.b_kc = 1;
@@ -529,6 +555,15 @@ extern "C" int ssc_decode_prepare_from(const ssc_model_cfg* cfg, const ssc_param
                            (size_t)S * sizeof(float), H4, hipMemcpyDeviceToDevice, st) != hipSuccess)
         return SSC_EHIP;
     }
+    if (l.planes) {   // (after the sums above and the scales: all on this stream)
+      const float* wr = p->att_w_ih + E + F;
+      SSC_TRY(ssc_split_f16(W + l.wsum_att, H4, H, l.Hp, SC + SC_ATTW, W + l.pw_att_h1, l.Hk, nullptr, nullptr, st));
+      SSC_TRY(ssc_split_f16(wr + H, H4, H, p->ld_att_w_ih, SC + SC_ATTW, W + l.pw_att_hd, l.Hk, nullptr, nullptr, st));
+      SSC_TRY(ssc_split_f16(W + l.wsum_dec, H4, H, l.Hp, SC + SC_DEC, W + l.pw_dec_hd, l.Hk, nullptr, nullptr, st));
+      SSC_TRY(ssc_split_f16(p->dec_w_ih + F, H4, H, p->ld_dec_w_ih, SC + SC_DEC, W + l.pw_dec_h1, l.Hk, nullptr, nullptr, st));
+      SSC_TRY(ssc_split_f16(p->wq, A, H, p->ld_wq, SC + SC_Q, W + l.pw_q, l.Hk, nullptr, nullptr, st));
+      SSC_TRY(ssc_split_f16(p->out_w, cfg->V, H, p->ld_out_w, SC + SC_OUT, W + l.pw_out, l.Hk, nullptr, nullptr, st));
+    }
   }
   return SSC_OK;
 }
@@ -538,6 +573,7 @@ extern "C" size_t ssc_decode_step_workspace_bytes(const ssc_model_cfg* cfg, int 
   return step_layout(cfg, G, R).total * sizeof(float);
 }
 
+int ssc_g_dec_planes = ssc_env_int("SSC_DEC_PLANES", 1);   // ssc_debug_set("dec_planes"): 0 = the 2xFP16 products split their operands themselves
 int ssc_g_dec_ungathered = ssc_env_int("SSC_DEC_UNGATHERED", 1);   // ssc_debug_set("dec_ungathered"): 0 = the caller re-orders the states
 extern "C" int ssc_decode_ungathered_ok(const ssc_model_cfg* cfg, int nimg, int G, int group, int att_table) {
   if (!cfg || nimg <= 0 || G <= 0) return 0;
@@ -611,13 +647,26 @@ extern "C" int ssc_decode_step(const ssc_model_cfg* cfg, const ssc_params* p, co
     return ssc_gemm(&g, st);
   };
   float* slabs_u = slabs + (size_t)G * H4;   // second product of the decoder gates (distinct parents): behind the first one's rows
+  // 2xFP16 products of a large call: the states are split into their fp16 pieces once per step (the distinct parents' previous
+  // states here, the new h1 / hd behind their cells) instead of in every column tile of the products that read them (38-79 times);
+  // the weights' pieces come from the image context.  Every other form of a product ignores the pieces.
+  const bool planes = il.planes && dedup && att_table && ssc_g_dec_planes && l.p_hd != l.p_h1;
+  const int Hk = l.Hk;
+  float* PH1 = planes ? W + l.p_h1 : nullptr; float* PHD = planes ? W + l.p_hd : nullptr;
+  float* PH1O = planes ? W + l.p_h1o : nullptr; float* PHDO = planes ? W + l.p_hdo : nullptr;
+  auto PW = [&](size_t off) -> const float* { return planes ? I + off : nullptr; };
+  if (planes) {
+    SSC_TRY(ssc_split_f16(d->h1, G, H, H, sc.at(SC_ACT), PH1, Hk, urows, ucount, st));
+    SSC_TRY(ssc_split_f16(d->hd, G, H, H, sc.at(SC_ACT), PHD, Hk, urows, ucount, st));
+  }
 
   // embedding + attention LSTM (updown_captioner.py:430, updown_cell.py:143-148)
   {
     const float* wr = p->att_w_ih + E + F;
     ssc_lstm_fwd_desc f{};
     if (il.token_table && !d->emb_override) {   // the embedding's gate term comes from the per-token table, row = the beam's last token
-      SSC_TRY(gemm_slabs(st, slabs, l.slab_floats, {{d->h1, H, I + il.wsum_att, il.Hp, H}, {d->hd, H, wr + H, p->ld_att_w_ih, H}}, G, H4,
+      SSC_TRY(gemm_slabs(st, slabs, l.slab_floats, {{d->h1, H, I + il.wsum_att, il.Hp, H, PH1, PW(il.pw_att_h1), Hk},
+                                                    {d->hd, H, wr + H, p->ld_att_w_ih, H, PHD, PW(il.pw_att_hd), Hk}}, G, H4,
                          &ns, ucount, urows, sc.at(SC_ACT), sc.at(SC_ATTW)));
       if (dedup && ns != 1) return SSC_EINVAL;   // (row lists and split-K slabs do not combine; G >= 512 never splits)
       f.slab_rows = slot;
@@ -636,10 +685,11 @@ extern "C" int ssc_decode_step(const ssc_model_cfg* cfg, const ssc_params* p, co
     f.c_out = d->c1_out; f.ld_cout = H; f.h_out = d->h1_out; f.ld_hout = H;
     if (live) { f.rows = lrows; f.row_count = lcount; }   // (rows nobody reads are not computed: their h1 / c1 stay stale)
     SSC_TRY(ssc_lstm_fwd(&f, st));
+    if (planes) SSC_TRY(ssc_split_f16(d->h1_out, G, H, H, sc.at(SC_ACT), PH1O, Hk, lrows, lcount, st));
   }
   // attention over the image's regions (attention.py:69-95, updown_cell.py:151-158)
-  if (live) SSC_TRY(gemm_live({{d->h1_out, H, p->wq, p->ld_wq, H}}, A, W + l.q, l.Ap, nullptr, sc.at(SC_ACT), sc.at(SC_Q)));
-  else SSC_TRY(gemm_nt(st, slabs, l.slab_floats, {{d->h1_out, H, p->wq, p->ld_wq, H}}, G, A, W + l.q, l.Ap, nullptr, sc.at(SC_ACT), sc.at(SC_Q)));
+  if (live) SSC_TRY(gemm_live({{d->h1_out, H, p->wq, p->ld_wq, H, PH1O, PW(il.pw_q), Hk}}, A, W + l.q, l.Ap, nullptr, sc.at(SC_ACT), sc.at(SC_Q)));
+  else SSC_TRY(gemm_nt(st, slabs, l.slab_floats, {{d->h1_out, H, p->wq, p->ld_wq, H, PH1O, PW(il.pw_q), Hk}}, G, A, W + l.q, l.Ap, nullptr, sc.at(SC_ACT), sc.at(SC_Q)));
   if (att_table && live)
     SSC_TRY(ssc_attn_weights_rows(W + l.q, l.Ap, I + il.pv, p->wa, I + il.mask, G, R, A, rpi, W + l.attn_logits, d->alpha, lrows, lcount, st));
   else if (att_table)
@@ -667,15 +717,15 @@ extern "C" int ssc_decode_step(const ssc_model_cfg* cfg, const ssc_params* p, co
     const int KC = sv2 && S > 1 ? il.Sp : 0;   // conditioning block as a K-segment over its 16-byte padded width (a segment with K = 0 is dropped)
     const Seg cseg{W + l.pm, l.Zp, I + il.wc, il.Sp, KC};
     if (att_table && dedup) {   // hd' segment on the distinct parents, [h1 | z] on every row
-      SSC_TRY(gemm_slabs(st, slabs_u, l.slab_floats - (size_t)G * H4, {{d->hd, H, I + il.wsum_dec, il.Hp, H}}, G, H4, &ns_u, ucount, urows,
+      SSC_TRY(gemm_slabs(st, slabs_u, l.slab_floats - (size_t)G * H4, {{d->hd, H, I + il.wsum_dec, il.Hp, H, PHD, PW(il.pw_dec_hd), Hk}}, G, H4, &ns_u, ucount, urows,
                          sc.at(SC_ACT), sc.at(SC_DEC)));
       if (ns_u != 1) return SSC_EINVAL;
       if (live) {
-        SSC_TRY(gemm_live({{d->h1_out, H, p->dec_w_ih + F, p->ld_dec_w_ih, H}, {W + l.z, l.Zp, I + il.wz, il.Zp, l.Zp}, cseg}, H4, slabs, H4, nullptr,
+        SSC_TRY(gemm_live({{d->h1_out, H, p->dec_w_ih + F, p->ld_dec_w_ih, H, PH1O, PW(il.pw_dec_h1), Hk}, {W + l.z, l.Zp, I + il.wz, il.Zp, l.Zp}, cseg}, H4, slabs, H4, nullptr,
                           sc.at(SC_ACT), sc.at(SC_DEC)));
         ns = 1;
       } else
-        SSC_TRY(gemm_slabs(st, slabs, (size_t)G * H4, {{d->h1_out, H, p->dec_w_ih + F, p->ld_dec_w_ih, H}, {W + l.z, l.Zp, I + il.wz, il.Zp, l.Zp}, cseg},
+        SSC_TRY(gemm_slabs(st, slabs, (size_t)G * H4, {{d->h1_out, H, p->dec_w_ih + F, p->ld_dec_w_ih, H, PH1O, PW(il.pw_dec_h1), Hk}, {W + l.z, l.Zp, I + il.wz, il.Zp, l.Zp}, cseg},
                            G, H4, &ns, nullptr, nullptr, sc.at(SC_ACT), sc.at(SC_DEC)));
     } else if (att_table)   // the attended-feature segment comes from the per-image table inside the cell kernel
       SSC_TRY(gemm_slabs(st, slabs, l.slab_floats,
@@ -699,12 +749,13 @@ extern "C" int ssc_decode_step(const ssc_model_cfg* cfg, const ssc_params* p, co
     f.c_out = d->cd_out; f.ld_cout = H; f.h_out = d->hd_out; f.ld_hout = H;
     if (att_table) SSC_TRY(ssc_lstm_fwd_img(&f, d->alpha, R, I + il.pd, R, rpi, st));
     else SSC_TRY(ssc_lstm_fwd(&f, st));
+    if (planes && (d->topk_part || d->log_probs)) SSC_TRY(ssc_split_f16(d->hd_out, G, H, H, sc.at(SC_ACT), PHDO, Hk, lrows, lcount, st));
   }
   // vocabulary log-probabilities (updown_captioner.py:444-450); skipped when only the cell output is wanted
   if (d->topk_part) {   // records per (row, 128-column tile) instead of the (G, V) logits (ssc_beam_step_parts selects from them)
     if (cfg->tied || cfg->gemm_mode == 2) return SSC_EINVAL;
     ssc_gemm_desc g;
-    fill_desc(g, {{d->hd_out, H, p->out_w, p->ld_out_w, H}}, G, V);
+    fill_desc(g, {{d->hd_out, H, p->out_w, p->ld_out_w, H, PHDO, PW(il.pw_out), Hk}}, G, V);
     g.bias = p->out_b; g.splits = 1; g.topk_part = d->topk_part;
     g.a_scale = sc.at(SC_ACT); g.b_scale = sc.at(SC_OUT);
     if (live) { g.m_count = lcount; g.a_rows = lrows; g.c_rows = lrows; }
@@ -718,9 +769,9 @@ extern "C" int ssc_decode_step(const ssc_model_cfg* cfg, const ssc_params* p, co
     SSC_TRY(gemm_nt(st, slabs, l.slab_floats, {{W + l.proj, l.Ep, p->emb, p->ld_emb, E}}, G, V, d->log_probs, V, nullptr,
                     sc.at(SC_ACT), sc.at(SC_OUT)));
   } else if (live) {
-    SSC_TRY(gemm_live({{d->hd_out, H, p->out_w, p->ld_out_w, H}}, V, d->log_probs, V, p->out_b, sc.at(SC_ACT), sc.at(SC_OUT)));
+    SSC_TRY(gemm_live({{d->hd_out, H, p->out_w, p->ld_out_w, H, PHDO, PW(il.pw_out), Hk}}, V, d->log_probs, V, p->out_b, sc.at(SC_ACT), sc.at(SC_OUT)));
   } else {
-    SSC_TRY(gemm_nt(st, slabs, l.slab_floats, {{d->hd_out, H, p->out_w, p->ld_out_w, H}}, G, V, d->log_probs, V, p->out_b,
+    SSC_TRY(gemm_nt(st, slabs, l.slab_floats, {{d->hd_out, H, p->out_w, p->ld_out_w, H, PHDO, PW(il.pw_out), Hk}}, G, V, d->log_probs, V, p->out_b,
                     sc.at(SC_ACT), sc.at(SC_OUT)));
   }
   if (!d->raw_logits) SSC_TRY(ssc_log_softmax(d->log_probs, V, G, V, d->log_probs, V, st));

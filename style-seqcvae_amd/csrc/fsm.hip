@@ -170,8 +170,9 @@ __global__ __launch_bounds__(256) void beam_row_fsm_kernel(const float* __restri
                                                            int per_node, int end_index, int skip_dead,
                                                            float* __restrict__ sval, int64_t* __restrict__ sidx) {
   extern __shared__ unsigned char smem[];
-  __shared__ Cand sh[4];
-  __shared__ float shr[16];
+  __shared__ Cand sh2[2][4];     // (256 threads = 4 waves; two slots each: the one-barrier reductions of beam_common.h)
+  __shared__ float shr2[2][4];
+  int par = 0;
   const int g = blockIdx.x, t = threadIdx.x;
   const int b = g / (S * beam), s = (g / beam) % S, k = g % beam;
   const int m = mach ? mach[b] : b;
@@ -192,12 +193,12 @@ __global__ __launch_bounds__(256) void beam_row_fsm_kernel(const float* __restri
 #pragma unroll
         for (int u = 0; u < ROW_NV; ++u)
           if (t + u * 256 < V) mx = fmaxf(mx, x[u]);
-        mx = dec_block_reduce(mx, shr, true);
+        mx = dec_block_reduce1(mx, shr2, par, true); par ^= 1;
         float sum = 0.f;
 #pragma unroll
         for (int u = 0; u < ROW_NV; ++u)
           if (t + u * 256 < V) sum += expf(x[u] - mx);
-        sum = dec_block_reduce(sum, shr, false);
+        sum = dec_block_reduce1(sum, shr2, par, false); par ^= 1;
         lse = mx + logf(sum);
 #pragma unroll
         for (int u = 0; u < ROW_NV; ++u) x[u] -= lse;
@@ -209,10 +210,10 @@ __global__ __launch_bounds__(256) void beam_row_fsm_kernel(const float* __restri
   } else if (NORM && !ended && !junk) {   // thread t owns v = t, t + 256, ...: the order of log_softmax_kernel
     float mx = -INFINITY;
     for (int v = t; v < V; v += 256) mx = fmaxf(mx, row[v]);
-    mx = dec_block_reduce(mx, shr, true);
+    mx = dec_block_reduce1(mx, shr2, par, true); par ^= 1;
     float sum = 0.f;
     for (int v = t; v < V; v += 256) sum += expf(row[v] - mx);
-    sum = dec_block_reduce(sum, shr, false);
+    sum = dec_block_reduce1(sum, shr2, par, false); par ^= 1;
     lse = mx + logf(sum);
   }
   auto xval = [&](int v) -> float {   // the cleaned log-prob of token v (cbs.py:177-186), any token
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(256) void beam_row_fsm_kernel(const float* __restri
           const float y = mk[v] ? xval(v) : -1e20f;
           if (after(y, v, prev) && (best.i < 0 || better(y, v, best))) best = Cand{y, v};
         }
-        best = block_best(best, sh);
+        best = block_best1(best, sh2, par); par ^= 1;
         if (t == 0) { sval[base + n] = best.v; sidx[base + n] = best.i; }
         prev = best;
       }
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(256) void beam_row_fsm_kernel(const float* __restri
           if (after(y, v, prev) && (best.i < 0 || better(y, v, best))) best = Cand{y, v};
         }
       }
-      best = block_best(best, sh);
+      best = block_best1(best, sh2, par); par ^= 1;
       if (t == 0) { ntv[n] = best.v; nti[n] = best.i; }
       prev = best;
     }

@@ -38,6 +38,12 @@ struct KSeg {
   const float* B;
   int lda, ldb, K, nsteps;
   int avec, bvec;  // 16 B/lane global loads allowed for this segment's A / B operand
+  // 2xFP16 form only: the operand also exists as PRE-SPLIT fp16 planes (ssc_gemm_seg.A16 / B16, made by ssc_split_f16): per row
+  // and 32-k block 32 hi halfs then 32 lo halfs = the footprint of 32 floats, so a plane operand is addressed exactly like the
+  // fp32 one (ld in 4-byte words) and the producers copy it into LDS without any arithmetic.  nullptr: split in the kernel.
+  const float* A16;
+  const float* B16;
+  int lda16, ldb16;
 };
 
 struct KArgs {
@@ -1215,6 +1221,17 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
     int ia[2][NA], ib[2][NB];   // KG: gathered k-row numbers of the next step, buffer = parity of that step (relative to s_lo)
     Cursor cur;
     int s_ld = s_lo;
+    // 2xFP16: the current segment's operands come as pre-split planes (uniform; KSeg::A16 / B16).  Same addressing as fp32 - the
+    // cursor's base and leading dimension are swapped - and no chunk is ever masked (the planes' K padding holds zeros).
+    bool pa = false, pb = false;
+    auto planes_of_segment = [&]() __attribute__((always_inline)) {
+      if constexpr (F16) {
+        const KSeg& sg = a.seg[cur.seg];
+        pa = sg.A16 != nullptr; pb = sg.B16 != nullptr;
+        if (pa) { cur.A = sg.A16; cur.lda = sg.lda16; }
+        if (pb) { cur.B = sg.B16; cur.ldb = sg.ldb16; }
+      }
+    };
     // chunk idx: k-contiguous operand -> (row idx>>3, k 4*(idx&7)); m/n-contiguous -> (k idx/Q, column 4*(idx%Q))
     auto base_ptrs = [&]() __attribute__((always_inline)) {
       const unsigned lda4 = (unsigned)cur.lda * 4u, ldb4 = (unsigned)cur.ldb * 4u;
@@ -1293,7 +1310,8 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
     // Branch-free (no branch may surround a staged load: see Stage::load_ptrs): every k-step takes the same form - a chunk
     // past the end of K reads the first k of the step instead (always in range) and is zeroed at LDS-store time.
     auto issue_loads = [&](f32x4 (&xa)[NA], f32x4 (&xb)[NB], unsigned& ma, unsigned& mb, bool& full) __attribute__((always_inline)) {
-      ma = mb = 0;
+      ma = pa ? 0x80000000u : 0u;   // bit 31: this set's tile is a plane tile (travels with the register set to its LDS store)
+      mb = pb ? 0x80000000u : 0u;
       full = cur.k0 + BK <= cur.K;
       // uniform bases of this k-step
       const float* sa = cur.A + (A_KC ? (size_t)cur.k0 : (KG ? (size_t)0 : (size_t)cur.k0 * cur.lda));
@@ -1305,7 +1323,7 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
       for (int u = 0; u < NA; ++u) {
         const int idx = tid + NPT * u;
         if constexpr (A_KC) {
-          ea[u] = kc_in ? oa[u] : za[u];
+          ea[u] = (kc_in || pa) ? oa[u] : za[u];
           ma |= (kc_in ? 1u : 0u) << u;
         } else {
           const bool in = cur.k0 + idx / QA < cur.K;
@@ -1318,7 +1336,7 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
       for (int u = 0; u < NB; ++u) {
         const int idx = tid + NPT * u;
         if constexpr (B_KC) {
-          eb[u] = kc_in ? ob[u] : zb[u];
+          eb[u] = (kc_in || pb) ? ob[u] : zb[u];
           mb |= (kc_in ? 1u : 0u) << u;
         } else {
           const bool in = cur.k0 + idx / QB < cur.K;
@@ -1349,6 +1367,7 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
     auto advance = [&](int buf) __attribute__((always_inline)) {   // buf: parity of the step the cursor moves TO (KG row buffers)
       const int how = cur.advance(a, s_ld >= s_last);
       s_ld = min(s_ld + 1, s_last);
+      if (how == 2) planes_of_segment();
       step_ptrs(how, buf);
     };
     auto put_chunk = [&](unsigned char* p, int plane, f32x4 v, bool ok, float scale) __attribute__((always_inline)) {
@@ -1367,16 +1386,33 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
         *reinterpret_cast<u32x2*>(p + 2 * plane) = lo;
       }
     };
+    // a chunk of a plane tile: 16 bytes = 8 consecutive k of ONE plane (chunks 0-3 of a row's k-block: hi, 4-7: lo)
+    auto put_pre = [&](unsigned char* row, int plane, int q, f32x4 v) __attribute__((always_inline)) {
+      *reinterpret_cast<f32x4*>(row + (q & 3) * 16 + (q >> 2) * plane) = v;
+    };
     auto put_planes_impl = [&](unsigned char* st, const f32x4 (&xa)[NA], const f32x4 (&xb)[NB], unsigned ma, unsigned mb, const bool all) __attribute__((always_inline)) {
+      bool a_pre = false, b_pre = false;   // uniform: scalar branches around VALU + LDS work only
+      if constexpr (F16 && A_KC) a_pre = (ma >> 31) != 0;
+      if constexpr (F16 && B_KC) b_pre = (mb >> 31) != 0;
+      if (a_pre) {
 #pragma unroll
-      for (int u = 0; u < NA; ++u) {
-        const int idx = tid + NPT * u;
-        put_chunk(st + (A_KC ? kc_row(tid, u, NA) * PL_ROW_B + (idx & 7) * 8 : (idx / QA) * MCA + (idx % QA) * 8), PLA, xa[u], all || ((ma >> u) & 1u), f16_sa);
+        for (int u = 0; u < NA; ++u) put_pre(st + kc_row(tid, u, NA) * PL_ROW_B, PLA, (tid + NPT * u) & 7, xa[u]);
+      } else {
+#pragma unroll
+        for (int u = 0; u < NA; ++u) {
+          const int idx = tid + NPT * u;
+          put_chunk(st + (A_KC ? kc_row(tid, u, NA) * PL_ROW_B + (idx & 7) * 8 : (idx / QA) * MCA + (idx % QA) * 8), PLA, xa[u], all || ((ma >> u) & 1u), f16_sa);
+        }
       }
+      if (b_pre) {
 #pragma unroll
-      for (int u = 0; u < NB; ++u) {
-        const int idx = tid + NPT * u;
-        put_chunk(st + NPL * PLA + (B_KC ? kc_row(tid, u, NB) * PL_ROW_B + (idx & 7) * 8 : (idx / QB) * MCB + (idx % QB) * 8), PLB, xb[u], all || ((mb >> u) & 1u), f16_sb);
+        for (int u = 0; u < NB; ++u) put_pre(st + NPL * PLA + kc_row(tid, u, NB) * PL_ROW_B, PLB, (tid + NPT * u) & 7, xb[u]);
+      } else {
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+          const int idx = tid + NPT * u;
+          put_chunk(st + NPL * PLA + (B_KC ? kc_row(tid, u, NB) * PL_ROW_B + (idx & 7) * 8 : (idx / QB) * MCB + (idx % QB) * 8), PLB, xb[u], all || ((mb >> u) & 1u), f16_sb);
+        }
       }
     };
     // a k-step inside its segment (uniform test: a scalar branch around VALU + LDS work only) needs no per-chunk select
@@ -1389,6 +1425,7 @@ __device__ __forceinline__ void x3w_body(const KArgs& a, const int blk_x, const 
     if (s_lo < s_hi) {
       cur.init(a, s_lo);
       if (a.kcount) { cur.K = Kc; cur.left = steps_total - 1 - cur.k0 / BK; }
+      planes_of_segment();
       base_ptrs();
       prefetch_rows(1);   // rows of step s_lo + 1
       // the first PF tiles are requested back to back (one exposed memory latency, not two); afterwards set (r+1) % PF
@@ -1799,6 +1836,12 @@ int build_args(const ssc_gemm_desc* d, KArgs& k) {
     k.steps_total += k.seg[i].nsteps;
     k.seg[i].avec = (ssc_aligned16(s.A) && !(s.lda & 3) && !((d->a_kc ? s.K : d->M) & 3)) ? 1 : 0;
     k.seg[i].bvec = (ssc_aligned16(s.B) && !(s.ldb & 3) && !((d->b_kc ? s.K : d->N) & 3)) ? 1 : 0;
+    // pre-split planes (optional; read by the 2xFP16 form only): k-contiguous operands, whole 32-k blocks, 16-byte rows
+    const int kp = ssc_cdiv(s.K, BK) * BK;
+    if (s.A16 && (!d->a_kc || s.lda16 < kp || (s.lda16 & 3) || !ssc_aligned16(s.A16))) return SSC_EINVAL;
+    if (s.B16 && (!d->b_kc || s.ldb16 < kp || (s.ldb16 & 3) || !ssc_aligned16(s.B16))) return SSC_EINVAL;
+    k.seg[i].A16 = static_cast<const float*>(s.A16); k.seg[i].lda16 = s.lda16;
+    k.seg[i].B16 = static_cast<const float*>(s.B16); k.seg[i].ldb16 = s.ldb16;
   }
   return SSC_OK;
 }
@@ -2008,6 +2051,9 @@ inline bool x3w_span_ok(const ssc_gemm_desc* d) {
     const size_t sa = d->a_kc ? (size_t)(d->M - 1) * d->seg[i].lda + K : (K - 1) * d->seg[i].lda + d->M;
     const size_t sb = d->b_kc ? (size_t)(d->N - 1) * d->seg[i].ldb + K : (K - 1) * d->seg[i].ldb + d->N;
     if (sa >= lim || sb >= lim) return false;
+    const size_t kp = (K + BK - 1) / BK * BK;
+    if (d->seg[i].A16 && (size_t)(d->M - 1) * d->seg[i].lda16 + kp >= lim) return false;
+    if (d->seg[i].B16 && (size_t)(d->N - 1) * d->seg[i].ldb16 + kp >= lim) return false;
   }
   return true;
 }
@@ -2409,6 +2455,47 @@ int ssc_gemm_dw_group(const ssc_gemm_desc* const* d, int n, hipStream_t st) {
   return SSC_OK;
 }
 
+// ssc_split_f16: an operand's two fp16 pieces in the plane layout (KSeg::A16), with exactly the arithmetic of the 2xFP16 producers
+// (x * scale, split4_f16): one thread per 4 consecutive k of a row
+namespace {
+__global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict__ x, int rows, int K, int ldx, const float* __restrict__ scale,
+                                                        unsigned* __restrict__ out, int ldo, const int* __restrict__ row_list,
+                                                        const int* __restrict__ row_count) {
+  const int kq = blockIdx.x * blockDim.x + threadIdx.x;   // chunk of 4 k
+  const int kp4 = (K + BK - 1) / BK * (BK / 4);
+  if (kq >= kp4) return;
+  const float sc = scale ? *scale : 1.f;
+  const int n = row_list ? min(rows, *row_count) : rows;
+  const bool vec = !(ldx & 3) && ssc_aligned16_dev(x);
+  const int k = 4 * kq;
+  for (int i = blockIdx.y; i < n; i += gridDim.y) {
+    const int r = row_list ? row_list[i] : i;
+    const float* xr = x + (size_t)r * ldx;
+    f32x4 v;
+    if (k + 4 <= K && vec) v = *reinterpret_cast<const f32x4*>(xr + k);
+    else
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = k + j < K ? xr[k + j] : 0.f;
+    v = v * sc;
+    u32x2 hi, lo;
+    split4_f16(v, hi, lo);
+    unsigned* o = out + (size_t)r * ldo + (kq >> 3) * 32 + (kq & 7) * 2;
+    *reinterpret_cast<u32x2*>(o) = hi;
+    *reinterpret_cast<u32x2*>(o + 16) = lo;
+  }
+}
+}  // namespace
+extern "C" int ssc_split_f16(const float* x, int rows, int K, int ldx, const float* scale, void* out, int ldo, const int* row_list,
+                             const int* row_count, void* stream) {
+  const int kp = ssc_cdiv(K, BK) * BK;
+  if (!x || !out || rows <= 0 || K <= 0 || ldx < K || ldo < kp || (ldo & 3) || !ssc_aligned16(out) || (row_list != nullptr) != (row_count != nullptr))
+    return SSC_EINVAL;
+  SSC_LAUNCH(split_f16_kernel, dim3(ssc_cdiv(kp / 4, 256), rows < 65535 ? rows : 65535), dim3(256), 0, (hipStream_t)stream, x, rows, K, ldx, scale,
+             static_cast<unsigned*>(out), ldo, row_list, row_count);
+  SSC_CHECK_LAUNCH();
+  return SSC_OK;
+}
+
 extern "C" int ssc_gemm(const ssc_gemm_desc* d, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   KArgs k;
@@ -2506,7 +2593,7 @@ extern "C" int ssc_set_gemm_mode(int mode) {
 }
 
 // ---- include/ssc_debug.h -----------------------------------------------------------------------------------------
-extern int ssc_g_dec_att_table, ssc_g_dec_dedup, ssc_g_beam_reg, ssc_g_dec_ungathered, ssc_g_dec_parts;   // decode.hip
+extern int ssc_g_dec_att_table, ssc_g_dec_dedup, ssc_g_beam_reg, ssc_g_dec_ungathered, ssc_g_dec_parts, ssc_g_dec_planes;   // decode.hip
 extern int ssc_g_img_mfma;   // pointwise.hip
 namespace {
 struct DebugKey { const char* name; int* var; };
@@ -2529,6 +2616,7 @@ const DebugKey g_debug_keys[] = {
     {"beam_reg", &ssc_g_beam_reg},             // decode: beam selection with the vocabulary row in registers (1 | 0)              (SSC_BEAM_REG)
     {"img_mfma", &ssc_g_img_mfma},             // decode: the image cell's table contraction on the fp32 matrix cores (1 | 0 = VALU form)   (SSC_IMG_MFMA)
     {"dec_ungathered", &ssc_g_dec_ungathered}, // decode: states left in the previous step's row order, read through the parent lists (1 | 0)   (SSC_DEC_UNGATHERED)
+    {"dec_planes", &ssc_g_dec_planes},         // decode: the 2xFP16 products of a large call read states and weights pre-split into fp16 pieces (1 | 0)   (SSC_DEC_PLANES)
     {"dec_parts", &ssc_g_dec_parts},           // decode: the vocabulary head of a one-state search leaves per-tile records instead of logits (1 | 0)   (SSC_DEC_PARTS)
     {"dec_att_table", &ssc_g_dec_att_table},   // decode: attended-feature term of the decoder gates from a per-image table (1 | 0)   (SSC_DEC_ATT_TABLE)
     {"f16_npw", &g_f16_npw},         // 2xFP16 kernel: producer waves (8 | 4 = two workgroups per CU)   (SSC_F16_NPW)

@@ -205,6 +205,10 @@ class DecodeEngine:
             assert tuple(eps.shape) == (max_steps - 1, G, d.Z), (eps.shape, (max_steps - 1, G, d.Z))
         sd.sentiment, sd.eps0, sd.eps = _lib.ptr(sent), _lib.ptr(eps0), _lib.ptr(eps) if max_steps > 1 else None
         sd.obj_atts = _lib.ptr(ctx.obj)
+        if mach is not None:   # one machine index per BATCH ENTRY (image, sample); the kernels index the machines with it unchecked
+            assert fsm is not None and mach.numel() == B, (mach.shape, B)
+            lo, hi = int(mach.min()), int(mach.max())
+            assert 0 <= lo and hi < fsm.size(0), (lo, hi, fsm.size(0))
         mach = mach.to(dev, torch.int32).contiguous() if mach is not None else None
         sd.fsm, sd.mach = _lib.ptr(fsm), _lib.ptr(mach)
         if compiled is not None:
@@ -321,6 +325,7 @@ def cbs_search(start_predictions: torch.Tensor, start_state, step: Callable, fsm
     if mach is not None:
         mach = mach.to(dev, torch.int32).contiguous()
         assert mach.numel() == B
+        assert 0 <= int(mach.min()) and int(mach.max()) < M, "machine index out of range"   # (the kernels index the machines with it unchecked)
     assert not skip_dead or compiled is not None
     SB = S * beam_size
     preds = torch.empty(max_steps, B, SB, dtype=torch.int64, device=dev)

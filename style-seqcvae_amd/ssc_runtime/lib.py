@@ -23,7 +23,8 @@ class SscError(RuntimeError):
 
 
 class GemmSeg(C.Structure):
-    _fields_ = [("A", vp), ("B", vp), ("lda", C.c_int), ("ldb", C.c_int), ("K", C.c_int)]
+    _fields_ = [("A", vp), ("B", vp), ("lda", C.c_int), ("ldb", C.c_int), ("K", C.c_int),
+                ("A16", vp), ("B16", vp), ("lda16", C.c_int), ("ldb16", C.c_int)]
 
 
 class GemmDesc(C.Structure):
@@ -140,6 +141,7 @@ SYMBOLS = {
     "ssc_gemm": (_i, [C.POINTER(GemmDesc), vp]),
     "ssc_gemm_auto_splits": (_i, [_i, _i, _i]),
     "ssc_pow2_scale": (_i, [vp, _sz, _i, _sz, _i, vp, _i, vp, vp]),
+    "ssc_split_f16": (_i, [vp, _i, _i, _i, vp, vp, _i, vp, vp, vp]),
     "ssc_set_gemm_mode": (_i, [_i]),
     "ssc_feat_prep": (_i, [vp, _i, _i, _i, vp, vp, vp]),
     "ssc_prep_tokens": (_i, [vp, _i, _i, _i, _i, vp, vp, vp, vp]),

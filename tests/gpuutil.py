@@ -26,8 +26,21 @@ def dev(t):
     return t.cuda().contiguous()
 
 
-def gemm(segs, M, N, a_kc, b_kc, Cout, bias=None, accumulate=0, splits=0, ws=None, compact=None, check=True):
-    """segs: list of (A, lda, B, ldb, K) with torch tensors (views allowed; pointer = data_ptr())."""
+def split_f16(x, K=None, scale=None, rows=None):
+    """ssc_split_f16 of x[:, :K] -> int32 tensor (rows, roundup(K, 32)) in the plane layout of ssc_gemm_seg.A16 / B16."""
+    lib = L.load()
+    K = x.size(1) if K is None else K
+    kp = (K + 31) // 32 * 32
+    out = torch.full((x.size(0), kp), 0x7E007E00, dtype=torch.int32, device=x.device)   # (fp16 NaNs: an unwritten word shows)
+    rl, rc = (None, None) if rows is None else (L.ptr(rows[0]), L.ptr(rows[1]))
+    lib.ssc_split_f16(L.ptr(x), x.size(0), K, x.stride(0), L.ptr(scale) if scale is not None else None, L.ptr(out), kp, rl, rc,
+                      L.stream_ptr())
+    return out
+
+
+def gemm(segs, M, N, a_kc, b_kc, Cout, bias=None, accumulate=0, splits=0, ws=None, compact=None, check=True, planes=None):
+    """segs: list of (A, lda, B, ldb, K) with torch tensors (views allowed; pointer = data_ptr()); planes: per segment
+    (A16 or None, B16 or None) int32 tensors from split_f16."""
     lib = L.load()
     d = L.GemmDesc()
     d.nseg = len(segs)
@@ -35,6 +48,12 @@ def gemm(segs, M, N, a_kc, b_kc, Cout, bias=None, accumulate=0, splits=0, ws=Non
         d.seg[i].A = A.data_ptr()
         d.seg[i].B = B.data_ptr()
         d.seg[i].lda, d.seg[i].ldb, d.seg[i].K = lda, ldb, K
+        if planes is not None:
+            a16, b16 = planes[i]
+            if a16 is not None:
+                d.seg[i].A16, d.seg[i].lda16 = a16.data_ptr(), a16.stride(0)
+            if b16 is not None:
+                d.seg[i].B16, d.seg[i].ldb16 = b16.data_ptr(), b16.stride(0)
     d.M, d.N, d.a_kc, d.b_kc = M, N, int(a_kc), int(b_kc)
     d.C = Cout.data_ptr()
     d.ldc = Cout.stride(0)

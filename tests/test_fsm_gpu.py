@@ -446,6 +446,51 @@ def test_search_from_records_equals_search_from_logits(end_bias, early):
         assert p1.shape[-1] < steps
 
 
+@pytest.mark.parametrize("H,V,machines", [(160, 1200, False), (100, 1100, False), (160, 600, True)])
+def test_search_on_presplit_operands_is_bit_identical(H, V, machines):
+    """Large calls under the 2xFP16 numerics hand their products states and weights ALREADY split into fp16 pieces (ssc_split_f16:
+    once per step / per image context instead of once per tile; ssc_gemm_seg.A16 / B16): beams, back-pointers and log-probs are the
+    bits of the search whose products split their operands themselves (ssc_debug_set("dec_planes", 0)).  Hidden sizes that are /
+    are not whole 32-k blocks (zero padding of the pieces), records and logits heads, one-state and compiled machines."""
+    from ssc_runtime import lib as L
+    from ssc_runtime.decode import CompiledFsm
+    lib = L.load()
+    R, Z, steps, nimg, ns, beam = 6, 8, 7, 8, 16, 5
+    m = _small_captioner(V, 1.0, H=H)
+    dec = m._dec
+    g = torch.Generator().manual_seed(H)
+    feats = torch.randn(nimg, R, 64, generator=g).cuda()
+    senti = torch.randint(-1, 2, (nimg,), generator=g).float().cuda()
+    B = nimg * ns
+    sent_b = senti.view(nimg, 1).expand(nimg, ns).reshape(B)
+    S = 1
+    compiled = mach = None
+    if machines:
+        S = 3
+        fsm = torch.zeros(2, S, S, V, dtype=torch.uint8)
+        for k in range(2):
+            for i in range(S):
+                fsm[k, i, i] = 1
+            words = torch.randperm(V - 4, generator=g)[:6] + 4
+            fsm[k, 0, 0, words[:3]] = 0; fsm[k, 0, 1, words[:3]] = 1
+            fsm[k, 1, 1, words[3:]] = 0; fsm[k, 1, 2, words[3:]] = 1
+        compiled = CompiledFsm(fsm.cuda())
+        mach = (torch.arange(nimg) % 2).view(nimg, 1).expand(nimg, ns).reshape(B).to(torch.int32).cuda()   # per batch entry
+    eps0 = torch.randn(B, Z, generator=g).cuda()
+    eps = torch.randn(steps - 1, B * S * beam, Z, generator=g).cuda()
+    outs = []
+    for on in (1, 0):
+        lib.ssc_debug_set(b"dec_planes", on)
+        try:
+            ctx = dec.prepare(feats)
+            outs.append(dec.search(ctx, sent_b, ns, beam, 2, steps, 1, eps0, eps, fsm=None if compiled is None else compiled.fsm,
+                                   compiled=compiled, mach=mach, early_stop=False))
+        finally:
+            lib.ssc_debug_set(b"dec_planes", 1)
+    (p1, l1), (p0, l0) = outs
+    assert torch.equal(p1, p0) and torch.equal(l1, l0)
+
+
 def test_ended_beams_are_not_stepped_in_a_one_state_search():
     """skip_dead with the trivial machine: a beam that has emitted END re-emits END whatever its logits are (cbs.py:177-181), so
     its row is left out of every product of the later steps - same captions as the search that steps every row (most beams end

@@ -342,3 +342,73 @@ def test_nt_split_fp16_form_is_fp32_accurate(M, N, Ks, scale_a, scale_b):
     finally:
         lib.ssc_debug_set(b"gemm_f16", 0)
         lib.ssc_debug_set(b"large_form", 1)
+
+
+@pytest.mark.parametrize("M,N,Ks", [(1280, 1024, [1000]), (700, 1300, [1000, 152, 96]), (300, 520, [40])])
+def test_presplit_plane_operands_are_bit_identical(M, N, Ks):
+    """ssc_gemm_seg.A16 / B16: an operand handed to the 2xFP16 form already split (ssc_split_f16, the producers' own arithmetic) gives
+    the bits of the in-kernel split - for A only, B only, both, segment by segment mixed, K that ends inside a 32-k block (the
+    planes' padding is zero), with row lists on A, and for the records epilogue; every other form of the product ignores the planes."""
+    from gpuutil import split_f16
+    lib = L.load()
+    g = torch.Generator().manual_seed(7 * M + N)
+    dA = [dev(torch.randn(M, K, generator=g) * 0.5) for K in Ks]
+    dB = [dev(torch.randn(N, K, generator=g) * 0.03) for K in Ks]
+    sc = torch.tensor([64.0, 2.0 ** 15], device="cuda")
+    segs = [(a, a.stride(0), b, b.stride(0), K) for a, b, K in zip(dA, dB, Ks)]
+    pA = [split_f16(a, scale=sc[0:1]) for a in dA]
+    pB = [split_f16(b, scale=sc[1:2]) for b in dB]
+    # the planes themselves: hi = x truncated to fp16, lo = (x - hi) truncated, zero padding
+    a0 = (dA[0] * 64.0).cpu()
+    hi = pA[0].cpu().view(torch.float16).view(M, -1, 2, 32)[:, :, 0, :].reshape(M, -1).float()
+    lo = pA[0].cpu().view(torch.float16).view(M, -1, 2, 32)[:, :, 1, :].reshape(M, -1).float()
+    K0 = Ks[0]
+    assert torch.all(hi[:, K0:] == 0) and torch.all(lo[:, K0:] == 0)
+    assert torch.all(hi[:, :K0].abs() <= a0.abs()) and torch.all((a0 - hi[:, :K0] - lo[:, :K0]).abs() <= a0.abs() * 2.0 ** -20 + 2.0 ** -24)
+    scales = {"a_scale": sc[0:1], "b_scale": sc[1:2]}
+
+    def run(planes, f16=1, extra=None, out=None):
+        lib.ssc_debug_set(b"gemm_f16", f16)
+        lib.ssc_debug_set(b"large_form", 2)
+        try:
+            out = torch.full((M, N), float("nan"), device="cuda") if out is None else out
+            gemm(segs, M, N, 1, 1, out, splits=1, compact=dict(scales, **(extra or {})), planes=planes)
+            torch.cuda.synchronize()
+            return out
+        finally:
+            lib.ssc_debug_set(b"gemm_f16", 0)
+            lib.ssc_debug_set(b"large_form", 1)
+
+    want = run(None)
+    none = [(None, None)] * len(Ks)
+    for name, planes in (("A", [(a, None) for a in pA]), ("B", [(None, b) for b in pB]), ("both", list(zip(pA, pB))),
+                         ("mixed", [(pA[i] if i % 2 == 0 else None, pB[i] if i % 2 == 1 else None) for i in range(len(Ks))])):
+        assert torch.equal(run(planes), want), name
+    # the 3xBF16 form of the same product reads the fp32 operands, whatever the planes hold
+    assert torch.equal(run(list(zip(pA, pB)), f16=0), run(none, f16=0))
+    # row lists on A (planes are addressed by the listed rows too)
+    n = M // 3
+    rows = torch.randperm(M, generator=g)[:n].sort().values.to(torch.int32).cuda()
+    cnt = torch.tensor([n], dtype=torch.int32, device="cuda")
+    ex = {"m_count": cnt, "a_rows": rows, "c_rows": rows}
+    o1 = run(none, extra=ex, out=torch.zeros(M, N, device="cuda"))
+    o2 = run(list(zip(pA, pB)), extra=ex, out=torch.zeros(M, N, device="cuda"))
+    assert torch.equal(o1, o2) and torch.equal(o1[rows.long()], want[rows.long()])
+    # planes of the listed rows only
+    pl = [split_f16(a, scale=sc[0:1], rows=(rows, cnt)) for a in dA]
+    assert all(torch.equal(x[rows.long()], y[rows.long()]) for x, y in zip(pl, pA))
+    # records epilogue
+    ntn = (N + 127) // 128
+    r1 = torch.zeros(M, ntn, 6, device="cuda"); r2 = torch.zeros(M, ntn, 6, device="cuda")
+    run(none, extra={"topk_part": r1}, out=torch.empty(1, N, device="cuda"))
+    run(list(zip(pA, pB)), extra={"topk_part": r2}, out=torch.empty(1, N, device="cuda"))
+    assert torch.equal(r1, r2)
+    # malformed planes are refused
+    d_bad = split_f16(dA[0], scale=sc[0:1])[:, :32 * ((Ks[0] + 31) // 32) - 32] if Ks[0] > 32 else None
+    if d_bad is not None:
+        bad = [(d_bad.contiguous(), None)] + [(None, None)] * (len(Ks) - 1)
+        lib.ssc_debug_set(b"gemm_f16", 1)
+        try:
+            assert gemm(segs, M, N, 1, 1, torch.empty(M, N, device="cuda"), splits=1, planes=bad, check=False) == -1   # SSC_EINVAL
+        finally:
+            lib.ssc_debug_set(b"gemm_f16", 0)
