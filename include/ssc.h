@@ -166,6 +166,10 @@ typedef struct {
                                 * previous step's row order, ssc_decode_step_desc.ungathered) */
   const int* rows; const int* row_count;   /* optional (ssc_lstm_fwd only): a device-side list of the rows to compute, *row_count of them
                                 * (decode: the rows that hold a finite, unfinished beam); the other rows' outputs are left as they are */
+  /* optional (ssc_lstm_fwd, ssc_lstm_fwd_img): h_out * planes_scale[0] also leaves the cell split into its two fp16 pieces, in the
+   * plane layout of ssc_split_f16 (ld_hplanes 4-byte words per row, >= H rounded up to 32; the padding columns are zeroed) - the
+   * operand of the next 2xFP16 product (ssc_gemm_seg.A16) without a pass of its own.  planes_scale NULL = 1. */
+  void* h_planes; int ld_hplanes; const float* planes_scale;
 } ssc_lstm_fwd_desc;
 int ssc_lstm_fwd(const ssc_lstm_fwd_desc* d, void* stream);
 /* The same with one more addend formed inside the kernel: pre[b,n] += z[b,:Z] . wz[n,:Z]  (z (B,Z) ld ldz; wz (4H,Z) ld ldwz;
@@ -501,7 +505,16 @@ typedef struct {
   float* topk_part;          /* optional (G, ceil(V / 128), 6): the vocabulary head leaves per-tile records (ssc_gemm_desc.topk_part) here INSTEAD
                               * of writing log_probs (which may then be NULL); untied head, 16-byte aligned H, not under the exact-fp32
                               * numerics (SSC_EINVAL otherwise).  For ssc_beam_step_parts */
+  /* 2xFP16 numerics, large calls (cfg->gemm_mode 3, parent sharing + attended-feature table in use): the step's products read the
+   * recurrent states already split into their fp16 pieces (ssc_split_f16 layout, ssc_decode_planes_ld(cfg) words per row, G rows).
+   * h1_planes_out / hd_planes_out (optional): where the cells leave the pieces of h1_out / hd_out (default: the step workspace);
+   * h1_planes / hd_planes (optional): the pieces of h1 / hd, i.e. what the PREVIOUS step left in its *_planes_out - without them the
+   * step splits h1 / hd itself.  Ignored by every other form of the step. */
+  const void* h1_planes; const void* hd_planes;
+  void* h1_planes_out; void* hd_planes_out;
 } ssc_decode_step_desc;
+/* words (4 bytes) per row of the state pieces above: H rounded up to 32 */
+int ssc_decode_planes_ld(const ssc_model_cfg* cfg);
 /* 1 if a step of G rows in groups of `group` (0: group size not known yet - any divisor of G above 1 will do) over an image context of
  * nimg images with this att_table mode can take un-gathered states */
 int ssc_decode_ungathered_ok(const ssc_model_cfg* cfg, int nimg, int G, int group, int att_table);

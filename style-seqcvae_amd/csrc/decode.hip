@@ -568,6 +568,8 @@ extern "C" int ssc_decode_prepare_from(const ssc_model_cfg* cfg, const ssc_param
   return SSC_OK;
 }
 
+extern "C" int ssc_decode_planes_ld(const ssc_model_cfg* cfg) { return cfg ? (cfg->H + 31) / 32 * 32 : 0; }
+
 extern "C" size_t ssc_decode_step_workspace_bytes(const ssc_model_cfg* cfg, int G, int R) {
   if (!cfg || G <= 0 || R <= 0) return 0;
   return step_layout(cfg, G, R).total * sizeof(float);
@@ -652,12 +654,17 @@ extern "C" int ssc_decode_step(const ssc_model_cfg* cfg, const ssc_params* p, co
   // the weights' pieces come from the image context.  Every other form of a product ignores the pieces.
   const bool planes = il.planes && dedup && att_table && ssc_g_dec_planes && l.p_hd != l.p_h1;
   const int Hk = l.Hk;
-  float* PH1 = planes ? W + l.p_h1 : nullptr; float* PHD = planes ? W + l.p_hd : nullptr;
-  float* PH1O = planes ? W + l.p_h1o : nullptr; float* PHDO = planes ? W + l.p_hdo : nullptr;
+  const float* PH1 = nullptr; const float* PHD = nullptr; float* PH1O = nullptr; float* PHDO = nullptr;
   auto PW = [&](size_t off) -> const float* { return planes ? I + off : nullptr; };
   if (planes) {
-    SSC_TRY(ssc_split_f16(d->h1, G, H, H, sc.at(SC_ACT), PH1, Hk, urows, ucount, st));
-    SSC_TRY(ssc_split_f16(d->hd, G, H, H, sc.at(SC_ACT), PHD, Hk, urows, ucount, st));
+    // the previous states' pieces: the caller's (what the previous step's cells left), else split here - the distinct parents' rows only
+    PH1 = static_cast<const float*>(d->h1_planes); PHD = static_cast<const float*>(d->hd_planes);
+    if (!PH1) { SSC_TRY(ssc_split_f16(d->h1, G, H, H, sc.at(SC_ACT), W + l.p_h1, Hk, urows, ucount, st)); PH1 = W + l.p_h1; }
+    if (!PHD) { SSC_TRY(ssc_split_f16(d->hd, G, H, H, sc.at(SC_ACT), W + l.p_hd, Hk, urows, ucount, st)); PHD = W + l.p_hd; }
+    // the new states' pieces are written by the cells themselves (ssc_lstm_fwd_desc.h_planes)
+    PH1O = d->h1_planes_out ? static_cast<float*>(d->h1_planes_out) : W + l.p_h1o;
+    PHDO = d->hd_planes_out ? static_cast<float*>(d->hd_planes_out) : W + l.p_hdo;
+    if ((reinterpret_cast<uintptr_t>(PH1) | reinterpret_cast<uintptr_t>(PHD) | reinterpret_cast<uintptr_t>(PH1O) | reinterpret_cast<uintptr_t>(PHDO)) & 15) return SSC_EALIGN;
   }
 
   // embedding + attention LSTM (updown_captioner.py:430, updown_cell.py:143-148)
@@ -684,8 +691,8 @@ extern "C" int ssc_decode_step(const ssc_model_cfg* cfg, const ssc_params* p, co
     f.c_prev = d->c1; f.ld_cprev = H; f.c_prev_rows = prow;
     f.c_out = d->c1_out; f.ld_cout = H; f.h_out = d->h1_out; f.ld_hout = H;
     if (live) { f.rows = lrows; f.row_count = lcount; }   // (rows nobody reads are not computed: their h1 / c1 stay stale)
+    if (planes) { f.h_planes = PH1O; f.ld_hplanes = Hk; f.planes_scale = sc.at(SC_ACT); }
     SSC_TRY(ssc_lstm_fwd(&f, st));
-    if (planes) SSC_TRY(ssc_split_f16(d->h1_out, G, H, H, sc.at(SC_ACT), PH1O, Hk, lrows, lcount, st));
   }
   // attention over the image's regions (attention.py:69-95, updown_cell.py:151-158)
   if (live) SSC_TRY(gemm_live({{d->h1_out, H, p->wq, p->ld_wq, H, PH1O, PW(il.pw_q), Hk}}, A, W + l.q, l.Ap, nullptr, sc.at(SC_ACT), sc.at(SC_Q)));
@@ -747,9 +754,9 @@ extern "C" int ssc_decode_step(const ssc_model_cfg* cfg, const ssc_params* p, co
     }
     f.c_prev = d->cd; f.ld_cprev = H; f.c_prev_rows = prow;
     f.c_out = d->cd_out; f.ld_cout = H; f.h_out = d->hd_out; f.ld_hout = H;
+    if (planes) { f.h_planes = PHDO; f.ld_hplanes = Hk; f.planes_scale = sc.at(SC_ACT); }
     if (att_table) SSC_TRY(ssc_lstm_fwd_img(&f, d->alpha, R, I + il.pd, R, rpi, st));
     else SSC_TRY(ssc_lstm_fwd(&f, st));
-    if (planes && (d->topk_part || d->log_probs)) SSC_TRY(ssc_split_f16(d->hd_out, G, H, H, sc.at(SC_ACT), PHDO, Hk, lrows, lcount, st));
   }
   // vocabulary log-probabilities (updown_captioner.py:444-450); skipped when only the cell output is wanted
   if (d->topk_part) {   // records per (row, 128-column tile) instead of the (G, V) logits (ssc_beam_step_parts selects from them)

@@ -606,20 +606,8 @@ __device__ __forceinline__ void split4(const f32x4& v, u32x2& hi, u32x2& mid, u3
   }
 }
 
-// 2xFP16 (ssc_model_cfg.gemm_mode 3): 4 consecutive fp32 into TWO fp16 planes, hi = x truncated to fp16, lo = (x - hi) truncated
-// to fp16 (x - hi is exact in fp32) - 21-22 significant bits of x, two v_cvt_pkrtz + two conversions back + two subtractions per
-// pair instead of the 3xBF16 split's masks, subtractions and byte permutes.  |x| must stay below 65504 (fp16 range).
-typedef __fp16 h16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void split4_f16(const f32x4& v, u32x2& hi, u32x2& lo) {
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const h16x2 h = __builtin_amdgcn_cvt_pkrtz(v[2 * j], v[2 * j + 1]);
-    const float r0 = v[2 * j] - (float)h[0], r1 = v[2 * j + 1] - (float)h[1];
-    const h16x2 l = __builtin_amdgcn_cvt_pkrtz(r0, r1);
-    hi[j] = __builtin_bit_cast(unsigned, h);
-    lo[j] = __builtin_bit_cast(unsigned, l);
-  }
-}
+// 2xFP16 (ssc_model_cfg.gemm_mode 3): 4 consecutive fp32 into TWO fp16 planes - ssc_split4_f16 (ssc_common.h)
+__device__ __forceinline__ void split4_f16(const f32x4& v, u32x2& hi, u32x2& lo) { ssc_split4_f16(v, hi, lo); }
 
 // WN = 32x32 MFMA tiles per wave along N: block tile 64 x (64*WN).  WN = 2 halves the A re-reads per streamed weight
 // byte (the CU-side load path, ~24 GB/s per CU, is what the skinny products saturate) at one workgroup per CU.

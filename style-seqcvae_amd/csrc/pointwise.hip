@@ -89,10 +89,16 @@ __global__ void embed_scatter_kernel(float* __restrict__ dt, int ldt, const int6
 __global__ void lstm_fwd_kernel(const ssc_lstm_fwd_desc d) {
   int j = blockIdx.x * blockDim.x + threadIdx.x;
   int b = blockIdx.y;
-  if (j >= d.H) return;
+  const bool pad = j >= d.H;   // (only with h_planes: the planes' padding columns H .. roundup(H, 32) are zeroed here)
+  if (pad && (!d.h_planes || j >= (d.H + 31) / 32 * 32)) return;
   if (d.rows) {   // only the listed rows (decode: the rows that are read at all)
     if (b >= *d.row_count) return;
     b = d.rows[b];
+  }
+  if (pad) {
+    unsigned short* hp = reinterpret_cast<unsigned short*>(d.h_planes) + ((size_t)b * d.ld_hplanes + (j >> 5) * 32) * 2 + (j & 31);
+    hp[0] = 0; hp[32] = 0;
+    return;
   }
   const int H = d.H, H4 = 4 * d.H;
   // The kernel moves ~20 MB: it is bound by memory latency, not bandwidth.  Every operand that does not depend on the
@@ -159,6 +165,12 @@ __global__ void lstm_fwd_kernel(const ssc_lstm_fwd_desc d) {
   }
   d.c_out[(size_t)b * d.ld_cout + j] = c;
   d.h_out[(size_t)b * d.ld_hout + j] = h;
+  if (d.h_planes) {   // h also as the two fp16 pieces of h * scale: halfs j of the row's k-block (hi: 32 halfs, then lo: 32 halfs)
+    unsigned short hi, lo;
+    ssc_split1_f16(h * (d.planes_scale ? *d.planes_scale : 1.f), hi, lo);
+    unsigned short* hp = reinterpret_cast<unsigned short*>(d.h_planes) + ((size_t)b * d.ld_hplanes + (j >> 5) * 32) * 2 + (j & 31);
+    hp[0] = hi; hp[32] = lo;
+  }
 }
 // lstm_fwd_kernel plus one more addend of the gate pre-activations computed IN the kernel: pre[b,n] += z[b,:] . wz[n,:]
 // (K = Z: the latent block of the decoder LSTM's input, updown_cell.py:211-229).  z only exists after the latent head of the
@@ -545,6 +557,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
       }
       *reinterpret_cast<ssc_f32x4v*>(d.c_out + (size_t)b * d.ld_cout + u) = c;
       *reinterpret_cast<ssc_f32x4v*>(d.h_out + (size_t)b * d.ld_hout + u) = h;
+      if (d.h_planes) {   // (uniform) h also as its two fp16 pieces (ssc_lstm_fwd_desc.h_planes)
+        ssc_u32x2 hi, lo;
+        ssc_split4_f16(h * (d.planes_scale ? *d.planes_scale : 1.f), hi, lo);
+        unsigned* hp = reinterpret_cast<unsigned*>(d.h_planes) + (size_t)b * d.ld_hplanes + ssc_plane_word(u);
+        *reinterpret_cast<ssc_u32x2*>(hp) = hi;
+        *reinterpret_cast<ssc_u32x2*>(hp + 16) = lo;
+      }
+    } else if (o.rok && d.h_planes && u < (H + 31) / 32 * 32) {   // the planes' padding columns (the grid then covers roundup(H, 32) units)
+      unsigned* hp = reinterpret_cast<unsigned*>(d.h_planes) + (size_t)b * d.ld_hplanes + ssc_plane_word(u);
+      *reinterpret_cast<ssc_u32x2*>(hp) = ssc_u32x2{0u, 0u};
+      *reinterpret_cast<ssc_u32x2*>(hp + 16) = ssc_u32x2{0u, 0u};
     }
     c0 += NW * 16;
     if (c0 < c_end) issue(c0, o);
@@ -1251,7 +1274,8 @@ extern "C" int ssc_lstm_fwd(const ssc_lstm_fwd_desc* d, void* stream) {
   if (d->sent && !d->wcol) return SSC_EINVAL;
   if (d->add1 && d->rows_per_add1 <= 0) return SSC_EINVAL;
   if ((d->rows != nullptr) != (d->row_count != nullptr)) return SSC_EINVAL;
-  SSC_LAUNCH(lstm_fwd_kernel, dim3(ssc_cdiv(d->H, 128), d->B), dim3(128), 0, S(stream), *d);
+  if (d->h_planes && (d->ld_hplanes < (d->H + 31) / 32 * 32 || (d->ld_hplanes & 3) || (reinterpret_cast<uintptr_t>(d->h_planes) & 15))) return SSC_EINVAL;
+  SSC_LAUNCH(lstm_fwd_kernel, dim3(ssc_cdiv(d->H, 128), d->B), dim3(128), 0, S(stream), *d);   // (128 threads per block: the grid covers roundup(H, 32))
   SSC_CHECK_LAUNCH();
   return SSC_OK;
 }
@@ -1283,8 +1307,10 @@ extern "C" int ssc_lstm_fwd_img(const ssc_lstm_fwd_desc* d, const float* alpha, 
                    al16(d->gates_out) && al16(d->add0) && al16(d->add1) && al16(d->b_ih) && al16(d->b_hh) && d->ld_cprev % 4 == 0 &&
                    d->ld_cout % 4 == 0 && d->ld_hout % 4 == 0 && d->ld_add0 % 4 == 0 && d->ld_add1 % 4 == 0 &&
                    d->slab_stride % 4 == 0 && d->slab2_stride % 4 == 0;
+  if (d->h_planes && (!(vec && ssc_g_img_mfma) || d->ld_hplanes < (d->H + 31) / 32 * 32 || (d->ld_hplanes & 3) || !al16(d->h_planes)))
+    return SSC_EINVAL;   // (the pieces are written by the matrix-core form only)
   if (vec && ssc_g_img_mfma) {
-    const int gx = ssc_cdiv(d->H, 16);
+    const int gx = ssc_cdiv(d->h_planes ? (d->H + 31) / 32 * 32 : d->H, 16);   // (+ the planes' padding columns)
     int cpw = (int)(((long)gx * nimg * chunks) / 4096);   // >= ~4096 workgroups when the rows allow it (the table tile is staged per row group)
     if (ssc_g_img_cpw > 0) cpw = ssc_g_img_cpw;
     cpw = std::min(std::max(cpw, 8), std::max(chunks, 8));   // (eight waves, a chunk each)

@@ -24,6 +24,7 @@ bool search_uses_parts(const ssc_model_cfg* cfg, const ssc_search_desc* d) {
 
 struct SearchLayout {
   size_t st[2][4];     // h1, c1, hd, cd: two generations of (G,H)
+  size_t pl[2][2];     // 2xFP16 numerics: the fp16 pieces of h1, hd - two generations of (G, Hk) words (ssc_decode_step_desc.h1_planes ...)
   size_t tokens0;      // (B) int64 start tokens
   size_t sent_rows;    // (G) float
   size_t preds;        // (max_steps, B, SB) int64
@@ -46,6 +47,9 @@ SearchLayout search_layout(const ssc_model_cfg* cfg, const ssc_search_desc* d) {
   size_t o = 0;
   for (int g = 0; g < 2; ++g)
     for (int k = 0; k < 4; ++k) { l.st[g][k] = o; o += a256(G * H * 4); }
+  const size_t prow = cfg->gemm_mode == 3 && !cfg->tied && G >= 512 ? (size_t)ssc_decode_planes_ld(cfg) : 0;
+  for (int g = 0; g < 2; ++g)
+    for (int k = 0; k < 2; ++k) { l.pl[g][k] = o; o += a256(G * prow * 4); }
   l.tokens0 = o; o += a256(B * 8);
   l.sent_rows = o; o += a256(G * 4);
   l.preds = o; o += a256((size_t)d->max_steps * G * 8);
@@ -205,6 +209,10 @@ extern "C" int ssc_decode_search(const ssc_model_cfg* cfg, const ssc_params* p, 
     sd.att_table = tmode ? (table_ready ? 1 : 2) : 0;
     table_ready = table_ready || tmode;
     sd.ungathered = ungathered ? 1 : 0;
+    if (l.pl[1][0] != l.pl[0][0]) {   // the states' fp16 pieces travel with the un-gathered states (a re-ordered state is split again by its step)
+      sd.h1_planes_out = W + l.pl[1 - cur][0]; sd.hd_planes_out = W + l.pl[1 - cur][1];
+      sd.h1_planes = ungathered ? W + l.pl[cur][0] : nullptr; sd.hd_planes = ungathered ? W + l.pl[cur][1] : nullptr;
+    }
     sd.row_lp = d->skip_dead ? lp[a] : nullptr; sd.end_index = d->end_index;
     if (use_parts) { sd.log_probs = nullptr; sd.topk_part = parts; }
     SSC_TRY(ssc_decode_step(cfg, p, &sd, W + l.stepws, l.stepws_bytes, st));

@@ -69,6 +69,32 @@ __device__ __forceinline__ float ssc_tanh_fast(float x) {
   return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
+// 2xFP16 pieces (ssc_model_cfg.gemm_mode 3): hi = x truncated to fp16, lo = (x - hi) truncated to fp16 (x - hi is exact in fp32) -
+// 21-22 significant bits of x; two v_cvt_pkrtz + two conversions back + two subtractions per pair.  |x| must stay below 65504.
+// ONE definition for the product kernels' producers, ssc_split_f16 and the cells that leave their output already split.
+typedef float ssc_f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned ssc_u32x2 __attribute__((ext_vector_type(2)));
+typedef __fp16 ssc_h16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void ssc_split4_f16(const ssc_f32x4& v, ssc_u32x2& hi, ssc_u32x2& lo) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const ssc_h16x2 h = __builtin_amdgcn_cvt_pkrtz(v[2 * j], v[2 * j + 1]);
+    const float r0 = v[2 * j] - (float)h[0], r1 = v[2 * j + 1] - (float)h[1];
+    const ssc_h16x2 l = __builtin_amdgcn_cvt_pkrtz(r0, r1);
+    hi[j] = __builtin_bit_cast(unsigned, h);
+    lo[j] = __builtin_bit_cast(unsigned, l);
+  }
+}
+// one value: the two halfs as raw bits (the same conversions, element by element)
+__device__ __forceinline__ void ssc_split1_f16(float x, unsigned short& hi, unsigned short& lo) {
+  const ssc_h16x2 h = __builtin_amdgcn_cvt_pkrtz(x, 0.f);
+  const ssc_h16x2 l = __builtin_amdgcn_cvt_pkrtz(x - (float)h[0], 0.f);
+  hi = (unsigned short)(__builtin_bit_cast(unsigned, h) & 0xffffu);
+  lo = (unsigned short)(__builtin_bit_cast(unsigned, l) & 0xffffu);
+}
+// plane layout (ssc_gemm_seg.A16): word offset of the hi half-pair of columns k, k + 1 (k even) inside a row; the lo pair is 16 words on
+__device__ __forceinline__ int ssc_plane_word(int k) { return (k >> 5) * 32 + ((k & 31) >> 1); }
+
 // internal cross-TU entry points (not part of the C ABI)
 int ssc_gemm_slabs(const ssc_gemm_desc* d, int splits, float* slabs, hipStream_t st);  // partial slabs only
 int ssc_attn_fwd_qslabs(const float* qslabs, int nslab, size_t slab_stride, float* q_out, int ldqo, const float* pv,

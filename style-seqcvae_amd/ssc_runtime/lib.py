@@ -40,7 +40,8 @@ class LstmFwdDesc(C.Structure):
                 ("b_ih", vp), ("b_hh", vp), ("sent", vp), ("wcol", vp), ("ldwcol", C.c_int), ("c_prev", vp),
                 ("ld_cprev", C.c_int), ("gates_out", vp), ("c_out", vp), ("ld_cout", C.c_int), ("h_out", vp),
                 ("ld_hout", C.c_int), ("add0_rows", vp), ("slab_rows", vp), ("slabs2", vp), ("nslab2", C.c_int),
-                ("slab2_stride", C.c_size_t), ("slab2_rows", vp), ("c_prev_rows", vp), ("rows", vp), ("row_count", vp)]
+                ("slab2_stride", C.c_size_t), ("slab2_rows", vp), ("c_prev_rows", vp), ("rows", vp), ("row_count", vp),
+                ("h_planes", vp), ("ld_hplanes", C.c_int), ("planes_scale", vp)]
 
 
 class LstmBwdDesc(C.Structure):
@@ -109,7 +110,8 @@ class DecodeStepDesc(C.Structure):
                 ("tokens", vp), ("sentiment", vp), ("eps", vp), ("h1", vp), ("c1", vp), ("hd", vp), ("cd", vp),
                 ("h1_out", vp), ("c1_out", vp), ("hd_out", vp), ("cd_out", vp), ("alpha", vp), ("log_probs", vp),
                 ("raw_logits", C.c_int), ("emb_override", C.c_int), ("parent", vp), ("group", C.c_int), ("att_table", C.c_int),
-                ("ungathered", C.c_int), ("row_lp", vp), ("end_index", C.c_int), ("obj_atts", vp), ("prior_mean_out", vp), ("prior_mean", vp), ("prior_var", vp), ("topk_part", vp)]
+                ("ungathered", C.c_int), ("row_lp", vp), ("end_index", C.c_int), ("obj_atts", vp), ("prior_mean_out", vp), ("prior_mean", vp), ("prior_var", vp), ("topk_part", vp),
+                ("h1_planes", vp), ("hd_planes", vp), ("h1_planes_out", vp), ("hd_planes_out", vp)]
 
 
 class FsmDims(C.Structure):
@@ -142,6 +144,7 @@ SYMBOLS = {
     "ssc_gemm_auto_splits": (_i, [_i, _i, _i]),
     "ssc_pow2_scale": (_i, [vp, _sz, _i, _sz, _i, vp, _i, vp, vp]),
     "ssc_split_f16": (_i, [vp, _i, _i, _i, vp, vp, _i, vp, vp, vp]),
+    "ssc_decode_planes_ld": (_i, [vp]),
     "ssc_set_gemm_mode": (_i, [_i]),
     "ssc_feat_prep": (_i, [vp, _i, _i, _i, vp, vp, vp]),
     "ssc_prep_tokens": (_i, [vp, _i, _i, _i, _i, vp, vp, vp, vp]),

@@ -636,6 +636,13 @@ def test_image_cell_kernel_equals_float64(nimg, rpi, R, H, variant):
             + add0.double()[rows0] + add1.double().repeat_interleave(rpi, 0)
         keep += [add0, rows0, add1, gates, srow]
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # the cell's output also as its two fp16 pieces (ssc_lstm_fwd_desc.h_planes; matrix-core form only)
+    planes = scale = None
+    if H % 4 == 0 and variant != "valu":
+        Hk = (H + 31) // 32 * 32
+        planes = torch.full((G, Hk), 0x7E007E00, dtype=torch.int32, device=dev_)
+        scale = torch.tensor([64.0], device=dev_)
+        f.h_planes, f.ld_hplanes, f.planes_scale = planes.data_ptr(), Hk, scale.data_ptr()
     if variant == "valu":
         lib.ssc_debug_set(b"img_mfma", 0)
     try:
@@ -643,6 +650,9 @@ def test_image_cell_kernel_equals_float64(nimg, rpi, R, H, variant):
         torch.cuda.synchronize()
     finally:
         lib.ssc_debug_set(b"img_mfma", 1)
+    if planes is not None:   # bit for bit what ssc_split_f16 makes of h_out, zero padding included
+        from gpuutil import split_f16
+        assert torch.equal(planes, split_f16(h_out, scale=scale))
     i, fg, gg, o = pre.view(G, 4, H).unbind(1)
     c = torch.sigmoid(fg) * cp + torch.sigmoid(i) * torch.tanh(gg)
     h = torch.sigmoid(o) * torch.tanh(c)
@@ -851,3 +861,44 @@ def test_lagging_early_stop_check_gives_the_output_of_the_per_step_check(every):
     assert a.shape == b.shape and torch.equal(a, b) and torch.equal(alp, blp)
     c, clp = cbs_search(start, None, step, None, 1, steps, beam, 2, early_stop=False)
     assert c.shape[-1] == steps and torch.equal(c[..., :a.shape[-1]], a) and torch.equal(clp, alp)
+
+
+@pytest.mark.parametrize("G,H,listed", [(70, 1000, False), (333, 96, True), (40, 100, True)])
+def test_cell_leaves_its_output_as_fp16_pieces(G, H, listed):
+    """ssc_lstm_fwd with h_planes: h_out * scale also split into the two fp16 pieces of the 2xFP16 products, bit for bit what
+    ssc_split_f16 makes of h_out (hidden sizes that end inside a 32-k block: zero padding); with a row list only the listed rows."""
+    import ctypes as C
+    from gpuutil import split_f16
+    from ssc_runtime import lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(G + H)
+    H4 = 4 * H
+    slabs = (torch.randn(G, H4, generator=g) * 0.5).cuda()
+    cprev = torch.randn(G, H, generator=g).cuda()
+    c_out, h_out = torch.zeros(G, H, device="cuda"), torch.zeros(G, H, device="cuda")
+    Hk = (H + 31) // 32 * 32
+    planes = torch.full((G, Hk), 0x7E007E00, dtype=torch.int32, device="cuda")
+    scale = torch.tensor([64.0], device="cuda")
+    f = L.LstmFwdDesc()
+    f.B, f.H = G, H
+    f.slabs, f.nslab, f.slab_stride = slabs.data_ptr(), 1, G * H4
+    f.c_prev, f.ld_cprev = cprev.data_ptr(), H
+    f.c_out, f.ld_cout, f.h_out, f.ld_hout = c_out.data_ptr(), H, h_out.data_ptr(), H
+    f.h_planes, f.ld_hplanes, f.planes_scale = planes.data_ptr(), Hk, scale.data_ptr()
+    rows = None
+    if listed:
+        rows = torch.randperm(G, generator=g)[:G // 2].sort().values.to(torch.int32).cuda()
+        cnt = torch.tensor([rows.numel()], dtype=torch.int32, device="cuda")
+        f.rows, f.row_count = rows.data_ptr(), cnt.data_ptr()
+    lib.ssc_lstm_fwd(C.byref(f), L.stream_ptr())
+    torch.cuda.synchronize()
+    want = split_f16(h_out, scale=scale)
+    if rows is None:
+        assert torch.equal(planes, want)
+    else:
+        r = rows.long()
+        assert torch.equal(planes[r], want[r])
+        other = torch.ones(G, dtype=torch.bool, device="cuda"); other[r] = False
+        assert bool((planes[other] == 0x7E007E00).all())          # untouched
+    f.ld_hplanes = Hk - 4 if Hk > H else H - 4                     # too narrow: refused
+    assert lib._raw_ssc_lstm_fwd(C.byref(f), L.stream_ptr()) == -1
