@@ -168,7 +168,8 @@ typedef struct {
                                 * (decode: the rows that hold a finite, unfinished beam); the other rows' outputs are left as they are */
   /* optional (ssc_lstm_fwd, ssc_lstm_fwd_img): h_out * planes_scale[0] also leaves the cell split into its two fp16 pieces, in the
    * plane layout of ssc_split_f16 (ld_hplanes 4-byte words per row, >= H rounded up to 32; the padding columns are zeroed) - the
-   * operand of the next 2xFP16 product (ssc_gemm_seg.A16) without a pass of its own.  planes_scale NULL = 1. */
+   * operand of the next 2xFP16 product (ssc_gemm_seg.A16) without a pass of its own.  planes_scale NULL = 1.  SSC_EINVAL from
+   * ssc_lstm_fwd_z / _p and from the VALU form of ssc_lstm_fwd_img (H % 4 != 0), which do not write them. */
   void* h_planes; int ld_hplanes; const float* planes_scale;
 } ssc_lstm_fwd_desc;
 int ssc_lstm_fwd(const ssc_lstm_fwd_desc* d, void* stream);
@@ -586,7 +587,7 @@ typedef struct {
   const uint8_t* fsm;            /* dense (M,S,S,V); NULL only for the trivial machine (S = 1, every transition allowed) */
   const void* tables;            /* from ssc_fsm_compile, or NULL: dense scans */
   ssc_fsm_dims dims;             /* of `tables` / `fsm` (M, S, V used when tables is NULL) */
-  const int* mach;               /* (B) or NULL */
+  const int* mach;               /* (B) or NULL; every entry in [0, dims.M) - the kernels index the machines with it unchecked */
   int B, beam, per_node, end_index;
   const int64_t* last_pred;      /* step: (B, S*beam) previous predictions */
   const float* last_lp;          /* step: (B, S, beam) running log-probs */
@@ -601,8 +602,9 @@ typedef struct {
   /* early stop without a host round trip (cbs.py:167 asks `(last_predictions == end).all()` before every step):
    * ctl = device int32[2 + 2*max_steps], zero-filled by the caller before the first step except ctl[0] = max_steps;
    * step t (1-based index of the column it writes, first = 0) counts the beams that have not ended, and the last workgroup of
-   * the step to finish sets ctl[0] = min(ctl[0], t + 1) when there are none and writes t + 1 to *host_flag (a device-visible
-   * pointer to pinned host memory, optional).  A step that finds ctl[0] <= t (the search had already stopped) emits END at +0
+   * the step to finish sets ctl[0] = min(ctl[0], t + 1) when there are none and writes t + 1 to host_flag[0]; it also notes its
+   * own completion, host_flag[1] = t (host_flag: a device-visible pointer to TWO ints of pinned host memory, zeroed by the caller,
+   * optional - ssc_decode_search bounds the host's run-ahead with [1]).  A step that finds ctl[0] <= t (the search had already stopped) emits END at +0
    * for every beam with the identity back-pointer, so that surplus steps queued by a host that polls *host_flag late change
    * nothing: columns [0, ctl[0]) of the back-trace ARE the reference's output. */
   int* ctl; int step_index; int max_steps; int* host_flag;
@@ -641,7 +643,7 @@ typedef struct {
   const uint8_t* fsm;            /* (M, S, S, V) dense machines; NULL with S = 1: the trivial machine */
   const void* tables;            /* ssc_fsm_compile of `fsm`, or NULL: dense scans */
   ssc_fsm_dims dims;             /* of `tables` */
-  const int* mach;               /* (B) machine of every batch entry, or NULL: machine b */
+  const int* mach;               /* (B) machine of every batch entry (each in [0, M): not checked on the device), or NULL: machine b */
   int skip_dead;                 /* ssc_beam_desc.skip_dead + ssc_decode_step_desc.row_lp: rows without a finite beam (needs `tables`) and rows
                                   * whose beam has ended (any machine; with the trivial machine these are the only ones) are neither
                                   * stepped nor scored from logits */
@@ -649,8 +651,10 @@ typedef struct {
   int64_t* predictions;          /* out (B, S*beam, max_steps): columns [0, ctl[0]) are the search's; the rest holds end_index */
   float* log_probs;              /* out (B, S, beam) */
   int* ctl;                      /* device int32[2 + 2*max_steps], initialised by the call; ctl[0] = number of columns (steps) */
-  int* host_flag;                /* optional: device-visible address of a pinned host word (ssc_host_device_ptr), zeroed by the caller */
-  const int* host_flag_host;     /* the same word's host address: polled between steps to stop queueing */
+  int* host_flag;                /* optional: device-visible address of TWO pinned host ints (ssc_host_device_ptr), zeroed by the caller:
+                                  * [0] = the stop flag, [1] = the last step the device has completed */
+  const int* host_flag_host;     /* the same words' host address: read between steps - the host stops queueing once [0] is set and
+                                  * stays at most two steps ahead of [1] (plain memory reads, no event, no synchronisation call) */
 } ssc_search_desc;
 size_t ssc_decode_search_workspace_bytes(const ssc_model_cfg* cfg, const ssc_search_desc* d);
 int ssc_decode_search(const ssc_model_cfg* cfg, const ssc_params* p, const ssc_search_desc* d, void* workspace,

@@ -419,13 +419,17 @@ __global__ __launch_bounds__(64) void beam_merge_kernel(const float* __restrict_
     if (not_ended) atomicAdd(cnt, not_ended);
     __threadfence();
     const int done = atomicAdd(ticket, 1);
-    if (done == (int)gridDim.x - 1 && !stopped) {   // the last workgroup of this step
-      __threadfence();
-      const int left = atomicAdd(cnt, 0);
-      if (left == 0) {
-        atomicMin(ctl, step_index + 1);
-        if (host_flag) __hip_atomic_store(host_flag, step_index + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (done == (int)gridDim.x - 1) {   // the last workgroup of this step
+      if (!stopped) {
+        __threadfence();
+        const int left = atomicAdd(cnt, 0);
+        if (left == 0) {
+          atomicMin(ctl, step_index + 1);
+          if (host_flag) __hip_atomic_store(host_flag, step_index + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
       }
+      // progress word: the host of ssc_decode_search queues step t only once step t - 2 has got here (its run-ahead bound)
+      if (host_flag) __hip_atomic_store(host_flag + 1, step_index, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 }

@@ -1286,6 +1286,7 @@ extern "C" int ssc_lstm_fwd_z(const ssc_lstm_fwd_desc* d, const float* z, int ld
   if (d->sent && !d->wcol) return SSC_EINVAL;
   if (d->add1 && d->rows_per_add1 <= 0) return SSC_EINVAL;
   if (!z || !wz || Z <= 0 || ldz < Z || ldwz < Z) return SSC_EINVAL;
+  if (d->h_planes) return SSC_EINVAL;   // (the fp16 pieces are written by ssc_lstm_fwd / ssc_lstm_fwd_img only)
   SSC_LAUNCH(lstm_fwd_z_kernel, dim3(ssc_cdiv(d->H, 16), ssc_cdiv(d->B, 32)), dim3(512), 0, S(stream), *d, z, ldz, wz, ldwz, Z);
   SSC_CHECK_LAUNCH();
   return SSC_OK;
@@ -1366,6 +1367,7 @@ extern "C" int ssc_lstm_fwd_p(const ssc_lstm_fwd_desc* d, const float* wp, int l
   if (d->sent && !d->wcol) return SSC_EINVAL;
   if (d->add1 && d->rows_per_add1 <= 0) return SSC_EINVAL;
   if (!wp || !pout || NP <= 0 || NP > 256 || ldwp < d->H) return SSC_EINVAL;
+  if (d->h_planes) return SSC_EINVAL;   // (the fp16 pieces are written by ssc_lstm_fwd / ssc_lstm_fwd_img only)
   SSC_LAUNCH(lstm_fwd_p_kernel, dim3(ssc_cdiv(d->H, 16), ssc_cdiv(d->B, 32)), dim3(512), 0, S(stream), *d, wp, ldwp, NP, pout);
   SSC_CHECK_LAUNCH();
   return SSC_OK;

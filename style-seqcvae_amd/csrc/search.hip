@@ -7,6 +7,7 @@
 // UpDownCaptioner._decode_step in eval mode (var_updown/var_updown/models/updown_captioner.py:371-455), as the reference's
 // inference loop does per image and latent sample (var_updown/scripts/inference.py:117-189).
 #include <algorithm>
+#include <thread>
 
 #include "ssc_common.h"
 
@@ -182,24 +183,28 @@ extern "C" int ssc_decode_search(const ssc_model_cfg* cfg, const ssc_params* p, 
   bd.skip_dead = d->skip_dead && d->tables ? 1 : 0;
   // Early stop and the host's run-ahead.  The host queues a step in a fraction of the time the device needs for it, so a host that
   // only polls the flag has long queued every step by the time the device writes it (measured: captions that all end at step 2 still
-  // cost all 20 steps).  The run-ahead is therefore bounded: step t is queued only once step t - RUN_AHEAD has completed (an event
-  // per step, three in rotation) - the device always has RUN_AHEAD steps of work queued, and at most that many surplus steps run.
-  // Not under stream capture (an event wait on the host is illegal there; a captured search queues every step).
+  // cost all 20 steps).  The run-ahead is therefore bounded: step t is queued only once step t - RUN_AHEAD has completed - the last
+  // workgroup of a step's merge kernel notes the step in the second pinned word (ssc_beam_desc.host_flag[1]) and the host reads it;
+  // no event, no synchronisation call (an event per step cost 1.7 % of a search that never stops).  The device always has RUN_AHEAD
+  // steps of work queued, and at most that many surplus steps run.  Not under stream capture (a captured search queues every step).
   constexpr int RUN_AHEAD = 2;
-  hipEvent_t ev[RUN_AHEAD + 1] = {};
   bool bounded = false;
   if (d->early_stop && d->host_flag_host) {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
     bounded = cs == hipStreamCaptureStatusNone;
-    for (int i = 0; bounded && i <= RUN_AHEAD; ++i)
-      if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); bounded = false; }
   }
-  struct EvGuard { hipEvent_t* e; int n; ~EvGuard() { for (int i = 0; i < n; ++i) if (e[i]) (void)hipEventDestroy(e[i]); } } ev_guard{ev, RUN_AHEAD + 1};
+  auto wait_for_step = [&](int step) {   // until the device has completed `step` (or stopped, or the stream has drained: an error upstream)
+    const volatile int* hf = (const volatile int*)d->host_flag_host;
+    for (unsigned spin = 1; hf[1] < step && hf[0] == 0; ++spin) {
+      if ((spin & 1023u) == 0 && hipStreamQuery(st) != hipErrorNotReady) { (void)hipGetLastError(); break; }
+      std::this_thread::yield();
+    }
+  };
   for (int t = 1; t < d->max_steps; ++t) {
     // cbs.py:167: the device notes the step after which every beam had ended and turns later steps into no-ops (ssc_beam_desc.ctl);
     // the host stops QUEUEING once it sees the flag the device wrote - a plain read of pinned memory
-    if (bounded && t > RUN_AHEAD) (void)hipEventSynchronize(ev[(t - RUN_AHEAD) % (RUN_AHEAD + 1)]);
+    if (bounded && t > RUN_AHEAD) wait_for_step(t - RUN_AHEAD);
     if (d->early_stop && d->host_flag_host && *(volatile const int*)d->host_flag_host != 0) break;
     const int64_t* last = preds + (size_t)(t - 1) * plane;
     sd.tokens = last; sd.eps = d->eps + (size_t)(t - 1) * G * Z;
@@ -221,7 +226,6 @@ extern "C" int ssc_decode_search(const ssc_model_cfg* cfg, const ssc_params* p, 
     if (use_parts) SSC_TRY(ssc_beam_step_parts(&bd, parts, st));
     else SSC_TRY(ssc_beam_step_fsm(&bd, st));
     a = 1 - a;
-    if (bounded) (void)hipEventRecord(ev[t % (RUN_AHEAD + 1)], st);
     if (ung) {   // the next step reads these outputs through the back-pointers (ssc_decode_step_desc.ungathered)
       cur = 1 - cur;
       ungathered = true;

@@ -275,9 +275,9 @@ _HOST_FLAGS = []   # pinned words for the early-stop flag, recycled (allocating 
 
 
 def _host_flag():
-    """-> (pinned int32 tensor [1] holding 0, its device-visible address)."""
+    """-> (pinned int32 tensor [2] holding zeros - stop flag, last completed step: ssc_beam_desc.host_flag -, its device-visible address)."""
     lib = _lib.load()
-    t = _HOST_FLAGS.pop() if _HOST_FLAGS else torch.zeros(1, dtype=torch.int32).pin_memory()
+    t = _HOST_FLAGS.pop() if _HOST_FLAGS else torch.zeros(2, dtype=torch.int32).pin_memory()
     t.zero_()
     dp = C.c_void_p()
     if lib._raw_ssc_host_device_ptr(C.c_void_p(t.data_ptr()), C.byref(dp)) != 0:
