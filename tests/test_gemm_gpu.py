@@ -412,3 +412,22 @@ def test_presplit_plane_operands_are_bit_identical(M, N, Ks):
             assert gemm(segs, M, N, 1, 1, torch.empty(M, N, device="cuda"), splits=1, planes=bad, check=False) == -1   # SSC_EINVAL
         finally:
             lib.ssc_debug_set(b"gemm_f16", 0)
+
+
+@pytest.mark.parametrize("rows,K", [(70, 37), (5, 1001), (33, 31)])
+def test_split_f16_of_unaligned_operands(rows, K):
+    """ssc_split_f16 on an operand without 16-byte rows (odd K = ld): the scalar load path gives the pieces of the aligned path, and
+    the columns K .. roundup(K, 32) are zero."""
+    from gpuutil import split_f16
+    g = torch.Generator().manual_seed(K)
+    x = (torch.randn(rows, K, generator=g) * 0.7).cuda()
+    sc = torch.tensor([32.0], device="cuda")
+    got = split_f16(x, scale=sc)                       # ld = K: rows are not 16-byte aligned
+    Ka = (K + 3) // 4 * 4
+    xa = torch.zeros(rows, Ka, device="cuda"); xa[:, :K] = x
+    want = split_f16(xa, K=K, scale=sc)                # aligned rows, same K
+    assert torch.equal(got, want)
+    halfs = got.cpu().view(torch.float16).view(rows, -1, 2, 32)
+    hi, lo = halfs[:, :, 0, :].reshape(rows, -1).float(), halfs[:, :, 1, :].reshape(rows, -1).float()
+    assert torch.all(hi[:, K:] == 0) and torch.all(lo[:, K:] == 0)
+    assert float((hi[:, :K] + lo[:, :K] - x.cpu() * 32.0).abs().max()) < 2.0 ** -9
