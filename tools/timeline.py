@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Timeline of one train step from a rocprofv3 kernel trace (kernel_trace.csv): for the LAST complete step found, every
 launch with its start offset, duration and the gap to its predecessor; then totals per kernel of busy time and of the gaps
-that precede it.  usage: python tools/timeline.py <..._kernel_trace.csv> [first-kernel-substring] [max rows]"""
+that precede it.  usage: python tools/timeline.py <..._kernel_trace.csv> [first-kernel-substring] [max rows] [skip]
+(skip: take the step that many occurrences before the last complete one)"""
 import collections
 import csv
 import sys
@@ -22,7 +23,11 @@ def main():
     if len(starts) < 2:
         print("need two occurrences of", first)
         return
-    lo, hi = starts[-2], starts[-1]
+    skip = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+    if len(starts) < 2 + skip:
+        print("need", 2 + skip, "occurrences of", first)
+        return
+    lo, hi = starts[-2 - skip], starts[-1 - skip]
     step = rows[lo:hi]
     t0 = step[0][0]
     print(f"step: {len(step)} launches, {(step[-1][1] - t0) / 1e3:.1f} us from first start to last end")
