@@ -384,6 +384,19 @@ def test_presplit_plane_operands_are_bit_identical(M, N, Ks):
     for name, planes in (("A", [(a, None) for a in pA]), ("B", [(None, b) for b in pB]), ("both", list(zip(pA, pB))),
                          ("mixed", [(pA[i] if i % 2 == 0 else None, pB[i] if i % 2 == 1 else None) for i in range(len(Ks))])):
         assert torch.equal(run(planes), want), name
+    # split-K: every workgroup starts in the middle of a segment list (the plane flags follow its cursor)
+    ws = torch.empty(4 * M * N + 64, device="cuda")
+    outs = []
+    for planes in (none, list(zip(pA, pB))):
+        lib.ssc_debug_set(b"gemm_f16", 1); lib.ssc_debug_set(b"large_form", 2)
+        try:
+            o = torch.full((M, N), float("nan"), device="cuda")
+            gemm(segs, M, N, 1, 1, o, splits=3, ws=ws, compact=dict(scales), planes=planes)
+            torch.cuda.synchronize()
+            outs.append(o)
+        finally:
+            lib.ssc_debug_set(b"gemm_f16", 0); lib.ssc_debug_set(b"large_form", 1)
+    assert torch.equal(outs[0], outs[1]) and float((outs[0] - want).abs().max()) < 1e-3
     # the 3xBF16 form of the same product reads the fp32 operands, whatever the planes hold
     assert torch.equal(run(list(zip(pA, pB)), f16=0), run(none, f16=0))
     # row lists on A (planes are addressed by the listed rows too)
